@@ -1,0 +1,186 @@
+/*
+ * sdfgpu.h -- C ABI of the MI355X-native signed-distance-field build path.
+ *
+ * This is the drop-in boundary for the one hot path of UM-ARM-Lab/sdf_tools:
+ *
+ *   sdf_generation::ExtractSignedDistanceField      include/sdf_tools/sdf_generation.hpp:209-271
+ *     = classify (:219-240) + BuildDistanceField x2 (:95-207, called :242-243)
+ *       + signed merge / extrema (:245-269)
+ *   its virtual-border variant                      include/sdf_tools/sdf_generation.hpp:273-420
+ *   the CollisionMapGrid predicate                  include/sdf_tools/collision_map.hpp:680-712
+ *
+ * A maintainer binds these entry points from the reference's C++ (see
+ * INTEGRATION.md); the in-tree mirror of the reference's C++ API
+ * (include/sdf_tools/ headers) and the pysdf_tools module call nothing else.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary
+ *   - voxel layout: index = x*ny*nz + y*nz + z (z fastest), the reference's
+ *     VoxelGrid layout (src/sdf_tools/sdf.cpp:241-245, utils_3d.py:71-73)
+ *   - every function returns SDFGPU_OK (0) or a negative sdfgpu_status;
+ *     nothing throws; sdfgpu_last_error() gives the message for the handle
+ *   - a handle is bound to one GPU; use one handle per host thread
+ *   - there is NO CPU fallback: without a usable HIP device sdfgpu_create fails
+ */
+#ifndef SDFGPU_H
+#define SDFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdfgpu_context* sdfgpu_handle;
+
+typedef enum sdfgpu_status {
+    SDFGPU_OK = 0,
+    SDFGPU_ERR_INVALID_ARGUMENT = -1, /* null pointer, non-positive dims, bad stride ...          */
+    SDFGPU_ERR_HIP = -2,              /* a HIP runtime call failed (maps to std::runtime_error)   */
+    SDFGPU_ERR_UNSUPPORTED_SIZE = -3, /* a dim > 16384 or nx^2+ny^2+nz^2 >= 2^30                   */
+    SDFGPU_ERR_NO_DEVICE = -4,        /* no HIP device / device index out of range                */
+    SDFGPU_ERR_UNRESOLVED = -5        /* slab x-sweep needed rows beyond the supplied halo        */
+} sdfgpu_status;
+
+/* Library version, e.g. "sdfgpu 0.1 (gfx950)". */
+const char* sdfgpu_version(void);
+
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int sdfgpu_device_count(void);
+
+/* Create / destroy a context on `device`.  The context owns the device scratch
+ * (int16 z-sweep field, int32 yz-sweep field, staging buffers) and re-uses it
+ * across calls, growing on demand -- needed for the 30 Hz streaming use. */
+int sdfgpu_create(int device, sdfgpu_handle* out_handle);
+int sdfgpu_destroy(sdfgpu_handle h);
+
+/* Message for the last non-OK status returned on this handle (never NULL).
+ * With h == NULL returns the message of the last failed sdfgpu_create. */
+const char* sdfgpu_last_error(sdfgpu_handle h);
+
+/* ---------------------------------------------------------------------------
+ * Whole-path entry points, host buffers.
+ * Replaces sdf_generation::ExtractSignedDistanceField (sdf_generation.hpp:273-420)
+ * once the caller has evaluated its predicate into `filled` (nonzero = filled),
+ * in the reference's x->y->z order (:221-239).
+ *   out_sdf : N floats, same layout.  sdf = filled ? -res*sqrt(D_free) : +res*sqrt(D_filled),
+ *             computed as float(double) exactly like :254-265; +/-inf when a class is empty.
+ *   out_max/out_min : extrema of the un-narrowed doubles (:246-269); with
+ *             add_virtual_border the (free.max, filled.min) pair of :416-418.
+ * ------------------------------------------------------------------------- */
+int sdfgpu_build(sdfgpu_handle h, const uint8_t* filled,
+                 int64_t nx, int64_t ny, int64_t nz,
+                 double resolution, int add_virtual_border,
+                 float* out_sdf, double* out_max, double* out_min);
+
+/* Fast path for CollisionMapGrid::ExtractSignedDistanceField
+ * (collision_map.hpp:680-712): `cells` is the grid's raw data
+ * (GetImmutableRawData()), records of `cell_stride` bytes whose float occupancy
+ * sits at `occupancy_offset`.  Classified on the device with exactly
+ * occupancy > 0.5f || (unknown_is_filled && occupancy == 0.5f). */
+int sdfgpu_build_cells(sdfgpu_handle h, const void* cells,
+                       size_t cell_stride, size_t occupancy_offset, int unknown_is_filled,
+                       int64_t nx, int64_t ny, int64_t nz,
+                       double resolution, int add_virtual_border,
+                       float* out_sdf, double* out_max, double* out_min);
+
+/* ---------------------------------------------------------------------------
+ * Device-pointer variants (benchmark / streaming / multi-GPU callers).
+ * All pointers are device pointers on the handle's GPU; `stream` is a
+ * hipStream_t (NULL = default stream).  Asynchronous: kernels are enqueued on
+ * `stream`, nothing is copied to the host.  Call sdfgpu_get_extrema afterwards
+ * (it synchronises `stream`) to obtain (max, min) of the most recent build.
+ * ------------------------------------------------------------------------- */
+int sdfgpu_build_device(sdfgpu_handle h, const uint8_t* d_filled,
+                        int64_t nx, int64_t ny, int64_t nz,
+                        double resolution, int add_virtual_border,
+                        float* d_out_sdf, void* stream);
+
+int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells,
+                              size_t cell_stride, size_t occupancy_offset, int unknown_is_filled,
+                              int64_t nx, int64_t ny, int64_t nz,
+                              double resolution, int add_virtual_border,
+                              float* d_out_sdf, void* stream);
+
+int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min);
+
+/* ---------------------------------------------------------------------------
+ * Stage-level entry points for the x-slab multi-GPU path.
+ * The grid is partitioned along x (the slowest axis); a rank owns rows
+ * [x0, x0+nxs).  The z and y sweeps are slab-local:
+ *
+ *   sdfgpu_sweep_zy_device : mask slab [nxs,ny,nz] -> signed squared in-plane
+ *       distance, int32 [nxs,ny,nz]  (+D for free voxels, -D for filled,
+ *       magnitude SDFGPU_DSQ_INF where the plane holds no opposite voxel).
+ *
+ * The caller exchanges `halo` boundary planes of that field with its x
+ * neighbours (RCCL send/recv) into one contiguous buffer
+ * [halo_lo + nxs + halo_hi, ny, nz] and runs
+ *
+ *   sdfgpu_sweep_x_device  : x sweep + signed merge over the extended buffer,
+ *       writing the nxs owned rows.  `lo_truncated` / `hi_truncated` say that
+ *       real grid rows exist beyond the buffer on that side.  A voxel whose
+ *       search would have needed such a row raises bit 0 of *d_status (uint32,
+ *       device, caller-zeroed); the caller all-reduces it and, if set, widens
+ *       the halo (or gathers whole lines) and re-runs.  x_global is the grid x
+ *       of the first owned row and nx_global the full grid extent (virtual
+ *       border clamp needs both).  Extrema of the owned rows go to
+ *       d_maxdsq[2] (uint32 device: max d^2 over free, over filled voxels;
+ *       caller-zeroed; all-reduce MAX then sdfgpu_extrema_from_dsq).
+ * ------------------------------------------------------------------------- */
+#define SDFGPU_DSQ_INF (1 << 30)
+
+int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled,
+                           int64_t nxs, int64_t ny, int64_t nz,
+                           int32_t* d_plane_dsq, void* stream);
+
+int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq,
+                          int64_t halo_lo, int64_t nxs, int64_t halo_hi,
+                          int64_t ny, int64_t nz,
+                          int lo_truncated, int hi_truncated,
+                          int64_t x_global, int64_t nx_global,
+                          double resolution, int add_virtual_border,
+                          float* d_out_sdf, uint32_t* d_maxdsq, uint32_t* d_status,
+                          void* stream);
+
+/* (max, min) from the two integer maxima (0 = class absent, >= SDFGPU_DSQ_INF =
+ * infinite), reproducing sdf_generation.hpp:246-269 / :416-418. */
+int sdfgpu_extrema_from_dsq(uint32_t max_dsq_free, uint32_t max_dsq_filled,
+                            double resolution, double* out_max, double* out_min);
+
+/* ---------------------------------------------------------------------------
+ * Next-row N1: grid-aligned gradient of a device-resident field,
+ * SignedDistanceField::GetGridAlignedGradient (include/sdf_tools/sdf.hpp:432-526)
+ * for every voxel at once.  d_out_grad: [nx,ny,nz,3] float64 when
+ * out_is_f64 != 0 (bit-identical to the reference's doubles) else float32.
+ * Interior voxels use central differences; edge voxels use the clamped
+ * one-sided form when enable_edge_gradients != 0, else are written as NaN
+ * (the reference returns an empty vector there).
+ * ------------------------------------------------------------------------- */
+int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf,
+                           int64_t nx, int64_t ny, int64_t nz,
+                           double resolution, int enable_edge_gradients,
+                           void* d_out_grad, int out_is_f64, void* stream);
+
+/* Debug / test hooks: copy the intermediates of the most recent
+ * sdfgpu_build*_device call to host buffers (N int16 / N int32). */
+int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n);
+int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
+
+/* Per-stage timing with HIP events recorded on the build's own stream (bench.py's roofline leg).
+ * While enabled, every sdfgpu_build*_device call brackets K1 (z sweep), K2 (y sweep) and
+ * K3 (x sweep + merge) with events.  sdfgpu_get_stage_times synchronises, adds the elapsed
+ * times since the last call into out_ms_sum[3] (milliseconds) and returns the number of
+ * builds they cover in *out_builds, then resets the accumulators. */
+int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
+int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
+
+/* Tuning hook (benchmarks): rows marched per thread in the y / x sweeps
+ * (0 = automatic). */
+int sdfgpu_set_tuning(sdfgpu_handle h, int rows_per_chunk_y, int rows_per_chunk_x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFGPU_H */

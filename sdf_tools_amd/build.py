@@ -1,0 +1,84 @@
+"""In-tree builds of the native pieces (no network, no cmake needed).
+
+  libsdfgpu.so   HIP kernels + C ABI (include/sdfgpu.h), hipcc --offload-arch=gfx950
+  pysdf_tools    pybind11 module mirroring the reference's src/sdf_tools/bindings.cpp
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the CPU container;
+the built .so files travel to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(PKG, "libsdfgpu.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.exists(c) or c == "hipcc":
+            return c
+
+
+def build_libsdfgpu(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, "sdfgpu.hip"), os.path.join(CSRC, "sdfgpu_kernels.hpp"),
+            os.path.join(INCLUDE, "sdfgpu.h")]
+    if not force and not _newer(LIB, srcs):
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", INCLUDE, srcs[0], "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def pysdf_tools_path():
+    suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    return os.path.join(PKG, "pysdf_tools" + suffix)
+
+
+def build_pysdf_tools(force=False, verbose=False):
+    import pybind11
+
+    src = os.path.join(CSRC, "pysdf_tools.cpp")
+    if not os.path.exists(src):
+        return None
+    out = pysdf_tools_path()
+    hdr_dir = os.path.join(INCLUDE, "sdf_tools")
+    deps = [src, os.path.join(INCLUDE, "sdfgpu.h")] + \
+        [os.path.join(hdr_dir, f) for f in sorted(os.listdir(hdr_dir))] + \
+        [os.path.join(INCLUDE, "arc_utilities", f) for f in sorted(os.listdir(os.path.join(INCLUDE, "arc_utilities")))]
+    if not force and not _newer(out, deps):
+        return out
+    build_libsdfgpu(force=False, verbose=verbose)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-I", INCLUDE, "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
+           src, "-o", out, "-L", PKG, "-lsdfgpu", "-Wl,-rpath,$ORIGIN", "-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    out = [build_libsdfgpu(force, verbose)]
+    p = build_pysdf_tools(force, verbose)
+    if p:
+        out.append(p)
+    return out
+
+
+if __name__ == "__main__":
+    print("\n".join(build_all(force="--force" in sys.argv, verbose=True)))

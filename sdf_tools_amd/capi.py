@@ -1,0 +1,209 @@
+"""ctypes binding of the C ABI in include/sdfgpu.h (libsdfgpu.so).
+
+This is the thin Python face of the drop-in boundary; it carries no compute.
+If the HIP library is missing or no GPU is usable every entry point raises --
+there is deliberately no CPU fallback (the CPU oracle lives in oracle/ and is
+test infrastructure only).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SDFGPU_DSQ_INF = 1 << 30
+_STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "HIP", -3: "UNSUPPORTED_SIZE", -4: "NO_DEVICE", -5: "UNRESOLVED"}
+
+# every symbol include/sdfgpu.h declares (tests check that the library exports them all)
+EXPORTS = [
+    "sdfgpu_version", "sdfgpu_device_count", "sdfgpu_create", "sdfgpu_destroy", "sdfgpu_last_error",
+    "sdfgpu_build", "sdfgpu_build_cells", "sdfgpu_build_device", "sdfgpu_build_cells_device",
+    "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
+    "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
+    "sdfgpu_set_profiling", "sdfgpu_get_stage_times",
+]
+
+
+class SdfGpuError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("sdfgpu %s (%d): %s" % (_STATUS.get(code, "?"), code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen sdf_tools_amd/libsdfgpu.so (must have been built: see build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise ImportError("libsdfgpu.so is not built (run `python -m sdf_tools_amd.build`); "
+                          "there is no CPU fallback for the SDF build path")
+    # torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Import it first so the
+    # dynamic loader binds libsdfgpu.so to the HIP runtime torch uses: streams and device pointers
+    # are then shared by both.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional plumbing
+        pass
+    L = ctypes.CDLL(path)
+    i64, dbl, ci, vp, sz = ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    u32 = ctypes.c_uint32
+    L.sdfgpu_version.restype = ctypes.c_char_p
+    L.sdfgpu_device_count.restype = ci
+    L.sdfgpu_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.sdfgpu_destroy.argtypes = [vp]
+    L.sdfgpu_last_error.argtypes = [vp]
+    L.sdfgpu_last_error.restype = ctypes.c_char_p
+    L.sdfgpu_build.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_build_cells.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp]
+    L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
+    L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
+    L.sdfgpu_sweep_zy_device.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.sdfgpu_sweep_x_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, ci, ci, i64, i64, dbl, ci, vp, vp, vp, vp]
+    L.sdfgpu_extrema_from_dsq.argtypes = [u32, u32, dbl, vp, vp]
+    L.sdfgpu_gradient_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci, vp]
+    L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
+    L.sdfgpu_debug_copy_yzsweep.argtypes = [vp, vp, i64]
+    L.sdfgpu_set_tuning.argtypes = [vp, ci, ci]
+    L.sdfgpu_set_profiling.argtypes = [vp, ci]
+    L.sdfgpu_get_stage_times.argtypes = [vp, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int or name not in ("sdfgpu_version", "sdfgpu_last_error"):
+            fn.restype = ci
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(load_library().sdfgpu_device_count())
+
+
+def extrema_from_dsq(max_dsq_free, max_dsq_filled, resolution):
+    """Host helper (no GPU needed): (max, min) from the integer maxima, as sdf_generation.hpp:246-269."""
+    out = (ctypes.c_double * 2)()
+    load_library().sdfgpu_extrema_from_dsq(int(max_dsq_free), int(max_dsq_filled), float(resolution),
+                                           ctypes.byref(out, 0), ctypes.byref(out, 8))
+    return float(out[0]), float(out[1])
+
+
+class SdfGpu:
+    """One context on one GPU (wraps sdfgpu_create / sdfgpu_destroy)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.sdfgpu_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise SdfGpuError(rc, self._lib.sdfgpu_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdfgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SdfGpuError(rc, self._lib.sdfgpu_last_error(self._h).decode())
+
+    # ---- host-buffer API -------------------------------------------------
+    def build(self, filled, resolution=1.0, add_virtual_border=False):
+        """filled: uint8/bool [nx,ny,nz].  Returns (sdf float32 [nx,ny,nz], (max, min))."""
+        m = np.ascontiguousarray(filled, dtype=np.uint8)
+        if m.ndim != 3:
+            raise ValueError("mask must be [nx, ny, nz]")
+        out = np.empty(m.shape, dtype=np.float32)
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_build(self._h, m.ctypes.data, *m.shape, float(resolution),
+                                           int(bool(add_virtual_border)), out.ctypes.data,
+                                           ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return out, (float(ext[0]), float(ext[1]))
+
+    def build_cells(self, cells, shape, cell_stride=8, occupancy_offset=0, unknown_is_filled=False,
+                    resolution=1.0, add_virtual_border=False):
+        """cells: raw COLLISION_CELL records (any contiguous array of nx*ny*nz*cell_stride bytes)."""
+        c = np.ascontiguousarray(cells)
+        nx, ny, nz = (int(s) for s in shape)
+        if c.nbytes != nx * ny * nz * cell_stride:
+            raise ValueError("cells buffer size does not match shape * cell_stride")
+        out = np.empty((nx, ny, nz), dtype=np.float32)
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_build_cells(self._h, c.ctypes.data, cell_stride, occupancy_offset,
+                                                 int(bool(unknown_is_filled)), nx, ny, nz, float(resolution),
+                                                 int(bool(add_virtual_border)), out.ctypes.data,
+                                                 ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return out, (float(ext[0]), float(ext[1]))
+
+    # ---- device-pointer API (raw integers: tensor.data_ptr(), stream.cuda_stream) -------------
+    def build_device(self, d_filled, shape, d_out, resolution=1.0, add_virtual_border=False, stream=0):
+        nx, ny, nz = (int(s) for s in shape)
+        self._check(self._lib.sdfgpu_build_device(self._h, d_filled, nx, ny, nz, float(resolution),
+                                                  int(bool(add_virtual_border)), d_out, stream or None))
+
+    def build_cells_device(self, d_cells, shape, d_out, cell_stride=8, occupancy_offset=0,
+                           unknown_is_filled=False, resolution=1.0, add_virtual_border=False, stream=0):
+        nx, ny, nz = (int(s) for s in shape)
+        self._check(self._lib.sdfgpu_build_cells_device(self._h, d_cells, cell_stride, occupancy_offset,
+                                                        int(bool(unknown_is_filled)), nx, ny, nz,
+                                                        float(resolution), int(bool(add_virtual_border)),
+                                                        d_out, stream or None))
+
+    def get_extrema(self):
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_get_extrema(self._h, ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return float(ext[0]), float(ext[1])
+
+    def sweep_zy_device(self, d_filled, slab_shape, d_plane_dsq, stream=0):
+        nxs, ny, nz = (int(s) for s in slab_shape)
+        self._check(self._lib.sdfgpu_sweep_zy_device(self._h, d_filled, nxs, ny, nz, d_plane_dsq, stream or None))
+
+    def sweep_x_device(self, d_plane_dsq, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated,
+                       x_global, nx_global, resolution, add_virtual_border, d_out, d_maxdsq, d_status, stream=0):
+        self._check(self._lib.sdfgpu_sweep_x_device(self._h, d_plane_dsq, int(halo_lo), int(nxs), int(halo_hi),
+                                                    int(ny), int(nz), int(bool(lo_truncated)),
+                                                    int(bool(hi_truncated)), int(x_global), int(nx_global),
+                                                    float(resolution), int(bool(add_virtual_border)),
+                                                    d_out, d_maxdsq, d_status or None, stream or None))
+
+    def gradient_device(self, d_sdf, shape, d_out, resolution=1.0, enable_edge_gradients=True, f64=True, stream=0):
+        nx, ny, nz = (int(s) for s in shape)
+        self._check(self._lib.sdfgpu_gradient_device(self._h, d_sdf, nx, ny, nz, float(resolution),
+                                                     int(bool(enable_edge_gradients)), d_out, int(bool(f64)),
+                                                     stream or None))
+
+    def debug_zsweep(self, shape):
+        out = np.empty(shape, dtype=np.int16)
+        self._check(self._lib.sdfgpu_debug_copy_zsweep(self._h, out.ctypes.data, out.size))
+        return out
+
+    def debug_yzsweep(self, shape):
+        out = np.empty(shape, dtype=np.int32)
+        self._check(self._lib.sdfgpu_debug_copy_yzsweep(self._h, out.ctypes.data, out.size))
+        return out
+
+    def set_profiling(self, enable=True):
+        self._check(self._lib.sdfgpu_set_profiling(self._h, int(bool(enable))))
+
+    def get_stage_times(self):
+        """(ms_sum[3] for K1/K2/K3, builds) since the last call; synchronises."""
+        ms = (ctypes.c_double * 3)()
+        n = ctypes.c_int64()
+        self._check(self._lib.sdfgpu_get_stage_times(self._h, ms, ctypes.byref(n)))
+        return [float(v) for v in ms], int(n.value)
+
+    def set_tuning(self, rows_per_chunk_y=0, rows_per_chunk_x=0):
+        self._check(self._lib.sdfgpu_set_tuning(self._h, int(rows_per_chunk_y), int(rows_per_chunk_x)))

@@ -1,0 +1,457 @@
+// sdfgpu.hip -- C ABI (include/sdfgpu.h) over the gfx950 kernels in sdfgpu_kernels.hpp.
+// Host side of the drop-in boundary for sdf_generation::ExtractSignedDistanceField
+// (reference include/sdf_tools/sdf_generation.hpp:209-420).  No CPU fallback.
+#include "sdfgpu_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfgpu.h"
+
+using namespace sdfgpu;
+
+namespace {
+
+constexpr int kH = 3;            // register-window radius of the marching sweeps
+constexpr int64_t kMaxDim = 16384;
+
+thread_local std::string g_create_error = "";
+
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct sdfgpu_context {
+    int device = 0;
+    std::string error;
+    DeviceBuffer zfield;     // int16 [N]   K1 output
+    DeviceBuffer yzfield;    // int32 [N]   K2 output
+    DeviceBuffer stage_in;   // host-API staging: mask / cells
+    DeviceBuffer stage_out;  // host-API staging: sdf
+    uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] pad
+    hipStream_t last_stream = nullptr;
+    double last_resolution = 1.0;
+    int64_t last_n = 0;
+    bool have_result = false;
+    int tune_ty = 0, tune_tx = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> events;   // 4 per profiled build: before K1, after K1, after K2, after K3
+};
+
+namespace {
+
+int fail(sdfgpu_handle h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) at %s", (int)e_,            \
+                        hipGetErrorString(e_), #expr);                                    \
+    } while (0)
+
+int ensure(sdfgpu_handle h, DeviceBuffer& b, size_t bytes) {
+    if (b.bytes >= bytes && b.ptr) return SDFGPU_OK;
+    if (b.ptr) { HIP_TRY(h, hipFree(b.ptr)); b.ptr = nullptr; b.bytes = 0; }
+    HIP_TRY(h, hipMalloc(&b.ptr, std::max<size_t>(bytes, 256)));
+    b.bytes = std::max<size_t>(bytes, 256);
+    return SDFGPU_OK;
+}
+
+// The EDT is symmetric under axis renaming, and a grid with singleton axes has
+// the same memory layout when those axes are moved to the front (index =
+// x*ny*nz + y*nz + z).  Canonicalising keeps the contiguous axis long, so 2-D
+// grids (the reference's test_bindings.py case is 20x40x1) sweep coalesced.
+void canonical_dims(int64_t& nx, int64_t& ny, int64_t& nz) {
+    if (nz == 1) { nz = ny; ny = nx; nx = 1; }
+    if (nz == 1) { nz = ny; ny = nx; nx = 1; }
+    if (ny == 1) { ny = nx; nx = 1; }
+}
+
+int check_dims(sdfgpu_handle h, int64_t nx, int64_t ny, int64_t nz) {
+    if (nx <= 0 || ny <= 0 || nz <= 0)
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid dimensions must be positive (got %lld x %lld x %lld)",
+                    (long long)nx, (long long)ny, (long long)nz);
+    if (nx > kMaxDim || ny > kMaxDim || nz > kMaxDim || nx * nx + ny * ny + nz * nz >= (int64_t)kInf32)
+        return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE,
+                    "grid %lld x %lld x %lld exceeds the supported extent (dims <= 16384, nx^2+ny^2+nz^2 < 2^30)",
+                    (long long)nx, (long long)ny, (long long)nz);
+    return SDFGPU_OK;
+}
+
+int rows_per_block(int nz) {
+    const int W = (nz + 63) / 64;
+    return std::max(1, 4096 / (W * 64));
+}
+
+// K1 launch.  cells == nullptr -> uint8 mask.
+int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, size_t stride, size_t off,
+                   int unknown, int64_t nx, int64_t ny, int64_t nz, int16_t* d_out, hipStream_t s) {
+    const int64_t nrows = nx * ny;
+    const int rpb = rows_per_block((int)nz);
+    const int W = ((int)nz + 63) / 64;
+    const size_t lds = (size_t)rpb * W * 8;
+    const int64_t nblocks = (nrows + rpb - 1) / rpb;
+    if (nblocks > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "too many z rows");
+    dim3 grid((unsigned)nblocks), block(kBlock);
+    if (d_cells) {
+        CellLoader ld{reinterpret_cast<const char*>(d_cells), (int64_t)stride, (int64_t)off, unknown};
+        hipLaunchKernelGGL(k_sweep_z_generic<CellLoader>, grid, block, lds, s, ld, d_out, nrows, (int)nz, rpb);
+    } else if ((nz % 16) == 0 && (reinterpret_cast<uintptr_t>(d_mask) % 16) == 0) {
+        hipLaunchKernelGGL(k_sweep_z_vec16, grid, block, lds, s, d_mask, d_out, nrows, (int)nz, rpb);
+    } else {
+        MaskLoader ld{d_mask};
+        hipLaunchKernelGGL(k_sweep_z_generic<MaskLoader>, grid, block, lds, s, ld, d_out, nrows, (int)nz, rpb);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
+int pick_T(int user, int span) {
+    int T = user > 0 ? user : 64;
+    T = std::max(T, 2 * kH + 1);
+    return std::min(T, std::max(span, 1));
+}
+
+template <int STAGE, bool VB>
+int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s) {
+    const int span = a.out_hi - a.out_lo;
+    const int nchunks = (span + a.T - 1) / a.T;
+    const int64_t nbx = (a.ncols + kBlock - 1) / kBlock;
+    if (nbx > 0x7fffffffLL || nchunks > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "sweep grid too large");
+    dim3 grid((unsigned)nbx, (unsigned)nchunks), block(kBlock);
+    if (vec4) hipLaunchKernelGGL((k_sweep_march<STAGE, 4, kH, VB>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_march<STAGE, 1, kH, VB>), grid, block, 0, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
+// K2 launch: int16 z field -> int32 in-plane signed d^2
+int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, int32_t* d_out, int64_t nx, int64_t ny, int64_t nz,
+                   hipStream_t s) {
+    const bool vec4 = (nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_in) % 8) == 0 &&
+                      (reinterpret_cast<uintptr_t>(d_out) % 16) == 0;
+    const int V = vec4 ? 4 : 1;
+    SweepArgs a{};
+    a.in = d_in; a.out = d_out;
+    a.cpl = nz / V;
+    a.ncols = nx * a.cpl;
+    a.outer_stride = ny * nz;
+    a.line_stride = nz;
+    a.L = (int)ny; a.out_lo = 0; a.out_hi = (int)ny;
+    a.T = pick_T(h->tune_ty, (int)ny);
+    return launch_march<2, false>(h, a, vec4, s);
+}
+
+// K3 launch: int32 plane field (optionally with x halo) -> fp32 sdf
+int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t halo_lo, int64_t nxs,
+                   int64_t halo_hi, int64_t ny, int64_t nz, int lo_trunc, int hi_trunc, int64_t x_global,
+                   int64_t nx_global, double resolution, int vb, uint32_t* d_maxdsq, uint32_t* d_status,
+                   hipStream_t s) {
+    const int64_t plane = ny * nz;
+    const bool vec4 = (plane % 4) == 0 && (reinterpret_cast<uintptr_t>(d_in) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(d_out) % 16) == 0;
+    const int V = vec4 ? 4 : 1;
+    SweepArgs a{};
+    a.in = d_in; a.out = d_out;
+    a.ncols = plane / V;
+    a.cpl = a.ncols;
+    a.outer_stride = 0;
+    a.line_stride = plane;
+    a.L = (int)(halo_lo + nxs + halo_hi);
+    a.out_lo = (int)halo_lo; a.out_hi = (int)(halo_lo + nxs);
+    a.T = pick_T(h->tune_tx, (int)nxs);
+    a.resolution = resolution;
+    a.lo_truncated = lo_trunc; a.hi_truncated = hi_trunc;
+    a.x_global = x_global; a.nx_global = nx_global; a.ny = ny; a.nz = nz;
+    a.maxdsq = d_maxdsq; a.status = d_status;
+    return vb ? launch_march<3, true>(h, a, vec4, s) : launch_march<3, false>(h, a, vec4, s);
+}
+
+int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_cells, size_t stride, size_t off,
+                      int unknown, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
+                      float* d_out, hipStream_t s) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if ((!d_filled && !d_cells) || !d_out) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    if (d_cells && (stride < 4 || (stride % 4) || (off % 4) || off + 4 > stride))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    canonical_dims(nx, ny, nz);
+    const int64_t n = nx * ny * nz;
+    if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
+    if (int rc = ensure(h, h->yzfield, (size_t)n * 4)) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 16, s));
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (h->profiling) {
+        for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
+        HIP_TRY(h, hipEventRecord(ev[0], s));
+    }
+    if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
+                                (int16_t*)h->zfield.ptr, s)) return rc;
+    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[1], s));
+    if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, (int32_t*)h->yzfield.ptr, nx, ny, nz, s)) return rc;
+    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[2], s));
+    if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
+                                resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+    if (h->profiling) {
+        HIP_TRY(h, hipEventRecord(ev[3], s));
+        for (auto e : ev) h->events.push_back(e);
+    }
+    h->last_stream = s;
+    h->last_resolution = resolution;
+    h->last_n = n;
+    h->have_result = true;
+    return SDFGPU_OK;
+}
+
+int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t stride, size_t off,
+                    int unknown, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb, float* out_sdf,
+                    double* out_max, double* out_min) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if ((!filled && !cells) || !out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t n = nx * ny * nz;
+    const size_t in_bytes = cells ? (size_t)n * stride : (size_t)n;
+    if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
+    if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
+    HIP_TRY(h, hipMemcpy(h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes, hipMemcpyHostToDevice));
+    int rc = build_device_impl(h, cells ? nullptr : (const uint8_t*)h->stage_in.ptr,
+                               cells ? h->stage_in.ptr : nullptr, stride, off, unknown, nx, ny, nz, resolution,
+                               vb, (float*)h->stage_out.ptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(out_sdf, h->stage_out.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    double mx, mn;
+    rc = sdfgpu_get_extrema(h, &mx, &mn);
+    if (rc) return rc;
+    if (out_max) *out_max = mx;
+    if (out_min) *out_min = mn;
+    return SDFGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sdfgpu_version(void) { return "sdfgpu 0.1 (gfx950, HIP)"; }
+
+int sdfgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
+    if (!out_handle) return fail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "out_handle is null");
+    *out_handle = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, SDFGPU_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(nullptr, SDFGPU_ERR_NO_DEVICE, "device index %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    sdfgpu_context* ctx = new (std::nothrow) sdfgpu_context();
+    if (!ctx) return fail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
+    ctx->device = device;
+    if (hipMalloc((void**)&ctx->d_small, 256) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, SDFGPU_ERR_HIP, "hipMalloc failed for context scratch");
+    }
+    *out_handle = ctx;
+    return SDFGPU_OK;
+}
+
+int sdfgpu_destroy(sdfgpu_handle h) {
+    if (!h) return SDFGPU_OK;
+    (void)hipSetDevice(h->device);
+    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->stage_in, &h->stage_out})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (h->d_small) (void)hipFree(h->d_small);
+    for (auto e : h->events) (void)hipEventDestroy(e);
+    delete h;
+    return SDFGPU_OK;
+}
+
+const char* sdfgpu_last_error(sdfgpu_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int sdfgpu_build(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                 int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    return build_host_impl(h, filled, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, out_sdf,
+                           out_max, out_min);
+}
+
+int sdfgpu_build_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                       int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                       int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    if (h && !cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cells is null");
+    if (h && (cell_stride < 4 || (cell_stride % 4) || (occupancy_offset % 4) || occupancy_offset + 4 > cell_stride))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
+    return build_host_impl(h, nullptr, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz,
+                           resolution, add_virtual_border, out_sdf, out_max, out_min);
+}
+
+int sdfgpu_build_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nx, int64_t ny, int64_t nz,
+                        double resolution, int add_virtual_border, float* d_out_sdf, void* stream) {
+    if (h && !d_filled) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_filled is null");
+    return build_device_impl(h, d_filled, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, d_out_sdf,
+                             (hipStream_t)stream);
+}
+
+int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
+                              int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                              int add_virtual_border, float* d_out_sdf, void* stream) {
+    if (h && !d_cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_cells is null");
+    return build_device_impl(h, nullptr, d_cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz,
+                             resolution, add_virtual_border, d_out_sdf, (hipStream_t)stream);
+}
+
+int sdfgpu_extrema_from_dsq(uint32_t max_dsq_free, uint32_t max_dsq_filled, double resolution, double* out_max,
+                            double* out_min) {
+    const double inf = std::numeric_limits<double>::infinity();
+    // sdf_generation.hpp:246-269: max is attained on a free voxel, min on a filled one;
+    // an absent class leaves the running value at its -inf / +inf start or at the
+    // other class's infinite distance (all-free -> (inf, inf); all-filled -> (-inf, -inf)).
+    double mx, mn;
+    if (max_dsq_free == 0) mx = -inf;
+    else if (max_dsq_free >= (uint32_t)kInf32) mx = inf;
+    else mx = std::sqrt((double)max_dsq_free) * resolution;
+    if (max_dsq_filled == 0) mn = inf;
+    else if (max_dsq_filled >= (uint32_t)kInf32) mn = -inf;
+    else mn = 0.0 - std::sqrt((double)max_dsq_filled) * resolution;
+    if (out_max) *out_max = mx;
+    if (out_min) *out_min = mn;
+    return SDFGPU_OK;
+}
+
+int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!h->have_result) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no build has been issued on this handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    uint32_t v[4];
+    HIP_TRY(h, hipMemcpyAsync(v, h->d_small, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    return sdfgpu_extrema_from_dsq(v[0], v[1], h->last_resolution, out_max, out_min);
+}
+
+int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
+                           int32_t* d_plane_dsq, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_filled || !d_plane_dsq) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (int rc = check_dims(h, nxs, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t n = nxs * ny * nz;
+    if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = launch_sweep_z(h, d_filled, nullptr, 0, 0, 0, nxs, ny, nz, (int16_t*)h->zfield.ptr, s)) return rc;
+    return launch_sweep_y(h, (const int16_t*)h->zfield.ptr, d_plane_dsq, nxs, ny, nz, s);
+}
+
+int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t halo_lo, int64_t nxs,
+                          int64_t halo_hi, int64_t ny, int64_t nz, int lo_truncated, int hi_truncated,
+                          int64_t x_global, int64_t nx_global, double resolution, int add_virtual_border,
+                          float* d_out_sdf, uint32_t* d_maxdsq, uint32_t* d_status, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_plane_dsq || !d_out_sdf || !d_maxdsq)
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (halo_lo < 0 || halo_hi < 0 || x_global < 0 || x_global + nxs > nx_global)
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "inconsistent slab geometry");
+    if (int rc = check_dims(h, halo_lo + nxs + halo_hi, ny, nz)) return rc;
+    if (int rc = check_dims(h, nx_global, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_sweep_x(h, d_plane_dsq, d_out_sdf, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated,
+                          x_global, nx_global, resolution, add_virtual_border, d_maxdsq, d_status,
+                          (hipStream_t)stream);
+}
+
+int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz,
+                           double resolution, int enable_edge_gradients, void* d_out_grad, int out_is_f64,
+                           void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_sdf || !d_out_grad) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t n = nx * ny * nz;
+    dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_is_f64)
+        hipLaunchKernelGGL(k_gradient<double>, grid, block, 0, s, d_sdf, (double*)d_out_grad, nx, ny, nz, resolution,
+                           enable_edge_gradients);
+    else
+        hipLaunchKernelGGL(k_gradient<float>, grid, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution,
+                           enable_edge_gradients);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
+int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {
+    if (!h || !out_host) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!h->have_result || n > h->last_n) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no matching build");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    HIP_TRY(h, hipMemcpy(out_host, h->zfield.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n) {
+    if (!h || !out_host) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!h->have_result || n > h->last_n) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no matching build");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    HIP_TRY(h, hipMemcpy(out_host, h->yzfield.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_set_profiling(sdfgpu_handle h, int enable) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    h->profiling = enable != 0;
+    return SDFGPU_OK;
+}
+
+int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds) {
+    if (!h || !out_ms_sum || !out_builds) return SDFGPU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    out_ms_sum[0] = out_ms_sum[1] = out_ms_sum[2] = 0.0;
+    *out_builds = 0;
+    if (h->events.empty()) return SDFGPU_OK;
+    HIP_TRY(h, hipEventSynchronize(h->events.back()));
+    for (size_t i = 0; i + 3 < h->events.size(); i += 4) {
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->events[i + k], h->events[i + k + 1]));
+            out_ms_sum[k] += ms;
+        }
+        ++*out_builds;
+    }
+    for (auto e : h->events) (void)hipEventDestroy(e);
+    h->events.clear();
+    return SDFGPU_OK;
+}
+
+int sdfgpu_set_tuning(sdfgpu_handle h, int rows_per_chunk_y, int rows_per_chunk_x) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    h->tune_ty = rows_per_chunk_y;
+    h->tune_tx = rows_per_chunk_x;
+    return SDFGPU_OK;
+}
+
+}  // extern "C"

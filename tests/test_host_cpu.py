@@ -1,0 +1,69 @@
+"""CPU: host logic that needs no GPU -- the C-ABI library loads and exports every declared
+symbol, fails loudly without a device, and the synthetic-input generators are deterministic."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sdf_tools_amd import capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sdfgpu.h")).read()
+    declared = set(re.findall(r"\b(sdfgpu_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sdfgpu_context", "sdfgpu_status", "sdfgpu_handle"}
+    assert declared == set(capi.EXPORTS)
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.sdfgpu_version()
+
+
+def test_library_contains_gfx950_code_object():
+    data = open(os.path.join(ROOT, "sdf_tools_amd", "libsdfgpu.so"), "rb").read()
+    assert b"gfx950" in data and b"k_sweep_march" in data
+
+
+def test_no_device_fails_loudly_without_fallback():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.SdfGpuError) as ei:
+        capi.SdfGpu(0)
+    assert ei.value.code == -4 and "no CPU fallback" in str(ei.value)
+
+
+def test_extrema_from_dsq_semantics():
+    # sdf_generation.hpp:246-269 (and :416-418 for the virtual-border pair)
+    inf = math.inf
+    assert capi.extrema_from_dsq(3, 2, 1.0) == (math.sqrt(3.0), -math.sqrt(2.0))
+    assert capi.extrema_from_dsq(1 << 30, 0, 1.0) == (inf, inf)        # all free
+    assert capi.extrema_from_dsq(0, 1 << 30, 1.0) == (-inf, -inf)      # all filled
+    assert capi.extrema_from_dsq(64, 0, 1.0) == (8.0, inf)             # vb, all free 16^3
+    assert capi.extrema_from_dsq(0, 64, 1.0) == (-inf, -8.0)           # vb, all filled 16^3
+    mx, mn = capi.extrema_from_dsq(12, 27, 0.01)
+    assert mx == math.sqrt(12.0) * 0.01 and mn == 0.0 - math.sqrt(27.0) * 0.01
+
+
+def test_bernoulli_mask_is_counter_based():
+    full = synth.bernoulli_mask((12, 10, 16), 0.5, 3)
+    slab = synth.bernoulli_mask((12, 10, 16), 0.5, 3, x_range=(4, 9))
+    assert np.array_equal(full[4:9], slab)
+    assert abs(full.mean() - 0.5) < 0.05
+    assert not np.array_equal(full, synth.bernoulli_mask((12, 10, 16), 0.5, 4))
+    sparse = synth.bernoulli_mask((32, 32, 32), 0.01, 1)
+    assert 0.003 < sparse.mean() < 0.03
+
+
+def test_bernoulli_mask_torch_matches_numpy():
+    torch = pytest.importorskip("torch")
+    a = synth.bernoulli_mask((7, 9, 16), 0.5, 5, x_range=(2, 6))
+    b = synth.bernoulli_mask_torch((7, 9, 16), 0.5, 5, x_range=(2, 6), device="cpu").numpy()
+    assert np.array_equal(a, b)
+    a = synth.bernoulli_mask((5, 5, 8), 0.93, 9)
+    b = synth.bernoulli_mask_torch((5, 5, 8), 0.93, 9, device="cpu").numpy()
+    assert np.array_equal(a, b)
