@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- SDF build throughput on MI355X (BASELINE.json metric: Mvoxels/s, % HBM roofline).
+
+A "step" is one pass of the hot path over one synthetic occupancy grid: device-resident uint8
+mask -> device-resident fp32 signed distance field + extrema, through the C ABI
+(libsdfgpu.so).  Inputs are i.i.d. Bernoulli(p = 0.5) occupancy,
+generated directly in HBM before the timed region.
+
+  N = 1 : 512^3 (the configuration the metric is quoted on)
+  N > 1 : one process per GPU (torchrun), the grid cut into x slabs with an RCCL halo exchange
+          (sdf_tools_amd/slab.py); weak scaling at 134 Mvoxel per GPU:
+          N=2 1024x512x512, N=4 1024x1024x512, N=8 1024^3 (the metric's 8-GPU configuration)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# Algorithmic bytes per voxel: uint8 mask in, int16 / int32 intermediates, fp32 out
+B_ALG = {"sweep_z": 1 + 2, "sweep_y": 2 + 4, "sweep_x": 4 + 4}
+B_ALG_TOTAL = 17
+KERNEL_NAMES = {"sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,4,3,false>",
+                "sweep_x": "k_sweep_march<3,4,3,false>"}
+
+GRIDS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, nargs=3, default=None, help="override grid nx ny nz")
+    ap.add_argument("--p", type=float, default=0.5, help="Bernoulli occupancy probability")
+    ap.add_argument("--resolution", type=float, default=0.01)
+    ap.add_argument("--halo", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the cube timed on the CPU oracle")
+    ap.add_argument("--tune", type=int, nargs=2, default=None, help="rows per chunk: y x")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_n, p, resolution):
+    """Times the CPU oracle (kind = "port": the C restatement of the reference's single-threaded
+    bucket-queue BuildDistanceField path) on a bounded sample of the same workload."""
+    import numpy as np  # noqa: F401
+
+    from oracle import oracle as O
+    from sdf_tools_amd import synth
+
+    m = synth.bernoulli_mask((sample_n,) * 3, p, 1)
+    t0 = time.perf_counter()
+    O.reference_sdf(m, resolution)
+    dt = time.perf_counter() - t0
+    return {"value": round(m.size / dt / 1e6, 4), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "host_cores": os.cpu_count(), "seconds": round(dt, 2),
+            "sample": "%d^3 Bernoulli(p=%g) occupancy grid, same generator and resolution as the GPU workload; "
+                      "single-threaded like the reference" % (sample_n, p)}
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/*_traffic.json), if any."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from sdf_tools_amd import capi, slab, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the SDF build path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    shape = tuple(args.size) if args.size else GRIDS.get(world, (128 * world, 1024, 1024))
+    nx, ny, nz = shape
+    n_total = nx * ny * nz
+    res = args.resolution
+    stream = torch.cuda.current_stream(dev)
+
+    if world == 1:
+        ctx = capi.SdfGpu(local_rank)
+        if args.tune:
+            ctx.set_tuning(*args.tune)
+        mask = synth.bernoulli_mask_torch(shape, args.p, 1, device=dev)
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+
+        def step():
+            ctx.build_device(mask.data_ptr(), shape, out.data_ptr(), res, False, stream.cuda_stream)
+    else:
+        stages = slab.HipStages(local_rank)
+        ctx = stages.ctx
+        if args.tune:
+            ctx.set_tuning(*args.tune)
+        x0, x1 = slab.slab_range(nx, rank, world)
+        mask = synth.bernoulli_mask_torch(shape, args.p, 1, x_range=(x0, x1), device=dev)
+        builder = slab.SlabSdfBuilder(stages, shape, res, False, halo=args.halo, rank=rank, world=world)
+
+        def step():
+            builder.build(mask)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if world == 1:
+        ctx.get_stage_times()           # drop anything recorded so far
+        ctx.set_profiling(True)         # HIP events on the launch stream around K1/K2/K3
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total / (dt / args.steps) / 1e6
+    result = {
+        "metric": "Mvoxels/sec SDF build", "value": round(value, 2), "unit": "Mvoxels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "%dx%dx%d uint8 occupancy grid, Bernoulli(p=%g) seed 1, resolution %g, "
+                               "no virtual border; device-resident mask -> device-resident fp32 SDF + extrema"
+                               % (nx, ny, nz, args.p, res),
+                   "grid": list(shape), "voxels": n_total,
+                   "partition": "single GPU" if world == 1 else "x-slab x%d, RCCL halo %d planes" % (world, args.halo)},
+    }
+
+    if world == 1:
+        ms_sum, builds = ctx.get_stage_times()
+        ctx.set_profiling(False)
+        mx, mn = ctx.get_extrema()
+        result["extrema"] = [mx, mn]
+        if builds:
+            stage_ms = dict(zip(("sweep_z", "sweep_y", "sweep_x"), (v / builds for v in ms_sum)))
+            dom = max(stage_ms, key=stage_ms.get)
+            achieved = n_total * B_ALG[dom] / (stage_ms[dom] * 1e-3) / 1e9
+            traffic = load_traffic()
+            kernel_ms = sum(stage_ms.values())
+            result["roofline"] = {
+                "bound": "hbm", "kernel": KERNEL_NAMES[dom], "stage": dom,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": (traffic or {}).get(dom),
+                "alg_bytes_per_voxel": B_ALG[dom], "avg_ms": round(stage_ms[dom], 4),
+                "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                "pipeline": {"alg_bytes_per_voxel": B_ALG_TOTAL, "kernel_ms": round(kernel_ms, 4),
+                             "achieved": round(n_total * B_ALG_TOTAL / (kernel_ms * 1e-3) / 1e9, 1),
+                             "frac": round(n_total * B_ALG_TOTAL / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            }
+    else:
+        result["fallbacks"] = builder.fallbacks
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.p, res)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""GPU: the slab-mode stage entry points (sdfgpu_sweep_zy_device / sdfgpu_sweep_x_device) that the
+multi-GPU path is built from.  One GPU plays every rank in turn; the "exchange" is a tensor copy.
+The RCCL exchange itself (sdf_tools_amd/slab.py) is covered on CPU with gloo (test_slab_gloo.py)
+and runs for real in `bench.py --gpus N`."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from sdf_tools_amd import capi, slab, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _emulate(shape, m, world, halo, res, vb):
+    import torch
+    dev = torch.device("cuda", 0)
+    stages = slab.HipStages(0)
+    nx, ny, nz = shape
+    ranges = [slab.slab_range(nx, r, world) for r in range(world)]
+    halo = min(halo, min(b - a for a, b in ranges))
+    planes = []
+    for (a, b) in ranges:                                   # step 1 on every "rank"
+        rows = torch.empty((b - a, ny, nz), dtype=torch.int32, device=dev)
+        stages.sweep_zy(torch.from_numpy(m[a:b]).to(dev), rows)
+        planes.append(rows)
+    full_field = torch.cat(planes)
+    out = np.empty(shape, np.float32)
+    maxima = np.zeros(2, np.int64)
+    status_any = 0
+    for r, (a, b) in enumerate(ranges):                     # steps 2-3
+        lo = halo if r > 0 else 0
+        hi = halo if r < world - 1 else 0
+        ext = full_field[a - lo:b + hi].contiguous()        # what the halo exchange would deliver
+        o = torch.empty((b - a, ny, nz), dtype=torch.float32, device=dev)
+        small = torch.zeros(4, dtype=torch.int32, device=dev)
+        stages.sweep_x(ext, lo, b - a, hi, a - lo > 0, b + hi < nx, a, nx, res, vb, o, small)
+        mf, mq, st, _ = small.tolist()
+        if st:                                              # step 5: whole lines
+            status_any = 1
+            small.zero_()
+            stages.sweep_x(full_field, a, b - a, nx - b, False, False, a, nx, res, vb, o, small)
+            mf, mq, st, _ = small.tolist()
+            assert st == 0
+        out[a:b] = o.cpu().numpy()
+        maxima = np.maximum(maxima, [mf, mq])
+    return out, capi.extrema_from_dsq(int(maxima[0]), int(maxima[1]), res), status_any
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_dense_slabs_halo_is_enough(gpu, world):
+    shape = (64, 32, 48)
+    m = synth.bernoulli_mask(shape, 0.5, 3)
+    got, ext, status = _emulate(shape, m, world, 4, 0.01, False)
+    want, want_ext = O.reference_sdf(m, 0.01)
+    assert status == 0
+    assert np.array_equal(got, want) and ext == want_ext
+
+
+@pytest.mark.parametrize("vb", [False, True])
+def test_sparse_slabs_raise_status_and_fallback_is_exact(gpu, vb):
+    shape = (48, 20, 24)
+    m = synth.bernoulli_mask(shape, 0.002, 9)
+    assert m.sum() > 0
+    got, ext, status = _emulate(shape, m, 4, 3, 1.0, vb)
+    want, want_ext, _ = O.exact_sdf(m, 1.0, vb)
+    assert status == 1
+    assert np.array_equal(got, want) and ext == want_ext
+
+
+def test_single_rank_slab_equals_whole_path(gpu):
+    shape = (40, 24, 32)
+    m = synth.bernoulli_mask(shape, 0.3, 4)
+    got, ext, status = _emulate(shape, m, 1, 8, 0.5, True)
+    want, want_ext = gpu.build(m, 0.5, True)
+    assert status == 0 and np.array_equal(got, want) and ext == want_ext
+
+
+def test_gradient_matches_reference_definition(gpu):
+    """N1: sdfgpu_gradient_device vs a numpy restatement of GetGridAlignedGradient (sdf.hpp:432-526)."""
+    import torch
+    shape = (12, 9, 10)
+    res = 0.25
+    m = synth.bernoulli_mask(shape, 0.3, 2)
+    sdf, _ = gpu.build(m, res)
+    f = torch.from_numpy(sdf).cuda()
+    g = torch.empty(shape + (3,), dtype=torch.float64, device="cuda")
+    gpu.gradient_device(f.data_ptr(), shape, g.data_ptr(), res, True, True)
+    got = g.cpu().numpy()
+    want = np.zeros(shape + (3,), np.float64)
+    nx, ny, nz = shape
+    for x in range(nx):
+        for y in range(ny):
+            for z in range(nz):
+                interior = 0 < x < nx - 1 and 0 < y < ny - 1 and 0 < z < nz - 1
+                idx = [x, y, z]
+                for ax, n in enumerate(shape):
+                    lo, hi = list(idx), list(idx)
+                    if interior:
+                        lo[ax] -= 1
+                        hi[ax] += 1
+                        want[x, y, z, ax] = float(np.float32(sdf[tuple(hi)] - sdf[tuple(lo)])) * (1.0 / (2.0 * res))
+                    else:
+                        lo[ax] = max(0, idx[ax] - 1)
+                        hi[ax] = min(n - 1, idx[ax] + 1)
+                        inc = (hi[ax] - lo[ax]) * res
+                        if inc > 0:
+                            want[x, y, z, ax] = (float(sdf[tuple(hi)]) - float(sdf[tuple(lo)])) * (1.0 / inc)
+    assert np.array_equal(got, want)
+    # edge gradients disabled -> NaN on the boundary shell, unchanged interior
+    gpu.gradient_device(f.data_ptr(), shape, g.data_ptr(), res, False, True)
+    got2 = g.cpu().numpy()
+    assert np.array_equal(got2[1:-1, 1:-1, 1:-1], want[1:-1, 1:-1, 1:-1])
+    assert np.all(np.isnan(got2[0])) and np.all(np.isnan(got2[:, :, -1]))
+    # test_bindings.py:33 -- gradient at (x=4, y=1) of the 20x40x1 scene is [1.5, 0]
+    m2 = np.zeros((20, 40, 1), np.uint8)
+    m2[3, 1, 0] = 1
+    s2, _ = gpu.build(m2, 0.05)
+    f2 = torch.from_numpy(s2).cuda()
+    g2 = torch.empty((20, 40, 1, 3), dtype=torch.float64, device="cuda")
+    gpu.gradient_device(f2.data_ptr(), (20, 40, 1), g2.data_ptr(), 0.05, True, True)
+    np.testing.assert_allclose(g2[4, 1, 0].cpu().numpy(), [1.5, 0.0, 0.0], rtol=0, atol=1e-6)

@@ -1,0 +1,151 @@
+"""CPU, world_size > 1 (gloo): the x-slab partition / halo exchange / unresolved fallback of
+sdf_tools_amd/slab.py, with a test-only stage executor built on the CPU oracle standing in for the
+HIP kernels (the product executor, HipStages, needs a GPU and is covered by test_gpu_slab.py)."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as O
+from sdf_tools_amd import slab, synth
+
+INF = 1 << 30
+
+
+class OracleStages:
+    """Test double with the contract of sdfgpu_sweep_zy_device / sdfgpu_sweep_x_device."""
+
+    device = torch.device("cpu")
+
+    def sweep_zy(self, mask_slab, rows):
+        m = mask_slab.numpy()
+        for x in range(m.shape[0]):
+            plane = m[x:x + 1]
+            d = np.where(plane != 0, O.exact_edt(plane, 0), O.exact_edt(plane, 1))[0]
+            d = np.where(d < 0, INF, d)
+            rows[x] = torch.from_numpy(np.where(plane[0] != 0, -d, d).astype(np.int32))
+
+    def sweep_x(self, ext, halo_lo, nxs, halo_hi, lo_trunc, hi_trunc, x_global, nx_global, res, vb, out, small):
+        e = ext.numpy().astype(np.int64)
+        L, ny, nz = e.shape
+        status = 0
+        for p in range(halo_lo, halo_lo + nxs):
+            cen = e[p]
+            filled = cen < 0
+            best = np.abs(cen)
+            for q in range(L):
+                same = (e[q] < 0) == filled
+                best = np.minimum(best, np.where(same, np.abs(e[q]), 0) + (p - q) ** 2)
+            if lo_trunc and np.any(best > (p + 1) ** 2):
+                status = 1
+            if hi_trunc and np.any(best > (L - p) ** 2):
+                status = 1
+            D = np.minimum(best, INF)
+            if vb:
+                gx = x_global + p - halo_lo
+                yy, zz = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
+                b = np.full((ny, nz), INF, np.int64)
+                if nx_global > 1:
+                    b = np.minimum(b, min(gx + 1, nx_global - gx))
+                if ny > 1:
+                    b = np.minimum(b, np.minimum(yy + 1, ny - yy))
+                if nz > 1:
+                    b = np.minimum(b, np.minimum(zz + 1, nz - zz))
+                D = np.where(b < 32768, np.minimum(D, b * b), D)
+            with np.errstate(over="ignore"):
+                f = np.where(D >= INF, np.inf, np.sqrt(D.astype(np.float64)) * res).astype(np.float32)
+            out[p - halo_lo] = torch.from_numpy(np.where(filled, -f, f))
+            if (~filled).any():
+                small[0] = max(int(small[0]), int(D[~filled].max()))
+            if filled.any():
+                small[1] = max(int(small[1]), int(D[filled].max()))
+        small[2] = max(int(small[2]), status)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, shape, p, seed, res, vb, halo, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x0, x1 = slab.slab_range(shape[0], rank, world)
+        mask = torch.from_numpy(synth.bernoulli_mask(shape, p, seed, x_range=(x0, x1)))
+        b = slab.SlabSdfBuilder(OracleStages(), shape, res, vb, halo=halo, rank=rank, world=world)
+        sdf, ext = b.build(mask)
+        q.put((rank, x0, x1, sdf.numpy().copy(), ext, b.fallbacks))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, shape, p, seed, res=1.0, vb=False, halo=4):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, p, seed, res, vb, halo, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    full = np.empty(shape, np.float32)
+    for rank, x0, x1, sdf, ext, fb in results:
+        full[x0:x1] = sdf
+    exts = {r[4] for r in results}
+    assert len(exts) == 1                       # every rank reports the same global extrema
+    return full, exts.pop(), max(r[5] for r in results)
+
+
+def test_two_ranks_dense_grid_halo_path():
+    shape = (24, 10, 12)
+    got, ext, fallbacks = _run(2, shape, 0.5, 1, res=0.5)
+    want, want_ext, _ = O.exact_sdf(synth.bernoulli_mask(shape, 0.5, 1), 0.5)
+    assert np.array_equal(got, want) and ext == want_ext
+    assert fallbacks == 0                       # d^2 <= halo^2 everywhere: the halo fast path suffices
+    ref, ref_ext = O.reference_sdf(synth.bernoulli_mask(shape, 0.5, 1), 0.5)
+    assert np.array_equal(got, ref) and ext == ref_ext
+
+
+def test_three_ranks_uneven_slabs_virtual_border():
+    shape = (20, 9, 8)
+    got, ext, _ = _run(3, shape, 0.5, 2, res=1.0, vb=True, halo=3)
+    want, want_ext, _ = O.exact_sdf(synth.bernoulli_mask(shape, 0.5, 2), 1.0, True)
+    assert np.array_equal(got, want) and ext == want_ext
+
+
+def test_two_ranks_sparse_grid_takes_allgather_fallback():
+    shape = (32, 8, 8)
+    got, ext, fallbacks = _run(2, shape, 0.004, 5, halo=2)
+    m = synth.bernoulli_mask(shape, 0.004, 5)
+    assert 0 < m.sum() < 16 and m[:13].sum() == 0      # rank 0's slab sees sites only far away
+    want, want_ext, _ = O.exact_sdf(m, 1.0)
+    assert np.array_equal(got, want) and ext == want_ext
+    assert fallbacks == 1                       # distances exceed the halo: whole-line re-sweep
+
+
+def test_two_ranks_one_class_only():
+    shape = (8, 4, 4)
+    got, ext, fallbacks = _run(2, shape, 0.0, 1, halo=2)
+    assert np.all(np.isposinf(got)) and ext == (math.inf, math.inf) and fallbacks == 1
+
+
+def test_slab_range_covers_grid():
+    for nx in (7, 8, 1024):
+        for world in (1, 2, 3, 8):
+            if nx < world:
+                continue
+            r = [slab.slab_range(nx, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == nx
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
