@@ -1,0 +1,111 @@
+// sdf_generation -- the drop-in seam.  Same namespace, names, parameter order and return type as the
+// reference's three ExtractSignedDistanceField overloads (include/sdf_tools/sdf_generation.hpp:209-441),
+// but the body marshals the predicate into a byte mask and hands it to the MI355X library through
+// the C ABI (include/sdfgpu.h).  BuildDistanceField itself (:95-207) has no counterpart here: the HIP
+// kernels compute both distance fields and the merge in one signed pass.
+//
+// Error behaviour mirrors the reference: std::invalid_argument("Grid must have uniform resolution")
+// (:280), HIP / size failures surface as std::runtime_error; nothing is caught on the path.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "arc_utilities/voxel_grid.hpp"
+#include "sdf_tools/sdf.hpp"
+#include "sdfgpu.h"
+
+namespace sdf_generation {
+
+// One GPU context per host thread (the ABI is re-entrant per context; SURVEY.md 8(b) "Threading").
+class GpuContext {
+public:
+    static sdfgpu_handle Get() {
+        thread_local GpuContext ctx;
+        if (!ctx.handle_) {
+            const int rc = sdfgpu_create(DeviceIndex(), &ctx.handle_);
+            if (rc != SDFGPU_OK) throw std::runtime_error(std::string("sdfgpu: ") + sdfgpu_last_error(nullptr));
+        }
+        return ctx.handle_;
+    }
+    static int& DeviceIndex() { static int device = 0; return device; }
+    ~GpuContext() { if (handle_) sdfgpu_destroy(handle_); }
+private:
+    sdfgpu_handle handle_ = nullptr;
+};
+
+inline void ThrowOnStatus(sdfgpu_handle h, const int rc) {
+    if (rc == SDFGPU_OK) return;
+    const std::string msg = std::string("sdfgpu: ") + sdfgpu_last_error(h);
+    if (rc == SDFGPU_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+
+// Core overload: origin, resolution, cell counts, index predicate (reference :209-271).
+// The predicate may be stateful (MoveIt collision checks), so it is evaluated on the host exactly
+// once per voxel in x -> y -> z order, like :221-239.
+template <typename T>
+inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> ExtractSignedDistanceField(
+    const Eigen::Isometry3d& grid_origin_tranform, const double grid_resolution, const int64_t grid_num_x_cells,
+    const int64_t grid_num_y_cells, const int64_t grid_num_z_cells,
+    const std::function<bool(const VoxelGrid::GRID_INDEX&)>& is_filled_fn, const float oob_value, const std::string& frame,
+    const bool add_virtual_border = false) {
+    std::vector<uint8_t> filled((size_t)(grid_num_x_cells * grid_num_y_cells * grid_num_z_cells));
+    size_t i = 0;
+    for (int64_t x = 0; x < grid_num_x_cells; x++)
+        for (int64_t y = 0; y < grid_num_y_cells; y++)
+            for (int64_t z = 0; z < grid_num_z_cells; z++) filled[i++] = is_filled_fn(VoxelGrid::GRID_INDEX(x, y, z)) ? 1 : 0;
+    sdf_tools::SignedDistanceField new_sdf(grid_origin_tranform, frame, grid_resolution, grid_num_x_cells, grid_num_y_cells,
+                                           grid_num_z_cells, oob_value);
+    double max_distance = 0.0, min_distance = 0.0;
+    sdfgpu_handle h = GpuContext::Get();
+    ThrowOnStatus(h, sdfgpu_build(h, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells, grid_resolution,
+                                  add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(), &max_distance, &min_distance));
+    return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+}
+
+// Grid overload with the virtual-border switch (reference :273-420).
+template <typename T, typename BackingStore = std::vector<T>>
+inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> ExtractSignedDistanceField(
+    const VoxelGrid::VoxelGrid<T, BackingStore>& grid, const std::function<bool(const VoxelGrid::GRID_INDEX&)>& is_filled_fn,
+    const float oob_value, const std::string& frame, const bool add_virtual_border) {
+    const Eigen::Vector3d cell_sizes = grid.GetCellSizes();
+    if ((cell_sizes.x() != cell_sizes.y()) || (cell_sizes.x() != cell_sizes.z()))
+        throw std::invalid_argument("Grid must have uniform resolution");
+    return ExtractSignedDistanceField<T>(grid.GetOriginTransform(), cell_sizes.x(), grid.GetNumXCells(), grid.GetNumYCells(),
+                                         grid.GetNumZCells(), is_filled_fn, oob_value, frame, add_virtual_border);
+}
+
+// Cell-predicate overload (reference :422-441).
+template <typename T, typename BackingStore = std::vector<T>>
+inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> ExtractSignedDistanceField(
+    const VoxelGrid::VoxelGrid<T, BackingStore>& grid, const std::function<bool(const T&)>& is_filled_fn, const float oob_value,
+    const std::string& frame) {
+    const std::function<bool(const VoxelGrid::GRID_INDEX&)> real_is_filled_fn = [&](const VoxelGrid::GRID_INDEX& index) {
+        return is_filled_fn(grid.GetImmutable(index).first);
+    };
+    return ExtractSignedDistanceField(grid, real_is_filled_fn, oob_value, frame, false);
+}
+
+// Fast path used by CollisionMapGrid: no per-voxel std::function, the raw cell array goes to the
+// device and is classified there (sdfgpu_build_cells).
+inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> ExtractSignedDistanceFieldFromCells(
+    const Eigen::Isometry3d& origin, const Eigen::Vector3d& cell_sizes, const int64_t nx, const int64_t ny, const int64_t nz,
+    const void* cells, const size_t cell_stride, const size_t occupancy_offset, const bool unknown_is_filled,
+    const float oob_value, const std::string& frame, const bool add_virtual_border) {
+    if ((cell_sizes.x() != cell_sizes.y()) || (cell_sizes.x() != cell_sizes.z()))
+        throw std::invalid_argument("Grid must have uniform resolution");
+    sdf_tools::SignedDistanceField new_sdf(origin, frame, cell_sizes.x(), nx, ny, nz, oob_value);
+    double max_distance = 0.0, min_distance = 0.0;
+    sdfgpu_handle h = GpuContext::Get();
+    ThrowOnStatus(h, sdfgpu_build_cells(h, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny, nz,
+                                        cell_sizes.x(), add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(),
+                                        &max_distance, &min_distance));
+    return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+}
+
+}  // namespace sdf_generation

@@ -1,0 +1,94 @@
+"""GPU: the reference's own Python test (test/test_bindings.py:11-33) restated against this build's
+pysdf_tools + utils_2d / utils_3d, plus C++-side queries (gradient, EstimateDistance, file / message
+round trips) on a field produced by the HIP path."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from oracle import oracle as O
+from sdf_tools_amd import synth, utils_2d, utils_3d
+from sdf_tools_amd._bindings import load_pysdf_tools
+
+pytestmark = pytest.mark.gpu
+m = load_pysdf_tools()
+IDENT = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
+
+
+def test_reference_test_bindings_restated():
+    res = 0.05
+    x_width, y_height = 20, 40
+    grid_world = np.zeros([y_height, x_width], dtype=np.uint8)
+    grid_world[1, 3] = 1
+    sdf_origin = [0 - x_width / 2, 0 - y_height / 2]
+    sdf, sdf_gradient = utils_2d.compute_sdf_and_gradient(grid_world, res, sdf_origin)
+    assert sdf[1, 3] == pytest.approx(-res, abs=1e-7)
+    assert sdf[2, 3] == pytest.approx(res, abs=1e-7)
+    assert sdf[0, 3] == pytest.approx(res, abs=1e-7)
+    assert sdf[1, 2] == pytest.approx(res, abs=1e-7)
+    assert sdf[1, 4] == pytest.approx(res, abs=1e-7)
+    assert sdf[3, 6] > 3 * res
+    assert sdf.shape == (y_height, x_width)
+    assert sdf_gradient.shape == (y_height, x_width, 2)
+    np.testing.assert_allclose(sdf_gradient[1, 4], [1.5, 0], atol=1e-6)
+
+
+def test_utils_3d_conventions_against_oracle():
+    env = (synth.bernoulli_mask((12, 9, 10), 0.4, 3)).astype(np.float32)          # env is [y, x, z]
+    sdf, grad = utils_3d.compute_sdf_and_gradient(env, 0.1, [0.0, 0.0, 0.0])
+    mask_xyz = np.transpose(env == 1, [1, 0, 2]).astype(np.uint8)
+    want, _ = O.reference_sdf(mask_xyz, 0.1)
+    assert np.array_equal(sdf, np.transpose(want, [1, 0, 2]))
+    assert grad.shape == env.shape + (3,) and grad.dtype == np.float32
+    obj = utils_3d.compute_sdf(env, 0.1, [0.0, 0.0, 0.0])
+    assert np.array_equal(np.array(obj.GetRawData(), np.float32).reshape(9, 12, 10), want)
+    g64 = utils_3d.get_gradient(obj)
+    assert np.array_equal(np.transpose(g64, [1, 0, 2, 3]).astype(np.float32), grad)
+
+
+def test_collision_map_extract_both_seams_and_extrema():
+    mask, res = scenes.tutorial_scene()
+    origin = m.Isometry3d([[1, 0, 0, -5.0], [0, 1, 0, -5.0], [0, 0, 1, -5.0], [0, 0, 0, 1]])
+    g = m.CollisionMapGrid(origin, "tutorial_frame", res, 40, 40, 40, m.COLLISION_CELL(0.0))
+    g.SetOccupancyFromNumpy(mask.astype(np.float32))
+    sdf, (mx, mn) = g.ExtractSignedDistanceField(0.0, False, False)
+    want, want_ext = O.reference_sdf(mask, res)
+    assert np.array_equal(sdf.GetRawDataNumpy(), want) and (mx, mn) == want_ext
+    assert sdf.GetFrame() == "tutorial_frame" and sdf.GetResolution() == res
+    sdf2, ext2 = g.ExtractSignedDistanceFieldViaPredicate(0.0, False, False)
+    assert np.array_equal(sdf2.GetRawDataNumpy(), want) and ext2 == want_ext
+    v, ok = sdf.GetValueByIndex(10, 10, 10)
+    assert ok and v == -2.5
+    v, ok = sdf.GetValueByCoordinates(-5.0 + 0.25 * 20.5, -5.0 + 0.25 * 20.5, -5.0 + 0.25 * 20.5)
+    assert ok and v == pytest.approx(0.4330127, abs=1e-7)
+    v, ok = sdf.GetValueByIndex(40, 0, 0)
+    assert not ok and v == 0.0
+    # interior gradient = central differences (sdf.hpp:447-458); +x of the box face points along +x
+    gx = sdf.GetGradient(25, 10, 10, False)
+    assert gx == pytest.approx([1.0, 0.0, 0.0], abs=1e-6)
+    assert sdf.GetGradient(0, 0, 0, False) == []                          # edge gradients disabled
+    assert len(sdf.GetGradient(0, 0, 0, True)) == 3
+    # trilinear estimate at a cell centre = value shrunk by half a cell (sdf.hpp:773-796)
+    est, ok = sdf.EstimateDistance(-5.0 + 0.25 * 30.5, -5.0 + 0.25 * 10.5, -5.0 + 0.25 * 10.5)
+    assert ok and est == pytest.approx(float(want[30, 10, 10]) - 0.125, abs=1e-6)
+
+
+def test_file_and_message_round_trip(tmp_path):
+    mask = synth.bernoulli_mask((9, 8, 7), 0.5, 2)
+    g = m.CollisionMapGrid(m.Isometry3d(IDENT), "world", 0.5, 9, 8, 7, m.COLLISION_CELL(0.0))
+    g.SetOccupancyFromNumpy(mask.astype(np.float32))
+    sdf, _ = g.ExtractSignedDistanceField(-1.0, False, True)
+    for compress in (True, False):
+        path = os.path.join(str(tmp_path), "f.sdf")
+        sdf.SaveToFile(path, compress)
+        assert open(path, "rb").read(4) == (b"SDFZ" if compress else b"SDFR")
+        back = m.SignedDistanceField.LoadFromFile(path)
+        assert np.array_equal(back.GetRawDataNumpy(), sdf.GetRawDataNumpy())
+        assert back.GetFrame() == "world" and back.GetResolution() == 0.5
+    msg = sdf.GetMessageRepresentation()
+    assert msg.is_compressed and msg.frame_id == "world"
+    back = m.SignedDistanceField.LoadFromMessageRepresentation(msg)
+    assert np.array_equal(back.GetRawDataNumpy(), sdf.GetRawDataNumpy())
+    with pytest.raises(ValueError):
+        m.SignedDistanceField.LoadFromFile(os.path.join(str(tmp_path), "missing.sdf"))
