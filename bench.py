@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--resolution", type=float, default=0.01)
     ap.add_argument("--halo", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the cube timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=320, help="edge of the cube timed on the CPU oracle")
     ap.add_argument("--tune", type=int, nargs=2, default=None, help="rows per chunk: y x")
     return ap.parse_args()
 

@@ -54,7 +54,7 @@ def pmc(dirs, out_json):
         for f in find(d, "*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 name = r.get("Kernel_Name", "")
-                label = short(name) or ("copy" if ("elementwise" in name or "copy" in name.lower()) else None)
+                label = short(name) or ("copy" if "direct_copy" in name else None)
                 if label:
                     per[label][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_units": "bytes per launch; raw = counter * 1024 (KiB); read_corrected = 2 * raw FETCH_SIZE "
