@@ -176,6 +176,15 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
 
+/* Named integer options (benchmarks / A-B tests): "fused_zy" (1 = use the fused z+y kernel when the
+ * shape allows, default; 0 = always run K1 + K2), "rows_per_chunk_y", "rows_per_chunk_x",
+ * "rows_per_chunk_zy" (0 = automatic), "fused_window" (register-window radius of the fused kernel at
+ * nz = 512: 2 or 3). */
+int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
+
+/* Which kernels the most recent sdfgpu_build*_device call used (*out_fused_zy = 1: K12 + K3). */
+int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy);
+
 /* Tuning hook (benchmarks): rows marched per thread in the y / x sweeps
  * (0 = automatic). */
 int sdfgpu_set_tuning(sdfgpu_handle h, int rows_per_chunk_y, int rows_per_chunk_x);

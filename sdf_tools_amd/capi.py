@@ -21,7 +21,7 @@ EXPORTS = [
     "sdfgpu_build", "sdfgpu_build_cells", "sdfgpu_build_device", "sdfgpu_build_cells_device",
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
-    "sdfgpu_set_profiling", "sdfgpu_get_stage_times",
+    "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info",
 ]
 
 
@@ -71,6 +71,8 @@ def load_library():
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_debug_copy_yzsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_set_tuning.argtypes = [vp, ci, ci]
+    L.sdfgpu_set_option.argtypes = [vp, ctypes.c_char_p, ci]
+    L.sdfgpu_last_build_info.argtypes = [vp, vp]
     L.sdfgpu_set_profiling.argtypes = [vp, ci]
     L.sdfgpu_get_stage_times.argtypes = [vp, vp, vp]
     for name in EXPORTS:
@@ -194,6 +196,14 @@ class SdfGpu:
         out = np.empty(shape, dtype=np.int32)
         self._check(self._lib.sdfgpu_debug_copy_yzsweep(self._h, out.ctypes.data, out.size))
         return out
+
+    def set_option(self, name, value):
+        self._check(self._lib.sdfgpu_set_option(self._h, name.encode(), int(value)))
+
+    def last_build_fused_zy(self):
+        v = ctypes.c_int()
+        self._check(self._lib.sdfgpu_last_build_info(self._h, ctypes.byref(v)))
+        return bool(v.value)
 
     def set_profiling(self, enable=True):
         self._check(self._lib.sdfgpu_set_profiling(self._h, int(bool(enable))))

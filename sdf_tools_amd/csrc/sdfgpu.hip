@@ -2,6 +2,7 @@
 // Host side of the drop-in boundary for sdf_generation::ExtractSignedDistanceField
 // (reference include/sdf_tools/sdf_generation.hpp:209-420).  No CPU fallback.
 #include "sdfgpu_kernels.hpp"
+#include "sdfgpu_fused_zy.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -42,7 +43,9 @@ struct sdfgpu_context {
     double last_resolution = 1.0;
     int64_t last_n = 0;
     bool have_result = false;
-    int tune_ty = 0, tune_tx = 0;
+    bool last_fused = false;
+    int tune_ty = 0, tune_tx = 0, tune_tzy = 0, fused_h = 0;
+    bool fused_zy = true;            // use K12 (z sweep fused into the y sweep) when the shape allows
     bool profiling = false;
     std::vector<hipEvent_t> events;   // 4 per profiled build: before K1, after K1, after K2, after K3
 };
@@ -160,6 +163,41 @@ int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, int32_t* d_out, int64_t
     return launch_march<2, false>(h, a, vec4, s);
 }
 
+// K12 launch: mask -> int32 in-plane signed d^2 in one kernel (nz = 512 or 1024, 16-B aligned mask)
+bool fused_zy_eligible(const sdfgpu_context* h, const uint8_t* d_mask, const int32_t* d_out, int64_t nz) {
+    return h->fused_zy && d_mask && (nz == 512 || nz == 1024) &&
+           (reinterpret_cast<uintptr_t>(d_mask) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0;
+}
+
+int launch_sweep_zy_fused(sdfgpu_handle h, const uint8_t* d_mask, int32_t* d_out, int64_t nx, int64_t ny, int64_t nz,
+                          hipStream_t s) {
+    FusedZyArgs a{};
+    a.mask = d_mask; a.out = d_out; a.nx = (int)nx; a.ny = (int)ny;
+    const int T = h->tune_tzy > 0 ? h->tune_tzy : 32;
+    const int wpb = kBlock / 64;
+    if (nz == 512 && h->fused_h == 2) {
+        constexpr int V = 8, H = 2, R = 2 * H + 1;
+        a.T = std::min(std::max(T, R), (int)ny);
+        dim3 grid((unsigned)((nx + wpb - 1) / wpb), (unsigned)((ny + a.T - 1) / a.T)), block(kBlock);
+        const size_t lds = (size_t)wpb * (R + 1) * (8 + 64 * (V / 8) + 8);
+        hipLaunchKernelGGL((k_sweep_zy_fused<V, H>), grid, block, lds, s, a);
+    } else if (nz == 512) {
+        constexpr int V = 8, H = 3, R = 2 * H + 1;
+        a.T = std::min(std::max(T, R), (int)ny);
+        dim3 grid((unsigned)((nx + wpb - 1) / wpb), (unsigned)((ny + a.T - 1) / a.T)), block(kBlock);
+        const size_t lds = (size_t)wpb * (R + 1) * (8 + 64 * (V / 8) + 8);
+        hipLaunchKernelGGL((k_sweep_zy_fused<V, H>), grid, block, lds, s, a);
+    } else {
+        constexpr int V = 16, H = 2, R = 2 * H + 1;
+        a.T = std::min(std::max(T, R), (int)ny);
+        dim3 grid((unsigned)((nx + wpb - 1) / wpb), (unsigned)((ny + a.T - 1) / a.T)), block(kBlock);
+        const size_t lds = (size_t)wpb * (R + 1) * (8 + 64 * (V / 8) + 8);
+        hipLaunchKernelGGL((k_sweep_zy_fused<V, H>), grid, block, lds, s, a);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
 // K3 launch: int32 plane field (optionally with x halo) -> fp32 sdf
 int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t halo_lo, int64_t nxs,
                    int64_t halo_hi, int64_t ny, int64_t nz, int lo_trunc, int hi_trunc, int64_t x_global,
@@ -204,10 +242,17 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
         HIP_TRY(h, hipEventRecord(ev[0], s));
     }
-    if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
-                                (int16_t*)h->zfield.ptr, s)) return rc;
+    const bool fused = !d_cells && fused_zy_eligible(h, d_filled, (const int32_t*)h->yzfield.ptr, nz);
+    h->last_fused = fused;
+    if (!fused)
+        if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
+                                    (int16_t*)h->zfield.ptr, s)) return rc;
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[1], s));
-    if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, (int32_t*)h->yzfield.ptr, nx, ny, nz, s)) return rc;
+    if (fused) {
+        if (int rc = launch_sweep_zy_fused(h, d_filled, (int32_t*)h->yzfield.ptr, nx, ny, nz, s)) return rc;
+    } else {
+        if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, (int32_t*)h->yzfield.ptr, nx, ny, nz, s)) return rc;
+    }
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[2], s));
     if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
                                 resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
@@ -360,8 +405,9 @@ int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs
     if (int rc = check_dims(h, nxs, ny, nz)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nxs * ny * nz;
-    if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (fused_zy_eligible(h, d_filled, d_plane_dsq, nz)) return launch_sweep_zy_fused(h, d_filled, d_plane_dsq, nxs, ny, nz, s);
+    if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     if (int rc = launch_sweep_z(h, d_filled, nullptr, 0, 0, 0, nxs, ny, nz, (int16_t*)h->zfield.ptr, s)) return rc;
     return launch_sweep_y(h, (const int16_t*)h->zfield.ptr, d_plane_dsq, nxs, ny, nz, s);
 }
@@ -406,6 +452,7 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
 int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {
     if (!h || !out_host) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!h->have_result || n > h->last_n) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no matching build");
+    if (h->last_fused) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "the last build fused the z sweep into the y sweep: no z field exists");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     HIP_TRY(h, hipMemcpy(out_host, h->zfield.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
@@ -444,6 +491,24 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
     }
     for (auto e : h->events) (void)hipEventDestroy(e);
     h->events.clear();
+    return SDFGPU_OK;
+}
+
+int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
+    if (!h || !name) return SDFGPU_ERR_INVALID_ARGUMENT;
+    const std::string n(name);
+    if (n == "fused_zy") h->fused_zy = value != 0;
+    else if (n == "rows_per_chunk_y") h->tune_ty = value;
+    else if (n == "rows_per_chunk_x") h->tune_tx = value;
+    else if (n == "rows_per_chunk_zy") h->tune_tzy = value;
+    else if (n == "fused_window") h->fused_h = value;
+    else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+    return SDFGPU_OK;
+}
+
+int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy) {
+    if (!h || !out_fused_zy) return SDFGPU_ERR_INVALID_ARGUMENT;
+    *out_fused_zy = h->last_fused ? 1 : 0;
     return SDFGPU_OK;
 }
 

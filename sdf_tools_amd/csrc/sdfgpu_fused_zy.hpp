@@ -1,0 +1,224 @@
+// sdfgpu_fused_zy.hpp -- K12: z sweep fused into the y sweep (mask -> int32 in-plane signed d^2).
+//
+// Removes the int16 z field from HBM: 1 B/voxel in, 4 B/voxel out instead of K1 (1+2) + K2 (2+4).
+// One wave owns one complete z-row (nz = 64*V voxels, V = 8 or 16 per lane) of one x-plane and
+// marches along y exactly like k_sweep_march<2,...>, but every row it needs is derived on the fly
+// from the occupancy bytes:
+//   - each lane loads its V mask bytes (one 8/16-byte load), folds them to V bits and drops them into
+//     a wave-private LDS row bitmap (64..128 bytes per row);
+//   - it reads back the 64-bit word holding its voxels, finds the nearest filled / free voxel on each
+//     side of its V-bit group once per lane (clz/ffs on the word; neighbouring words only when the word
+//     has none) and gets every voxel's distance to the nearest opposite-class voxel with two running
+//     passes over its V bits (~8 integer ops per voxel) -- exact for any row.
+// The outward scan beyond the register window recomputes rows the same way, so the kernel stays
+// exact for any input.  Used when nz is 512 or 1024 (the benchmark shapes); other shapes take K1 + K2.
+#pragma once
+#include "sdfgpu_kernels.hpp"
+
+namespace sdfgpu {
+
+constexpr int kWinNone = 1 << 14;    // "no such voxel in this row" (clamped so the running adds cannot overflow)
+
+template <int V> struct MaskRawT;
+template <> struct MaskRawT<8> { using type = uint2; };
+template <> struct MaskRawT<16> { using type = uint4; };
+
+template <int V>
+__device__ __forceinline__ uint32_t pack_mask_bits(const typename MaskRawT<V>::type& r) {
+    if constexpr (V == 8) return nonzero_bits4(r.x) | (nonzero_bits4(r.y) << 4);
+    else return nonzero_bits4(r.x) | (nonzero_bits4(r.y) << 4) | (nonzero_bits4(r.z) << 8) | (nonzero_bits4(r.w) << 12);
+}
+
+struct FusedZyArgs {
+    const uint8_t* mask;
+    int32_t* out;
+    int nx, ny;     // x-planes in this launch, rows per plane (nz = 64*V is a template constant)
+    int T;          // rows marched per wave
+};
+
+// z sweep of one row for this lane's V voxels, from the wave's LDS row bitmap (64-bit words at
+// row + 8).  The nearest filled / free voxel on either side of the lane's V-bit group is looked up once
+// per lane (own word first, neighbouring words only if it has none), then two running passes over the
+// V bits give every voxel's distance to the nearest opposite-class voxel -- exact for any row.
+// Returns signed squared distances (+ free / - filled, kInf32 magnitude if the row has no opposite voxel).
+template <int V>
+__device__ __forceinline__ void row_from_bitmap(const unsigned char* row, int lane, int (&s)[V]) {
+    constexpr int W64 = V, nz = 64 * V;
+    const uint64_t* row64 = reinterpret_cast<const uint64_t*>(row + 8);
+    const int z0 = V * lane, w = z0 >> 6, zb0 = z0 & 63;
+    const uint64_t word = row64[w];
+    const uint32_t B = (uint32_t)(word >> zb0) & ((1u << V) - 1u);           // this lane's voxels
+    const uint64_t below = (1ull << zb0) - 1ull;
+    const uint64_t above = (zb0 + V >= 64) ? 0ull : (~0ull << (zb0 + V));
+    const uint64_t lf = word & below, le = ~word & below;
+    const uint64_t hf = word & above, he = ~word & above;
+    const int pLF = lf ? 64 * w + 63 - __clzll((long long)lf) : far_left(row64, w, true);
+    const int pLE = le ? 64 * w + 63 - __clzll((long long)le) : far_left(row64, w, false);
+    const int pRF = hf ? 64 * w + __ffsll((unsigned long long)hf) - 1 : far_right(row64, w, W64, nz, true);
+    const int pRE = he ? 64 * w + __ffsll((unsigned long long)he) - 1 : far_right(row64, w, W64, nz, false);
+    int d[V];
+    {   // left-to-right: distance to the last filled / free voxel seen so far
+        int cF = min(z0 - pLF, kWinNone), cE = min(z0 - pLE, kWinNone);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const bool b = (B >> k) & 1u;
+            d[k] = b ? cE : cF;
+            cF = b ? 1 : cF + 1;
+            cE = b ? cE + 1 : 1;
+        }
+    }
+    {   // right-to-left
+        int rF = min(pRF - (z0 + V - 1), kWinNone), rE = min(pRE - (z0 + V - 1), kWinNone);
+#pragma unroll
+        for (int k = V - 1; k >= 0; --k) {
+            const bool b = (B >> k) & 1u;
+            const int dr = b ? rE : rF;
+            rF = b ? 1 : rF + 1;
+            rE = b ? rE + 1 : 1;
+            const int dk = min(d[k], dr);
+            const int sq = (dk >= kWinNone) ? kInf32 : dk * dk;
+            s[k] = b ? -sq : sq;
+        }
+    }
+}
+
+template <int V, int H>
+__global__ __launch_bounds__(kBlock) void k_sweep_zy_fused(const FusedZyArgs a) {
+    constexpr int R = 2 * H + 1;
+    constexpr int BPL = V / 8;                     // bitmap bytes per lane
+    constexpr int ROWB = 8 + 64 * BPL + 8;         // zero pads on both sides keep window reads in-bounds
+    constexpr int nz = 64 * V;
+    using RawT = typename MaskRawT<V>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = (int)blockIdx.x * (kBlock / 64) + wv;
+    if (x >= a.nx) return;                         // wave-uniform; no workgroup barriers below
+    unsigned char* wl = smem_raw + wv * (R + 1) * ROWB;   // R batch rows + 1 row for the outward scan
+    for (int r = 0; r <= R; ++r)
+        if (lane < 8) { wl[r * ROWB + lane] = 0; wl[r * ROWB + 8 + 64 * BPL + lane] = 0; }
+
+    const int L = a.ny;
+    const int p0 = (int)blockIdx.y * a.T;
+    const int p1 = min(L, p0 + a.T);
+    if (p0 >= p1) return;
+    const uint8_t* col_in = a.mask + (int64_t)x * L * nz + lane * V;
+    int32_t* col_out = a.out + (int64_t)x * L * nz + lane * V;
+
+    auto put_bits = [&](int slot, const RawT& raw) {
+        const uint32_t bits = pack_mask_bits<V>(raw);
+        if constexpr (V == 8) wl[slot * ROWB + 8 + lane] = (unsigned char)bits;
+        else *reinterpret_cast<uint16_t*>(wl + slot * ROWB + 8 + 2 * lane) = (uint16_t)bits;
+    };
+    auto lds_sync = [&]() {      // same-wave LDS write -> read ordering (DS ops of a wave execute in order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // one row through the scan slot (prologue, tail and outward scan)
+    auto fetch_row = [&](int p, int (&dst)[V]) {
+        const RawT raw = *reinterpret_cast<const RawT*>(col_in + (int64_t)p * nz);
+        lds_sync();
+        put_bits(R, raw);
+        lds_sync();
+        row_from_bitmap<V>(wl + R * ROWB, lane, dst);
+    };
+
+    int win[R][V];
+
+    auto step = [&](int p, auto r_tag, auto check_tag) {
+        constexpr int r = decltype(r_tag)::value;
+        constexpr bool CHECK = decltype(check_tag)::value;
+        const int (&cen)[V] = win[(r + H) % R];
+        int best[V], m[V], negm[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            m[k] = cen[k] >> 31;
+            negm[k] = -m[k];
+            best[k] = (cen[k] ^ m[k]) + negm[k];
+        }
+#pragma unroll
+        for (int d = 1; d <= H; ++d) {
+            const int dd = d * d;
+            const int (&lo)[V] = win[(r + H - d) % R];
+            const int (&hi)[V] = win[(r + H + d) % R];
+            const bool lo_ok = !CHECK || (p - d >= 0);
+            const bool hi_ok = !CHECK || (p + d < L);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                if (lo_ok) best[k] = min(best[k], candidate(lo[k], m[k], negm[k], dd));
+                if (hi_ok) best[k] = min(best[k], candidate(hi[k], m[k], negm[k], dd));
+            }
+        }
+        bool need = false;
+#pragma unroll
+        for (int k = 0; k < V; ++k) need |= best[k] >= (H + 1) * (H + 1);
+        if (__any(need)) {
+            for (int d = H + 1;; ++d) {
+                const int lo = p - d, hi = p + d;
+                if (lo < 0 && hi >= L) break;
+                const int dd = d * d;
+                bool act = false;
+#pragma unroll
+                for (int k = 0; k < V; ++k) act |= dd < best[k];
+                if (!__any(act)) break;
+                int s[V];
+                if (lo >= 0) {                      // whole wave recomputes the row (wave-wide ops inside)
+                    fetch_row(lo, s);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) best[k] = min(best[k], candidate(s[k], m[k], negm[k], dd));
+                }
+                if (hi < L) {
+                    fetch_row(hi, s);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) best[k] = min(best[k], candidate(s[k], m[k], negm[k], dd));
+                }
+            }
+        }
+        int o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int D = min(best[k], kInf32);
+            o[k] = (D ^ m[k]) + negm[k];
+        }
+        int4* dst = reinterpret_cast<int4*>(col_out + (int64_t)p * nz);
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) dst[q] = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    };
+
+    // prologue: rows p0-H .. p0+H-1 -> slots 0 .. 2H-1
+    static_for<2 * H>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int p = p0 - H + k;
+        if (p >= 0 && p < L) fetch_row(p, win[k]);
+    });
+
+    for (int pb = p0; pb < p1; pb += R) {
+        const bool fast = (pb - H >= 0) && (pb + R - 1 + H < L) && (pb + R <= p1);
+        if (fast) {
+            RawT raw[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw[r] = *reinterpret_cast<const RawT*>(col_in + (int64_t)(pb + r + H) * nz);
+            lds_sync();                              // earlier reads of the batch slots are done
+#pragma unroll
+            for (int r = 0; r < R; ++r) put_bits(r, raw[r]);
+            lds_sync();
+            static_for<R>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                row_from_bitmap<V>(wl + r * ROWB, lane, win[(r + 2 * H) % R]);
+                step(pb + r, rc, std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);   // keep rows sequential: hoisting all 7 rows' bit work costs >200 VGPRs
+            });
+        } else {
+            static_for<R>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int p = pb + r;
+                if (p < p1) {
+                    if (p + H < L) fetch_row(p + H, win[(r + 2 * H) % R]);
+                    step(p, rc, std::true_type{});
+                }
+            });
+        }
+    }
+}
+
+}  // namespace sdfgpu

@@ -7,7 +7,8 @@ reference's VoxelGrid layout.  The z and y sweeps are slab-local; only the x swe
   1. ``sweep_zy``   mask slab -> signed in-plane d^2 (int32), written straight into the middle of
                     an extended buffer ``[halo_lo + nxs + halo_hi, ny, nz]``
   2. halo exchange  the first / last ``halo`` planes go to the x-neighbours (grouped
-                    send/recv: one message per direct xGMI link, 4 MiB per plane at 1024^2)
+                    send/recv: one message per direct xGMI link, 4 MiB per plane at 1024^2); the
+                    boundary planes are swept first so the exchange overlaps the interior sweeps
   3. ``sweep_x``    x sweep + signed merge over the extended buffer; the kernel itself checks that
                     no voxel needed a plane beyond the halo and raises a status bit otherwise
   4. all-reduce     (MAX) of {max d^2 free, max d^2 filled, status}: 3 integers
@@ -64,7 +65,7 @@ class SlabSdfBuilder:
     ``(sdf_slab float32 [nxs, ny, nz], (max, min))`` with the extrema of the *whole* grid.
     """
 
-    def __init__(self, stages, shape, resolution=1.0, add_virtual_border=False, halo=8,
+    def __init__(self, stages, shape, resolution=1.0, add_virtual_border=False, halo=3,
                  rank=None, world=None, group=None, device=None):
         self.stages = stages
         self.nx, self.ny, self.nz = (int(s) for s in shape)
@@ -91,9 +92,10 @@ class SlabSdfBuilder:
         self.fallbacks = 0
 
     # -- step 2 ------------------------------------------------------------------------------
-    def _exchange_halo(self):
+    def _start_halo_exchange(self):
+        """Posts the grouped nearest-neighbour send/recv (asynchronous on RCCL's stream)."""
         if self.world == 1 or self.halo == 0:
-            return
+            return []
         h, lo, n = self.halo, self.halo_lo, self.nxs
         ops = []
         if self.rank > 0:          # lower neighbour: send my first h planes, receive its last h
@@ -102,8 +104,7 @@ class SlabSdfBuilder:
         if self.rank < self.world - 1:
             ops.append(dist.P2POp(dist.isend, self.ext[lo + n - h:lo + n], self._peer(self.rank + 1), self.group))
             ops.append(dist.P2POp(dist.irecv, self.ext[lo + n:lo + n + h], self._peer(self.rank + 1), self.group))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        return dist.batch_isend_irecv(ops)
 
     def _peer(self, group_rank):
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
@@ -123,9 +124,19 @@ class SlabSdfBuilder:
 
     def build(self, mask_slab):
         assert tuple(mask_slab.shape) == (self.nxs, self.ny, self.nz), (mask_slab.shape, self.nxs)
-        lo, n, hi = self.halo_lo, self.nxs, self.halo_hi
-        self.stages.sweep_zy(mask_slab, self.ext[lo:lo + n])
-        self._exchange_halo()
+        lo, n, hi, h = self.halo_lo, self.nxs, self.halo_hi, self.halo
+        own = self.ext[lo:lo + n]
+        if self.world > 1 and 0 < h and 2 * h < n:
+            # boundary planes first, so their exchange over xGMI overlaps the interior z/y sweeps
+            self.stages.sweep_zy(mask_slab[:h], own[:h])
+            self.stages.sweep_zy(mask_slab[n - h:], own[n - h:])
+            works = self._start_halo_exchange()
+            self.stages.sweep_zy(mask_slab[h:n - h], own[h:n - h])
+        else:
+            self.stages.sweep_zy(mask_slab, own)
+            works = self._start_halo_exchange()
+        for w in works:
+            w.wait()
         self.small.zero_()
         self.stages.sweep_x(self.ext, lo, n, hi, self.x0 - lo > 0, self.x1 + hi < self.nx, self.x0, self.nx,
                             self.resolution, self.vb, self.out, self.small)
