@@ -29,10 +29,11 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # priced at their sum (9); the bytes it actually has to move are fewer (1 in + 4 out) and are reported
 # next to it as design_bytes_per_voxel.
 B_ALG = {"sweep_z": 1 + 2, "sweep_y": 2 + 4, "sweep_zy": 9, "sweep_x": 4 + 4}
-B_DESIGN = {"sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8}
+B_DESIGN32 = {"sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8}      # int32 plane field
+B_DESIGN16 = {"sweep_z": 3, "sweep_y": 4, "sweep_zy": 3, "sweep_x": 6}      # int16 plane field + side table
 B_ALG_TOTAL = 17
-KERNEL_NAMES = {"sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,4,3,false>",
-                "sweep_zy": "k_sweep_zy_fused", "sweep_x": "k_sweep_march<3,4,3,false>"}
+KERNEL_NAMES = {"sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,...>",
+                "sweep_zy": "k_sweep_zy_fused", "sweep_x": "k_sweep_march<3,...> / k_sweep_x16"}
 
 GRIDS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
 
@@ -177,7 +178,10 @@ def main():
         mx, mn = ctx.get_extrema()
         result["extrema"] = [mx, mn]
         if builds:
-            if ctx.last_build_fused_zy():
+            info = ctx.last_build_info()
+            B_DESIGN = B_DESIGN16 if info["plane16"] else B_DESIGN32
+            result["config"]["kernels"] = info
+            if info["fused_zy"]:
                 stage_ms = {"sweep_zy": ms_sum[1] / builds, "sweep_x": ms_sum[2] / builds}
             else:
                 stage_ms = dict(zip(("sweep_z", "sweep_y", "sweep_x"), (v / builds for v in ms_sum)))

@@ -179,10 +179,13 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
 /* Named integer options (benchmarks / A-B tests): "fused_zy" (1 = use the fused z+y kernel when the
  * shape allows, default; 0 = always run K1 + K2), "rows_per_chunk_y", "rows_per_chunk_x",
  * "rows_per_chunk_zy" (0 = automatic), "fused_window" (register-window radius of the fused kernel at
- * nz = 512: 2 or 3). */
+ * nz = 512: 2 or 3), "plane16" (1 = int16 plane field + int32 side table between the y and x sweeps
+ * when the shape allows, default; 0 = int32 plane field), "x16_voxels_per_lane" (4 or 8),
+ * "x16_window" (2 or 3). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
-/* Which kernels the most recent sdfgpu_build*_device call used (*out_fused_zy = 1: K12 + K3). */
+/* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),
+ * bit 1 = 16-bit plane field (K3/16). */
 int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy);
 
 /* Tuning hook (benchmarks): rows marched per thread in the y / x sweeps

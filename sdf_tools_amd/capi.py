@@ -200,10 +200,13 @@ class SdfGpu:
     def set_option(self, name, value):
         self._check(self._lib.sdfgpu_set_option(self._h, name.encode(), int(value)))
 
-    def last_build_fused_zy(self):
+    def last_build_info(self):
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_last_build_info(self._h, ctypes.byref(v)))
-        return bool(v.value)
+        return {"fused_zy": bool(v.value & 1), "plane16": bool(v.value & 2)}
+
+    def last_build_fused_zy(self):
+        return self.last_build_info()["fused_zy"]
 
     def set_profiling(self, enable=True):
         self._check(self._lib.sdfgpu_set_profiling(self._h, int(bool(enable))))

@@ -2,6 +2,7 @@
 // Host side of the drop-in boundary for sdf_generation::ExtractSignedDistanceField
 // (reference include/sdf_tools/sdf_generation.hpp:209-420).  No CPU fallback.
 #include "sdfgpu_kernels.hpp"
+#include "sdfgpu_sweep_x16.hpp"
 #include "sdfgpu_fused_zy.hpp"
 
 #include <algorithm>
@@ -35,7 +36,8 @@ struct sdfgpu_context {
     int device = 0;
     std::string error;
     DeviceBuffer zfield;     // int16 [N]   K1 output
-    DeviceBuffer yzfield;    // int32 [N]   K2 output
+    DeviceBuffer yzfield;    // int32 [N]   K2 output (32-bit pipeline) / side table (16-bit pipeline)
+    DeviceBuffer plane16;    // int16 [N]   plane field of the 16-bit pipeline
     DeviceBuffer stage_in;   // host-API staging: mask / cells
     DeviceBuffer stage_out;  // host-API staging: sdf
     uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] pad
@@ -46,6 +48,9 @@ struct sdfgpu_context {
     bool last_fused = false;
     int tune_ty = 0, tune_tx = 0, tune_tzy = 0, fused_h = 0;
     bool fused_zy = true;            // use K12 (z sweep fused into the y sweep) when the shape allows
+    bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
+    int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
+    bool last_plane16 = false;
     bool profiling = false;
     std::vector<hipEvent_t> events;   // 4 per profiled build: before K1, after K1, after K2, after K3
 };
@@ -147,13 +152,17 @@ int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s) {
 }
 
 // K2 launch: int16 z field -> int32 in-plane signed d^2
-int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, int32_t* d_out, int64_t nx, int64_t ny, int64_t nz,
-                   hipStream_t s) {
+// (d_side != nullptr: write the int16 plane field to d_out and exact saturated groups to d_side;
+//  requires the vec4 path)
+int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, void* d_out, int32_t* d_side, int64_t nx, int64_t ny,
+                   int64_t nz, hipStream_t s) {
     const bool vec4 = (nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_in) % 8) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_out) % 16) == 0;
+    if (d_side && !vec4) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "16-bit plane output needs nz % 4 == 0");
     const int V = vec4 ? 4 : 1;
     SweepArgs a{};
     a.in = d_in; a.out = d_out;
+    a.out16 = d_side ? 1 : 0; a.side = d_side;
     a.cpl = nz / V;
     a.ncols = nx * a.cpl;
     a.outer_stride = ny * nz;
@@ -164,36 +173,76 @@ int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, int32_t* d_out, int64_t
 }
 
 // K12 launch: mask -> int32 in-plane signed d^2 in one kernel (nz = 512 or 1024, 16-B aligned mask)
-bool fused_zy_eligible(const sdfgpu_context* h, const uint8_t* d_mask, const int32_t* d_out, int64_t nz) {
+bool fused_zy_eligible(const sdfgpu_context* h, const uint8_t* d_mask, const void* d_out, int64_t nz) {
     return h->fused_zy && d_mask && (nz == 512 || nz == 1024) &&
            (reinterpret_cast<uintptr_t>(d_mask) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0;
 }
 
-int launch_sweep_zy_fused(sdfgpu_handle h, const uint8_t* d_mask, int32_t* d_out, int64_t nx, int64_t ny, int64_t nz,
-                          hipStream_t s) {
-    FusedZyArgs a{};
-    a.mask = d_mask; a.out = d_out; a.nx = (int)nx; a.ny = (int)ny;
-    const int T = h->tune_tzy > 0 ? h->tune_tzy : 32;
+template <int V, int H>
+void launch_fused_variant(const FusedZyArgs& a0, int T, int64_t nx, int64_t ny, bool out16, hipStream_t s) {
+    constexpr int R = 2 * H + 1;
+    FusedZyArgs a = a0;
+    a.T = std::min(std::max(T, R), (int)ny);
     const int wpb = kBlock / 64;
-    if (nz == 512 && h->fused_h == 2) {
-        constexpr int V = 8, H = 2, R = 2 * H + 1;
-        a.T = std::min(std::max(T, R), (int)ny);
-        dim3 grid((unsigned)((nx + wpb - 1) / wpb), (unsigned)((ny + a.T - 1) / a.T)), block(kBlock);
-        const size_t lds = (size_t)wpb * (R + 1) * (8 + 64 * (V / 8) + 8);
-        hipLaunchKernelGGL((k_sweep_zy_fused<V, H>), grid, block, lds, s, a);
-    } else if (nz == 512) {
-        constexpr int V = 8, H = 3, R = 2 * H + 1;
-        a.T = std::min(std::max(T, R), (int)ny);
-        dim3 grid((unsigned)((nx + wpb - 1) / wpb), (unsigned)((ny + a.T - 1) / a.T)), block(kBlock);
-        const size_t lds = (size_t)wpb * (R + 1) * (8 + 64 * (V / 8) + 8);
-        hipLaunchKernelGGL((k_sweep_zy_fused<V, H>), grid, block, lds, s, a);
-    } else {
-        constexpr int V = 16, H = 2, R = 2 * H + 1;
-        a.T = std::min(std::max(T, R), (int)ny);
-        dim3 grid((unsigned)((nx + wpb - 1) / wpb), (unsigned)((ny + a.T - 1) / a.T)), block(kBlock);
-        const size_t lds = (size_t)wpb * (R + 1) * (8 + 64 * (V / 8) + 8);
-        hipLaunchKernelGGL((k_sweep_zy_fused<V, H>), grid, block, lds, s, a);
-    }
+    dim3 grid((unsigned)((nx + wpb - 1) / wpb), (unsigned)((ny + a.T - 1) / a.T)), block(kBlock);
+    const size_t lds = (size_t)wpb * (R + 1) * (8 + 64 * (V / 8) + 8);
+    if (out16) hipLaunchKernelGGL((k_sweep_zy_fused<V, H, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_sweep_zy_fused<V, H, false>), grid, block, lds, s, a);
+}
+
+// d_side != nullptr: d_out is the int16 plane field, saturated groups go to d_side
+int launch_sweep_zy_fused(sdfgpu_handle h, const uint8_t* d_mask, void* d_out, int32_t* d_side, int64_t nx,
+                          int64_t ny, int64_t nz, hipStream_t s) {
+    FusedZyArgs a{};
+    a.mask = d_mask; a.out = d_out; a.side = d_side; a.nx = (int)nx; a.ny = (int)ny;
+    const int T = h->tune_tzy > 0 ? h->tune_tzy : 64;
+    const bool o16 = d_side != nullptr;
+    if (nz == 512 && h->fused_h == 3) launch_fused_variant<8, 3>(a, T, nx, ny, o16, s);
+    else if (nz == 512) launch_fused_variant<8, 2>(a, T, nx, ny, o16, s);
+    else launch_fused_variant<16, 2>(a, T, nx, ny, o16, s);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
+// K3/16 launch: int16 plane field + side table (optionally with x halo) -> fp32 sdf
+template <int V, int H>
+void launch_x16_variant(const SweepX16Args& a, dim3 grid, dim3 block, bool vb, bool slab, hipStream_t s) {
+    if (vb && slab) hipLaunchKernelGGL((k_sweep_x16<V, H, true, true>), grid, block, 0, s, a);
+    else if (vb) hipLaunchKernelGGL((k_sweep_x16<V, H, true, false>), grid, block, 0, s, a);
+    else if (slab) hipLaunchKernelGGL((k_sweep_x16<V, H, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_x16<V, H, false, false>), grid, block, 0, s, a);
+}
+
+bool plane16_eligible(const sdfgpu_context* h, int64_t ny, int64_t nz) {
+    return h->plane16_on && (nz % 4) == 0 && ((ny * nz) % 8) == 0;
+}
+
+int launch_sweep_x16(sdfgpu_handle h, const int16_t* d_in16, const int32_t* d_side, float* d_out, int64_t halo_lo,
+                     int64_t nxs, int64_t halo_hi, int64_t side_lo, int64_t side_hi, int64_t ny, int64_t nz,
+                     int lo_trunc, int hi_trunc, int64_t x_global, int64_t nx_global, double resolution, int vb,
+                     uint32_t* d_maxdsq, uint32_t* d_status, hipStream_t s) {
+    const int64_t plane = ny * nz;
+    const int V = (h->x16_v == 8) ? 8 : 4;
+    SweepX16Args a{};
+    a.in16 = d_in16; a.side32 = d_side; a.out = d_out;
+    a.ncols = plane / V; a.plane = plane;
+    a.L = (int)(halo_lo + nxs + halo_hi);
+    a.out_lo = (int)halo_lo; a.out_hi = (int)(halo_lo + nxs);
+    a.T = pick_T(h->tune_tx, (int)nxs);
+    a.side_lo = (int)side_lo; a.side_hi = (int)side_hi;
+    a.resolution = resolution;
+    a.lo_truncated = lo_trunc; a.hi_truncated = hi_trunc;
+    a.x_global = x_global; a.nx_global = nx_global; a.ny = ny; a.nz = nz;
+    a.maxdsq = d_maxdsq; a.status = d_status;
+    const int span = a.out_hi - a.out_lo;
+    const int nchunks = (span + a.T - 1) / a.T;
+    const int64_t nbx = (a.ncols + kBlock - 1) / kBlock;
+    if (nbx > 0x7fffffffLL || nchunks > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "sweep grid too large");
+    dim3 grid((unsigned)nbx, (unsigned)nchunks), block(kBlock);
+    const bool slab = lo_trunc || hi_trunc || side_lo > 0 || side_hi < a.L;
+    if (V == 8) launch_x16_variant<8, 3>(a, grid, block, vb != 0, slab, s);
+    else if (h->x16_h == 2) launch_x16_variant<4, 2>(a, grid, block, vb != 0, slab, s);
+    else launch_x16_variant<4, 3>(a, grid, block, vb != 0, slab, s);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -234,28 +283,38 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     HIP_TRY(h, hipSetDevice(h->device));
     canonical_dims(nx, ny, nz);
     const int64_t n = nx * ny * nz;
-    if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
-    if (int rc = ensure(h, h->yzfield, (size_t)n * 4)) return rc;
+    const bool p16 = plane16_eligible(h, ny, nz);
+    if (int rc = ensure(h, h->yzfield, (size_t)n * 4)) return rc;          // int32 plane field / side table
+    if (p16) if (int rc = ensure(h, h->plane16, (size_t)n * 2)) return rc;
+    void* zy_out = p16 ? h->plane16.ptr : h->yzfield.ptr;
+    int32_t* zy_side = p16 ? (int32_t*)h->yzfield.ptr : nullptr;
+    const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
+    if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 16, s));
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (h->profiling) {
         for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
         HIP_TRY(h, hipEventRecord(ev[0], s));
     }
-    const bool fused = !d_cells && fused_zy_eligible(h, d_filled, (const int32_t*)h->yzfield.ptr, nz);
     h->last_fused = fused;
+    h->last_plane16 = p16;
     if (!fused)
         if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
                                     (int16_t*)h->zfield.ptr, s)) return rc;
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[1], s));
     if (fused) {
-        if (int rc = launch_sweep_zy_fused(h, d_filled, (int32_t*)h->yzfield.ptr, nx, ny, nz, s)) return rc;
+        if (int rc = launch_sweep_zy_fused(h, d_filled, zy_out, zy_side, nx, ny, nz, s)) return rc;
     } else {
-        if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, (int32_t*)h->yzfield.ptr, nx, ny, nz, s)) return rc;
+        if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s)) return rc;
     }
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[2], s));
-    if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
-                                resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+    if (p16) {
+        if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
+                                      0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+    } else {
+        if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
+                                    resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+    }
     if (h->profiling) {
         HIP_TRY(h, hipEventRecord(ev[3], s));
         for (auto e : ev) h->events.push_back(e);
@@ -329,7 +388,7 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
 int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
-    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->stage_in, &h->stage_out})
+    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->stage_in, &h->stage_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
     for (auto e : h->events) (void)hipEventDestroy(e);
@@ -406,10 +465,10 @@ int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nxs * ny * nz;
     hipStream_t s = (hipStream_t)stream;
-    if (fused_zy_eligible(h, d_filled, d_plane_dsq, nz)) return launch_sweep_zy_fused(h, d_filled, d_plane_dsq, nxs, ny, nz, s);
+    if (fused_zy_eligible(h, d_filled, d_plane_dsq, nz)) return launch_sweep_zy_fused(h, d_filled, d_plane_dsq, nullptr, nxs, ny, nz, s);
     if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     if (int rc = launch_sweep_z(h, d_filled, nullptr, 0, 0, 0, nxs, ny, nz, (int16_t*)h->zfield.ptr, s)) return rc;
-    return launch_sweep_y(h, (const int16_t*)h->zfield.ptr, d_plane_dsq, nxs, ny, nz, s);
+    return launch_sweep_y(h, (const int16_t*)h->zfield.ptr, d_plane_dsq, nullptr, nxs, ny, nz, s);
 }
 
 int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t halo_lo, int64_t nxs,
@@ -465,6 +524,16 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     HIP_TRY(h, hipMemcpy(out_host, h->yzfield.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (h->last_plane16) {
+        // 16-bit pipeline: the int32 buffer is the side table (valid only for saturated groups of 4)
+        std::vector<int16_t> p16((size_t)n);
+        HIP_TRY(h, hipMemcpy(p16.data(), h->plane16.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
+        for (int64_t g = 0; g + 3 < n; g += 4) {
+            bool sat = false;
+            for (int k = 0; k < 4; ++k) sat |= std::abs((int)p16[(size_t)(g + k)]) >= 32767;
+            if (!sat) for (int k = 0; k < 4; ++k) out_host[g + k] = p16[(size_t)(g + k)];
+        }
+    }
     return SDFGPU_OK;
 }
 
@@ -502,13 +571,16 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "rows_per_chunk_x") h->tune_tx = value;
     else if (n == "rows_per_chunk_zy") h->tune_tzy = value;
     else if (n == "fused_window") h->fused_h = value;
+    else if (n == "plane16") h->plane16_on = value != 0;
+    else if (n == "x16_voxels_per_lane") h->x16_v = value;
+    else if (n == "x16_window") h->x16_h = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return SDFGPU_OK;
 }
 
 int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy) {
     if (!h || !out_fused_zy) return SDFGPU_ERR_INVALID_ARGUMENT;
-    *out_fused_zy = h->last_fused ? 1 : 0;
+    *out_fused_zy = (h->last_fused ? 1 : 0) | (h->last_plane16 ? 2 : 0);
     return SDFGPU_OK;
 }
 

@@ -14,6 +14,7 @@
 // exact for any input.  Used when nz is 512 or 1024 (the benchmark shapes); other shapes take K1 + K2.
 #pragma once
 #include "sdfgpu_kernels.hpp"
+#include "sdfgpu_sweep_x16.hpp"
 
 namespace sdfgpu {
 
@@ -31,7 +32,8 @@ __device__ __forceinline__ uint32_t pack_mask_bits(const typename MaskRawT<V>::t
 
 struct FusedZyArgs {
     const uint8_t* mask;
-    int32_t* out;
+    void* out;          // int32 plane field, or int16 plane field when OUT16
+    int32_t* side;      // OUT16: exact values of saturated 4-voxel groups
     int nx, ny;     // x-planes in this launch, rows per plane (nz = 64*V is a template constant)
     int T;          // rows marched per wave
 };
@@ -82,7 +84,7 @@ __device__ __forceinline__ void row_from_bitmap(const unsigned char* row, int la
     }
 }
 
-template <int V, int H>
+template <int V, int H, bool OUT16>
 __global__ __launch_bounds__(kBlock) void k_sweep_zy_fused(const FusedZyArgs a) {
     constexpr int R = 2 * H + 1;
     constexpr int BPL = V / 8;                     // bitmap bytes per lane
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_zy_fused(const FusedZyArgs a) 
     const int p1 = min(L, p0 + a.T);
     if (p0 >= p1) return;
     const uint8_t* col_in = a.mask + (int64_t)x * L * nz + lane * V;
-    int32_t* col_out = a.out + (int64_t)x * L * nz + lane * V;
+    const int64_t col_elem = (int64_t)x * L * nz + lane * V;
 
     auto put_bits = [&](int slot, const RawT& raw) {
         const uint32_t bits = pack_mask_bits<V>(raw);
@@ -180,9 +182,25 @@ __global__ __launch_bounds__(kBlock) void k_sweep_zy_fused(const FusedZyArgs a) 
             const int D = min(best[k], kInf32);
             o[k] = (D ^ m[k]) + negm[k];
         }
-        int4* dst = reinterpret_cast<int4*>(col_out + (int64_t)p * nz);
+        const int64_t oelem = col_elem + (int64_t)p * nz;
+        if constexpr (OUT16) {
+            uint2 pk[V / 4];
 #pragma unroll
-        for (int q = 0; q < V / 4; ++q) dst[q] = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            for (int q = 0; q < V / 4; ++q) {
+                const int grp[4] = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+                pk[q] = pack_plane16_group(grp, a.side + oelem + 4 * q);
+            }
+            int16_t* dst = reinterpret_cast<int16_t*>(a.out) + oelem;
+            if constexpr (V == 8) *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0].x, pk[0].y, pk[1].x, pk[1].y);
+            else {
+                reinterpret_cast<uint4*>(dst)[0] = make_uint4(pk[0].x, pk[0].y, pk[1].x, pk[1].y);
+                reinterpret_cast<uint4*>(dst)[1] = make_uint4(pk[2].x, pk[2].y, pk[3].x, pk[3].y);
+            }
+        } else {
+            int4* dst = reinterpret_cast<int4*>(reinterpret_cast<int32_t*>(a.out) + oelem);
+#pragma unroll
+            for (int q = 0; q < V / 4; ++q) dst[q] = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        }
     };
 
     // prologue: rows p0-H .. p0+H-1 -> slots 0 .. 2H-1

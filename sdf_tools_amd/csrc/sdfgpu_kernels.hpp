@@ -209,6 +209,9 @@ struct SweepArgs {
     int64_t nx_global, ny, nz;        // full extents (virtual border)
     uint32_t* maxdsq;                 // [0] free, [1] filled
     uint32_t* status;                 // bit 0: unresolved voxel (slab mode)
+    // K2 with 16-bit output (plane16 + side table, see sdfgpu_sweep_x16.hpp)
+    int out16;
+    int32_t* side;
 };
 
 template <int STAGE, int V> struct InVecT;
@@ -372,9 +375,27 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
                 o[k] = (D ^ m[k]) + negm[k];
             }
             if (valid) {
-                int32_t* dst = reinterpret_cast<int32_t*>(a.out) + oelem;
-                if constexpr (V == 4) *reinterpret_cast<int4*>(dst) = make_int4(o[0], o[1], o[2], o[3]);
-                else *dst = o[0];
+                if (a.out16) {
+                    // plane16 format: saturate at +-32767, exact values of saturated groups to the side table
+                    if constexpr (V == 4) {
+                        bool sat = false;
+                        int s16[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int mag = abs(o[k]);
+                            sat |= mag >= 32767;
+                            s16[k] = o[k] < 0 ? -min(mag, 32767) : min(mag, 32767);
+                        }
+                        if (sat) *reinterpret_cast<int4*>(a.side + oelem) = make_int4(o[0], o[1], o[2], o[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<int16_t*>(a.out) + oelem) =
+                            make_uint2(((uint32_t)s16[0] & 0xffffu) | ((uint32_t)s16[1] << 16),
+                                       ((uint32_t)s16[2] & 0xffffu) | ((uint32_t)s16[3] << 16));
+                    }
+                } else {
+                    int32_t* dst = reinterpret_cast<int32_t*>(a.out) + oelem;
+                    if constexpr (V == 4) *reinterpret_cast<int4*>(dst) = make_int4(o[0], o[1], o[2], o[3]);
+                    else *dst = o[0];
+                }
             }
         } else {
             float o[V];
