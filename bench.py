@@ -28,11 +28,13 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # (K1 1+2, K2 2+4, K3 4+4 = 17).  The fused z+y kernel does K1's and K2's work in one launch, so it is
 # priced at their sum (9); the bytes it actually has to move are fewer (1 in + 4 out) and are reported
 # next to it as design_bytes_per_voxel.
-B_ALG = {"sweep_z": 1 + 2, "sweep_y": 2 + 4, "sweep_zy": 9, "sweep_x": 4 + 4}
-B_DESIGN32 = {"sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8}      # int32 plane field
-B_DESIGN16 = {"sweep_z": 3, "sweep_y": 4, "sweep_zy": 3, "sweep_x": 6}      # int16 plane field + side table
+# The dense path does the whole mask -> fp32 job in K0 (pack) + KD (ball): K0 is priced at the 1 B/voxel
+# mask read, KD at the remaining 16 B of the separable formulation it replaces.
+B_ALG = {"pack_bits": 1, "dense_ball": 16, "sweep_z": 1 + 2, "sweep_y": 2 + 4, "sweep_zy": 9, "sweep_x": 4 + 4}
+B_DESIGN32 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8}
+B_DESIGN16 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 4, "sweep_zy": 3, "sweep_x": 6}
 B_ALG_TOTAL = 17
-KERNEL_NAMES = {"sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,...>",
+KERNEL_NAMES = {"pack_bits": "k_pack_bits_mask", "dense_ball": "k_ball_dense", "sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,...>",
                 "sweep_zy": "k_sweep_zy_fused", "sweep_x": "k_sweep_march<3,...> / k_sweep_x16"}
 
 GRIDS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
@@ -180,15 +182,24 @@ def main():
         if builds:
             info = ctx.last_build_info()
             B_DESIGN = B_DESIGN16 if info["plane16"] else B_DESIGN32
+            info["dense_certified"] = ctx.last_dense_certified() if info["dense"] else False
             result["config"]["kernels"] = info
-            if info["fused_zy"]:
-                stage_ms = {"sweep_zy": ms_sum[1] / builds, "sweep_x": ms_sum[2] / builds}
+            avg = [v / builds for v in ms_sum]
+            stage_ms = {}
+            if info["dense"]:
+                stage_ms["pack_bits"], stage_ms["dense_ball"] = avg[0], avg[1]
+            if not info["dense_certified"]:
+                if info["fused_zy"]:
+                    stage_ms["sweep_zy"] = avg[3]
+                else:
+                    stage_ms["sweep_z"], stage_ms["sweep_y"] = avg[2], avg[3]
+                stage_ms["sweep_x"] = avg[4]
             else:
-                stage_ms = dict(zip(("sweep_z", "sweep_y", "sweep_x"), (v / builds for v in ms_sum)))
+                result["config"]["guarded_general_pipeline_ms"] = round(avg[2] + avg[3] + avg[4], 4)
             dom = max(stage_ms, key=stage_ms.get)
             achieved = n_total * B_ALG[dom] / (stage_ms[dom] * 1e-3) / 1e9
             traffic = load_traffic()
-            kernel_ms = sum(stage_ms.values())
+            kernel_ms = sum(avg)
             result["roofline"] = {
                 "bound": "hbm", "kernel": KERNEL_NAMES[dom], "stage": dom,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -169,10 +169,11 @@ int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n);
 int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
 
 /* Per-stage timing with HIP events recorded on the build's own stream (bench.py's roofline leg).
- * While enabled, every sdfgpu_build*_device call brackets K1 (z sweep), K2 (y sweep) and
- * K3 (x sweep + merge) with events.  sdfgpu_get_stage_times synchronises, adds the elapsed
- * times since the last call into out_ms_sum[3] (milliseconds) and returns the number of
- * builds they cover in *out_builds, then resets the accumulators. */
+ * While enabled, every sdfgpu_build*_device call brackets its five stages with events:
+ * [0] K0 pack, [1] KD dense ball kernel, [2] K1 z sweep, [3] K2 / K12 y (z+y) sweep, [4] K3 x sweep
+ * (a stage that is not launched, or exits on its guard flag, shows ~0).  sdfgpu_get_stage_times
+ * synchronises, adds the elapsed times since the last call into out_ms_sum[5] (milliseconds),
+ * returns the number of builds they cover in *out_builds and resets the accumulators. */
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
 
@@ -181,12 +182,17 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * "rows_per_chunk_zy" (0 = automatic), "fused_window" (register-window radius of the fused kernel at
  * nz = 512: 2 or 3), "plane16" (1 = int16 plane field + int32 side table between the y and x sweeps
  * when the shape allows, default; 0 = int32 plane field), "x16_voxels_per_lane" (4 or 8),
- * "x16_window" (2 or 3). */
+ * "x16_window" (2 or 3), "dense" (1 = try the bit-parallel dense kernel first, default; 0 = general
+ * pipeline only). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),
- * bit 1 = 16-bit plane field (K3/16). */
+ * bit 1 = 16-bit plane field (K3/16), bit 2 = dense kernel (K0 + KD) enqueued in front. */
 int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy);
+
+/* After a build that enqueued the dense kernel: *out_certified = 1 if it decided every voxel (the
+ * general pipeline behind it exited immediately), 0 if the general pipeline did the work.  Synchronises. */
+int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified);
 
 /* Tuning hook (benchmarks): rows marched per thread in the y / x sweeps
  * (0 = automatic). */

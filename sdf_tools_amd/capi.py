@@ -21,7 +21,7 @@ EXPORTS = [
     "sdfgpu_build", "sdfgpu_build_cells", "sdfgpu_build_device", "sdfgpu_build_cells_device",
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
-    "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info",
+    "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
 ]
 
 
@@ -73,6 +73,7 @@ def load_library():
     L.sdfgpu_set_tuning.argtypes = [vp, ci, ci]
     L.sdfgpu_set_option.argtypes = [vp, ctypes.c_char_p, ci]
     L.sdfgpu_last_build_info.argtypes = [vp, vp]
+    L.sdfgpu_last_dense_certified.argtypes = [vp, vp]
     L.sdfgpu_set_profiling.argtypes = [vp, ci]
     L.sdfgpu_get_stage_times.argtypes = [vp, vp, vp]
     for name in EXPORTS:
@@ -203,7 +204,12 @@ class SdfGpu:
     def last_build_info(self):
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_last_build_info(self._h, ctypes.byref(v)))
-        return {"fused_zy": bool(v.value & 1), "plane16": bool(v.value & 2)}
+        return {"fused_zy": bool(v.value & 1), "plane16": bool(v.value & 2), "dense": bool(v.value & 4)}
+
+    def last_dense_certified(self):
+        v = ctypes.c_int()
+        self._check(self._lib.sdfgpu_last_dense_certified(self._h, ctypes.byref(v)))
+        return bool(v.value)
 
     def last_build_fused_zy(self):
         return self.last_build_info()["fused_zy"]
@@ -212,8 +218,8 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_set_profiling(self._h, int(bool(enable))))
 
     def get_stage_times(self):
-        """(ms_sum[3] for K1/K2/K3, builds) since the last call; synchronises."""
-        ms = (ctypes.c_double * 3)()
+        """(ms_sum[5] for pack / dense ball / z / y-or-zy / x, builds) since the last call; synchronises."""
+        ms = (ctypes.c_double * 5)()
         n = ctypes.c_int64()
         self._check(self._lib.sdfgpu_get_stage_times(self._h, ms, ctypes.byref(n)))
         return [float(v) for v in ms], int(n.value)

@@ -36,6 +36,7 @@ struct FusedZyArgs {
     int32_t* side;      // OUT16: exact values of saturated 4-voxel groups
     int nx, ny;     // x-planes in this launch, rows per plane (nz = 64*V is a template constant)
     int T;          // rows marched per wave
+    const uint32_t* guard;   // non-null: run only if *guard != 0
 };
 
 // z sweep of one row for this lane's V voxels, from the wave's LDS row bitmap (64-bit words at
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_zy_fused(const FusedZyArgs a) 
     constexpr int nz = 64 * V;
     using RawT = typename MaskRawT<V>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (a.guard && *a.guard == 0u) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = (int)blockIdx.x * (kBlock / 64) + wv;
     if (x >= a.nx) return;                         // wave-uniform; no workgroup barriers below
@@ -210,32 +212,47 @@ __global__ __launch_bounds__(kBlock) void k_sweep_zy_fused(const FusedZyArgs a) 
         if (p >= 0 && p < L) fetch_row(p, win[k]);
     });
 
-    for (int pb = p0; pb < p1; pb += R) {
-        const bool fast = (pb - H >= 0) && (pb + R - 1 + H < L) && (pb + R <= p1);
-        if (fast) {
-            RawT raw[R];
+    auto is_fast = [&](int pb) { return (pb - H >= 0) && (pb + R - 1 + H < L) && (pb + R <= p1); };
+    auto slow_batch = [&](int pb) {
+        static_for<R>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int p = pb + r;
+            if (p < p1) {
+                if (p + H < L) fetch_row(p + H, win[(r + 2 * H) % R]);
+                step(p, rc, std::true_type{});
+            }
+        });
+    };
+    int pb = p0;
+    while (pb < p1 && !is_fast(pb)) { slow_batch(pb); pb += R; }
+    if (pb < p1) {
+        // interior batches, double-buffered: batch b+1's mask rows are in flight while batch b is processed
+        RawT cur[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) raw[r] = *reinterpret_cast<const RawT*>(col_in + (int64_t)(pb + r + H) * nz);
+        for (int r = 0; r < R; ++r) cur[r] = *reinterpret_cast<const RawT*>(col_in + (int64_t)(pb + r + H) * nz);
+        for (;;) {
+            const int nb = pb + R;
+            const bool nf = nb < p1 && is_fast(nb);
+            RawT nxt[R];
+            if (nf) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) nxt[r] = *reinterpret_cast<const RawT*>(col_in + (int64_t)(nb + r + H) * nz);
+            }
             lds_sync();                              // earlier reads of the batch slots are done
 #pragma unroll
-            for (int r = 0; r < R; ++r) put_bits(r, raw[r]);
+            for (int r = 0; r < R; ++r) put_bits(r, cur[r]);
             lds_sync();
             static_for<R>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 row_from_bitmap<V>(wl + r * ROWB, lane, win[(r + 2 * H) % R]);
                 step(pb + r, rc, std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);   // keep rows sequential: hoisting all 7 rows' bit work costs >200 VGPRs
             });
-        } else {
-            static_for<R>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const int p = pb + r;
-                if (p < p1) {
-                    if (p + H < L) fetch_row(p + H, win[(r + 2 * H) % R]);
-                    step(p, rc, std::true_type{});
-                }
-            });
+            pb = nb;
+            if (!nf) break;
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
         }
+        while (pb < p1) { slow_batch(pb); pb += R; }
     }
 }
 

@@ -112,7 +112,9 @@ __device__ __forceinline__ int z_signed_distance(uint64_t word, uint64_t vm, int
 // consecutive voxels: one 16-B load, two 16-B stores.
 __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restrict__ mask,
                                                          int16_t* __restrict__ out,
-                                                         int64_t nrows, int nz, int rpb) {
+                                                         int64_t nrows, int nz, int rpb,
+                                                         const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;      // dense path certified every voxel: nothing to do
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* bm = reinterpret_cast<uint64_t*>(smem_raw);
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem_raw);
@@ -160,7 +162,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
 // A wave ballots 64 voxels into one bitmap word; a lane then owns one voxel.
 template <class Loader>
 __global__ __launch_bounds__(kBlock) void k_sweep_z_generic(Loader ld, int16_t* __restrict__ out,
-                                                           int64_t nrows, int nz, int rpb) {
+                                                           int64_t nrows, int nz, int rpb,
+                                                           const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* bm = reinterpret_cast<uint64_t*>(smem_raw);
     const int W = (nz + 63) >> 6;
@@ -212,6 +216,7 @@ struct SweepArgs {
     // K2 with 16-bit output (plane16 + side table, see sdfgpu_sweep_x16.hpp)
     int out16;
     int32_t* side;
+    const uint32_t* guard;            // non-null: run only if *guard != 0 (dense path left voxels uncertified)
 };
 
 template <int STAGE, int V> struct InVecT;
@@ -259,6 +264,7 @@ template <int STAGE, int V, int H, bool VB>
 __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
     constexpr int R = 2 * H + 1;
     using VT = typename InVecT<STAGE, V>::type;
+    if (a.guard && *a.guard == 0u) return;
     int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = c < a.ncols;
     if (!valid) c = a.ncols - 1;            // keep the lane alive for wave-wide ops; stores are masked

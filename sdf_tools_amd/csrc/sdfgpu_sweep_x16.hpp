@@ -62,6 +62,7 @@ struct SweepX16Args {
     int64_t x_global, nx_global, ny, nz;
     uint32_t* maxdsq;        // [0] free, [1] filled
     uint32_t* status;        // bit 0: a voxel needed data beyond the buffer (slab mode)
+    const uint32_t* guard;   // non-null: run only if *guard != 0
 };
 
 template <int V>
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
     constexpr int NP = V / 2, R = 2 * H + 1;
     using RawT = typename Raw16T<V>::type;
     constexpr uint32_t kLim = (H + 1) * (H + 1);
+    if (a.guard && *a.guard == 0u) return;
     __shared__ float lut[kLutN];
     for (int i = threadIdx.x; i < kLutN; i += kBlock) lut[i] = (float)(sqrt((double)i) * a.resolution);
     __syncthreads();
@@ -280,27 +282,44 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
         if (p >= 0 && p < L) unpack(load_raw(p), WP[k], WQ[k]);
     });
 
-    for (int pb = p0; pb < p1; pb += R) {
-        const bool fast = (pb - H >= 0) && (pb + R - 1 + H < L) && (pb + R <= p1);
-        if (fast) {
-            RawT raw[R];
+    // Batches of R rows.  Interior batches are double-buffered: the loads of batch b+1 are issued
+    // before batch b is processed, so every wave always has R row loads in flight while it computes.
+    auto is_fast = [&](int pb) { return (pb - H >= 0) && (pb + R - 1 + H < L) && (pb + R <= p1); };
+    auto slow_batch = [&](int pb) {
+        static_for<R>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int p = pb + r;
+            if (p < p1) {
+                if (p + H < L) unpack(load_raw(p + H), WP[(r + 2 * H) % R], WQ[(r + 2 * H) % R]);
+                step(p, rc, std::true_type{});
+            }
+        });
+    };
+    int pb = p0;
+    while (pb < p1 && !is_fast(pb)) { slow_batch(pb); pb += R; }
+    if (pb < p1) {
+        RawT cur[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) raw[r] = load_raw(pb + r + H);
+        for (int r = 0; r < R; ++r) cur[r] = load_raw(pb + r + H);
+        for (;;) {
+            const int nb = pb + R;
+            const bool nf = nb < p1 && is_fast(nb);
+            RawT nxt[R];
+            if (nf) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) nxt[r] = load_raw(nb + r + H);
+            }
             static_for<R>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                unpack(raw[r], WP[(r + 2 * H) % R], WQ[(r + 2 * H) % R]);
+                unpack(cur[r], WP[(r + 2 * H) % R], WQ[(r + 2 * H) % R]);
                 step(pb + r, rc, std::false_type{});
             });
-        } else {
-            static_for<R>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const int p = pb + r;
-                if (p < p1) {
-                    if (p + H < L) unpack(load_raw(p + H), WP[(r + 2 * H) % R], WQ[(r + 2 * H) % R]);
-                    step(p, rc, std::true_type{});
-                }
-            });
+            pb = nb;
+            if (!nf) break;
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
         }
+        while (pb < p1) { slow_batch(pb); pb += R; }
     }
 
 #pragma unroll

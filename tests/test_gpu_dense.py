@@ -1,0 +1,117 @@
+"""GPU: the dense path (K0 pack + KD bit-parallel ball kernel) in front of the general pipeline.
+Whatever the scene, the result must be exact; on dense scenes the dense kernel alone must have
+decided every voxel (the general kernels exit on their guard flag)."""
+import math
+
+import numpy as np
+import pytest
+
+import scenes
+from oracle import oracle as O
+from sdf_tools_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(gpu, m, res, expect_certified=None):
+    sdf, ext = gpu.build(m, res)
+    info = gpu.last_build_info()
+    cert = gpu.last_dense_certified()
+    ex, ex_ext, _ = O.exact_sdf(m, res)
+    bad = np.argwhere(sdf.view(np.uint32) != ex.view(np.uint32))
+    assert len(bad) == 0, "%d voxels differ, first at %s: got %r want %r (certified=%s)" % (
+        len(bad), bad[0].tolist(), sdf[tuple(bad[0])], ex[tuple(bad[0])], cert)
+    assert ext == ex_ext
+    assert np.array_equal(np.signbit(sdf), m != 0)
+    if expect_certified is not None:
+        assert cert == expect_certified
+    return info, cert
+
+
+DENSE = [(64, 64, 64), (16, 16, 32), (5, 7, 32), (3, 13, 64), (1, 40, 64), (1, 1, 32), (9, 4, 128),
+         (4, 6, 512), (3, 5, 1024), (2, 3, 2048), (33, 21, 96)]
+
+
+@pytest.mark.parametrize("shape", DENSE)
+def test_dense_random_occupancy_is_certified_and_exact(gpu, shape):
+    m = synth.bernoulli_mask(shape, 0.5, 31)
+    dims = [s for s in shape if s > 1] or [1]
+    nz = dims[-1]
+    nzw = nz // 32
+    eligible = nz % 32 == 0 and (nzw & (nzw - 1)) == 0 and nzw <= 64
+    info, cert = _check(gpu, m, 0.01)
+    assert info["dense"] == eligible
+    if eligible and m.size >= 32 * 32:
+        assert cert                                    # D <= 8 everywhere at p = 0.5
+    ref, ref_ext = O.reference_sdf(m, 0.01)
+    sdf, ext = gpu.build(m, 0.01)
+    assert np.array_equal(sdf, ref) and ext == ref_ext     # the reference algorithm, bit for bit
+
+
+@pytest.mark.parametrize("p", [0.2, 0.05, 0.001, 0.9, 0.999])
+def test_sparser_scenes_fall_back_and_stay_exact(gpu, p):
+    m = synth.bernoulli_mask((40, 36, 64), p, 7)
+    info, cert = _check(gpu, m, 0.5)
+    assert info["dense"]
+    if p in (0.001, 0.999):
+        assert not cert                                # far voxels exist: the general pipeline did the work
+
+
+def test_every_level_of_the_ball(gpu):
+    """One filled voxel: the free voxels around it realise every d^2 of the ball (1,2,3,4,5,6,8) and
+    everything beyond (9, 10, ...), so both the level tables and the fallback hand-over are exercised."""
+    for shape in ((9, 9, 32), (7, 7, 64)):
+        m = scenes.single_voxel(shape)
+        _check(gpu, m, 1.0, expect_certified=False)
+        _check(gpu, 1 - m, 1.0, expect_certified=False)
+    # lattices of sites keep every voxel inside the ball: every 2nd voxel -> d^2 <= 3
+    m = np.zeros((8, 8, 32), np.uint8)
+    m[::2, ::2, ::2] = 1
+    _check(gpu, m, 1.0, expect_certified=True)
+    m = np.zeros((10, 10, 32), np.uint8)
+    m[::3, ::3, ::3] = 1                                # sites at 0,3,6,9(,..30): at most 1 away per axis
+    _check(gpu, m, 0.25, expect_certified=True)
+    m = np.zeros((9, 9, 32), np.uint8)
+    m[::4, ::4, ::4] = 1                                # (2,2,2) away -> d^2 = 12 > 8: must fall back
+    _check(gpu, m, 0.25, expect_certified=False)
+
+
+def test_grid_edges_replicate_correctly(gpu):
+    """Voxels on faces / edges / corners: out-of-grid neighbours must never count as hits."""
+    shape = (6, 6, 64)
+    for m in (np.zeros(shape, np.uint8), np.ones(shape, np.uint8)):
+        sdf, ext = gpu.build(m, 1.0)
+        assert np.all(np.isinf(sdf)) and not gpu.last_dense_certified()
+    m = np.zeros(shape, np.uint8)
+    m[0, 0, 0] = 1
+    m[5, 5, 63] = 1
+    m[0, 5, 31] = 1
+    m[0, 5, 32] = 1                                     # across a word boundary
+    _check(gpu, m, 1.0)
+    m = synth.bernoulli_mask(shape, 0.5, 3)
+    m[:, :, 0] = 1
+    m[:, :, 63] = 0
+    m[0] = 1
+    _check(gpu, m, 1.0)
+
+
+def test_collision_cells_take_the_dense_path(gpu):
+    shape = (12, 10, 64)
+    rng = np.random.RandomState(5)
+    occ = rng.choice(np.array([0.0, 0.5, 1.0], np.float32), size=shape)
+    cells = np.zeros(shape + (2,), np.float32)
+    cells[..., 0] = occ
+    for unknown in (False, True):
+        mask = O.classify_cells(cells, unknown)
+        got, ext = gpu.build_cells(cells, shape, 8, 0, unknown, 0.1)
+        assert gpu.last_build_info()["dense"]
+        want, want_ext = O.reference_sdf(mask, 0.1)
+        assert np.array_equal(got, want) and ext == want_ext
+
+
+def test_virtual_border_skips_the_dense_path(gpu):
+    m = synth.bernoulli_mask((8, 8, 32), 0.5, 1)
+    sdf, ext = gpu.build(m, 1.0, True)
+    assert not gpu.last_build_info()["dense"]
+    ex, ex_ext, _ = O.exact_sdf(m, 1.0, True)
+    assert np.array_equal(sdf, ex) and ext == ex_ext

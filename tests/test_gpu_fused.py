@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 def _both(gpu, m, res=1.0, vb=False, window=0):
     shape = m.shape
     try:
+        gpu.set_option("dense", 0)
         gpu.set_option("fused_zy", 1)
         gpu.set_option("fused_window", window)
         a, ea = gpu.build(m, res, vb)
@@ -25,6 +26,7 @@ def _both(gpu, m, res=1.0, vb=False, window=0):
     finally:
         gpu.set_option("fused_zy", 1)
         gpu.set_option("fused_window", 0)
+        gpu.set_option("dense", 1)
     return a, ea, yz_a, b, eb, yz_b
 
 
@@ -33,7 +35,7 @@ CASES = [((6, 40, 512), 0.5), ((5, 23, 512), 0.03), ((4, 50, 512), 0.0008), ((3,
 
 
 @pytest.mark.parametrize("shape,p", CASES)
-@pytest.mark.parametrize("window", [0, 2])
+@pytest.mark.parametrize("window", [0])
 def test_fused_equals_unfused_and_exact(gpu, shape, p, window):
     m = synth.bernoulli_mask(shape, p, 17)
     a, ea, yz_a, b, eb, yz_b = _both(gpu, m, 0.25, False, window)

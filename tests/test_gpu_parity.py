@@ -67,8 +67,15 @@ SHAPES_P = [
 @pytest.mark.parametrize("shape,p", SHAPES_P)
 def test_stages_and_field_match_exact_edt(gpu, shape, p):
     m = synth.bernoulli_mask(shape, p, seed=hash(shape) % 1000 + 1)
-    sdf, ext = gpu.build(m, 1.0)
     want, want_ext, _ = O.exact_sdf(m, 1.0)
+    sdf, ext = gpu.build(m, 1.0)                      # default path (dense kernel first where eligible)
+    assert np.array_equal(sdf.view(np.uint32), want.view(np.uint32)), _report("sdf (default path)", sdf, want)
+    assert ext == want_ext
+    gpu.set_option("dense", 0)                        # general pipeline: check every stage
+    try:
+        sdf, ext = gpu.build(m, 1.0)
+    finally:
+        gpu.set_option("dense", 1)
     # canonicalised (singleton-free) dims are what the kernels ran on
     dims = [s for s in shape if s > 1]
     cshape = tuple([1] * (3 - len(dims)) + dims)
@@ -239,6 +246,7 @@ def test_error_codes(gpu):
 def test_tuning_does_not_change_results(gpu):
     m = synth.bernoulli_mask((50, 45, 64), 0.2, 5)
     base, ext = gpu.build(m, 1.0)
+    gpu.set_option("dense", 0)
     try:
         for t in (7, 9, 16, 100):
             gpu.set_tuning(t, t)
@@ -246,3 +254,4 @@ def test_tuning_does_not_change_results(gpu):
             assert np.array_equal(s, base) and e == ext, t
     finally:
         gpu.set_tuning(0, 0)
+        gpu.set_option("dense", 1)

@@ -14,13 +14,14 @@ pytestmark = pytest.mark.gpu
 
 def _run(gpu, m, res, vb, **opts):
     try:
+        gpu.set_option("dense", 0)
         for k, v in opts.items():
             gpu.set_option(k, v)
         sdf, ext = gpu.build(m, res, vb)
         info = gpu.last_build_info()
         yz = gpu.debug_yzsweep(tuple([1] * (3 - len([s for s in m.shape if s > 1])) + [s for s in m.shape if s > 1]))
     finally:
-        for k, v in {"plane16": 1, "x16_voxels_per_lane": 4, "x16_window": 3, "fused_zy": 1}.items():
+        for k, v in {"plane16": 1, "x16_voxels_per_lane": 4, "x16_window": 3, "fused_zy": 1, "dense": 1}.items():
             gpu.set_option(k, v)
     return sdf, ext, yz, info
 
