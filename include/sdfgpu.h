@@ -144,6 +144,21 @@ int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq,
                           float* d_out_sdf, uint32_t* d_maxdsq, uint32_t* d_status,
                           void* stream);
 
+/* Dense-scene stages (see sdf_tools_amd/csrc/sdfgpu_dense.hpp), also usable on x slabs:
+ *   sdfgpu_pack_bits_device : n_rows z-rows of nz occupancy bytes -> n_rows * nz / 32 words (bit i of
+ *       word w = voxel z = 32 w + i is filled); nz % 32 == 0.
+ *   sdfgpu_dense_ball_device: bit planes [rows_x, ny, nz/32] -> fp32 SDF of planes [out_lo, out_hi),
+ *       exact for every voxel whose nearest opposite-class voxel is within squared distance 8
+ *       (needs 2 planes of context on each side, i.e. halo planes from the x neighbours in slab
+ *       mode; at a true grid face the buffer simply ends).  Raises *d_uncertified (uint32, caller-
+ *       zeroed) if some voxel is farther than that -- the caller must then run the general path.
+ *       d_maxdsq[2] as in sdfgpu_sweep_x_device.  nz must be 32 * 2^k <= 2048. */
+int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_rows, int64_t nz,
+                            uint32_t* d_bits, void* stream);
+int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t rows_x, int64_t out_lo,
+                             int64_t out_hi, int64_t ny, int64_t nz, double resolution,
+                             float* d_out_sdf, uint32_t* d_maxdsq, uint32_t* d_uncertified, void* stream);
+
 /* (max, min) from the two integer maxima (0 = class absent, >= SDFGPU_DSQ_INF =
  * infinite), reproducing sdf_generation.hpp:246-269 / :416-418. */
 int sdfgpu_extrema_from_dsq(uint32_t max_dsq_free, uint32_t max_dsq_filled,

@@ -22,6 +22,7 @@ EXPORTS = [
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
+    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device",
 ]
 
 
@@ -66,6 +67,8 @@ def load_library():
     L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
     L.sdfgpu_sweep_zy_device.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     L.sdfgpu_sweep_x_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, ci, ci, i64, i64, dbl, ci, vp, vp, vp, vp]
+    L.sdfgpu_pack_bits_device.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.sdfgpu_dense_ball_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, dbl, vp, vp, vp, vp]
     L.sdfgpu_extrema_from_dsq.argtypes = [u32, u32, dbl, vp, vp]
     L.sdfgpu_gradient_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci, vp]
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
@@ -181,6 +184,15 @@ class SdfGpu:
                                                     int(bool(hi_truncated)), int(x_global), int(nx_global),
                                                     float(resolution), int(bool(add_virtual_border)),
                                                     d_out, d_maxdsq, d_status or None, stream or None))
+
+    def pack_bits_device(self, d_filled, n_rows, nz, d_bits, stream=0):
+        self._check(self._lib.sdfgpu_pack_bits_device(self._h, d_filled, int(n_rows), int(nz), d_bits, stream or None))
+
+    def dense_ball_device(self, d_bits, rows_x, out_lo, out_hi, ny, nz, resolution, d_out, d_maxdsq, d_uncertified,
+                          stream=0):
+        self._check(self._lib.sdfgpu_dense_ball_device(self._h, d_bits, int(rows_x), int(out_lo), int(out_hi), int(ny),
+                                                       int(nz), float(resolution), d_out, d_maxdsq, d_uncertified,
+                                                       stream or None))
 
     def gradient_device(self, d_sdf, shape, d_out, resolution=1.0, enable_edge_gradients=True, f64=True, stream=0):
         nx, ny, nz = (int(s) for s in shape)

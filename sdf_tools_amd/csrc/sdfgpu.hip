@@ -295,7 +295,9 @@ int launch_pack_bits(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells
                            ld, d_bits, n);
     } else if ((reinterpret_cast<uintptr_t>(d_mask) % 16) == 0) {
         const int64_t n16 = n / 16;
-        hipLaunchKernelGGL(k_pack_bits_mask, dim3((unsigned)((n16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_mask, d_bits, n16);
+        const int64_t per_block = (int64_t)kBlock * kPackChunks;
+        hipLaunchKernelGGL(k_pack_bits_mask, dim3((unsigned)((n16 + per_block - 1) / per_block)), dim3(kBlock), 0, s, d_mask,
+                           d_bits, n16);
     } else {
         MaskLoader ld{d_mask};
         hipLaunchKernelGGL(k_pack_bits_generic<MaskLoader>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
@@ -321,6 +323,8 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
         if (cost < best_cost || (cost == best_cost && ty > best_ty)) { best_cost = cost; best_tx = tx; best_ty = ty; }
     }
     a.tx = best_tx; a.ty = best_ty;
+    a.log2_ty = 0;
+    while ((1 << a.log2_ty) < a.ty) ++a.log2_ty;
     a.resolution = resolution;
     a.maxdsq = d_maxdsq; a.uncertified = d_uncert;
     const int64_t gx = (ny + a.ty - 1) / a.ty, gy = (out_hi - out_lo + a.tx - 1) / a.tx;
@@ -348,7 +352,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (p16) if (int rc = ensure(h, h->plane16, (size_t)n * 2)) return rc;
     void* zy_out = p16 ? h->plane16.ptr : h->yzfield.ptr;
     int32_t* zy_side = p16 ? (int32_t*)h->yzfield.ptr : nullptr;
-    const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
+    // When the dense kernel runs in front, the general pipeline only does work on scenes that are
+    // not dense; there K1 + K2 (rows from the int16 z field) beat the fused kernel's recomputation.
+    const bool dense = dense_eligible(h, nz, vb) && ny <= 0x7fffffff;
+    const bool fused = !dense && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 16, s));
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -358,7 +365,6 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     }
     // Dense path first: exact wherever the nearest opposite voxel is within d^2 <= 8; raises
     // d_small[3] otherwise, in which case (and only then) the general pipeline below does any work.
-    const bool dense = dense_eligible(h, nz, vb) && ny <= 0x7fffffff;
     h->last_dense = dense;
     h->guard = nullptr;
     if (dense) {
@@ -565,6 +571,28 @@ int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t h
     return launch_sweep_x(h, d_plane_dsq, d_out_sdf, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated,
                           x_global, nx_global, resolution, add_virtual_border, d_maxdsq, d_status,
                           (hipStream_t)stream);
+}
+
+int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_rows, int64_t nz, uint32_t* d_bits,
+                            void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_filled || !d_bits) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (n_rows <= 0 || nz <= 0 || (nz % 32) != 0) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "pack_bits needs nz % 32 == 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_pack_bits(h, d_filled, nullptr, 0, 0, 0, n_rows * nz, d_bits, (hipStream_t)stream);
+}
+
+int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t rows_x, int64_t out_lo, int64_t out_hi,
+                             int64_t ny, int64_t nz, double resolution, float* d_out_sdf, uint32_t* d_maxdsq,
+                             uint32_t* d_uncertified, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_bits || !d_out_sdf || !d_maxdsq || !d_uncertified) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (out_lo < 0 || out_hi <= out_lo || out_hi > rows_x) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "inconsistent slab geometry");
+    if (int rc = check_dims(h, rows_x, ny, nz)) return rc;
+    if (!dense_eligible(h, nz, 0)) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense kernel needs nz = 32 * 2^k <= 2048");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_ball_dense(h, d_bits, d_out_sdf, rows_x, out_lo, out_hi, ny, nz, resolution, d_maxdsq, d_uncertified,
+                             (hipStream_t)stream);
 }
 
 int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz,

@@ -32,16 +32,27 @@ namespace sdfgpu {
 // ---------------------------------------------------------------------------------------------
 
 // uint8 mask, nz % 32 == 0, 16-byte aligned: a lane folds 16 bytes, lane pairs form one 32-bit word.
+// Each lane handles kPackChunks chunks a whole grid apart, so four independent 16-byte loads are in
+// flight per lane and the launch has 4x fewer workgroups to schedule.
+constexpr int kPackChunks = 4;
 __global__ __launch_bounds__(kBlock) void k_pack_bits_mask(const uint8_t* __restrict__ mask,
                                                           uint32_t* __restrict__ bits, int64_t n16) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;       // 16-voxel chunk index
-    uint32_t b = 0;
-    if (i < n16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(mask + 16 * i);
-        b = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) | (nonzero_bits4(v.w) << 12);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // 16-voxel chunk index
+    uint4 v[kPackChunks];
+#pragma unroll
+    for (int k = 0; k < kPackChunks; ++k) {
+        const int64_t i = i0 + k * stride;
+        v[k] = (i < n16) ? *reinterpret_cast<const uint4*>(mask + 16 * i) : make_uint4(0, 0, 0, 0);
     }
-    const uint32_t other = __shfl_xor(b, 1);
-    if (i < n16 && (threadIdx.x & 1) == 0) bits[i >> 1] = b | (other << 16);
+#pragma unroll
+    for (int k = 0; k < kPackChunks; ++k) {
+        const int64_t i = i0 + k * stride;
+        const uint32_t b = nonzero_bits4(v[k].x) | (nonzero_bits4(v[k].y) << 4) | (nonzero_bits4(v[k].z) << 8) |
+                           (nonzero_bits4(v[k].w) << 12);
+        const uint32_t other = __shfl_xor(b, 1);
+        if (i < n16 && (threadIdx.x & 1) == 0) bits[i >> 1] = b | (other << 16);
+    }
 }
 
 // any loader (COLLISION_CELL records, unaligned masks): one ballot = 64 voxels; needs nz % 32 == 0
@@ -70,7 +81,8 @@ struct DenseArgs {
     int ny;
     int rows_x;             // x-planes present in `bits`
     int out_lo, out_hi;     // x-planes (buffer coordinates) whose voxels are written
-    int tx, ty;             // tile rows per workgroup along x / y; tx * ty * nzw == 256
+    int tx, ty;             // tile rows per workgroup along x / y (powers of two); tx * ty * nzw == 256
+    int log2_ty;
     double resolution;
     uint32_t* maxdsq;       // [0] free, [1] filled
     uint32_t* uncertified;  // set to 1 if some voxel has no opposite-class voxel within d^2 <= 8
@@ -103,24 +115,31 @@ __global__ __launch_bounds__(kBlock) void k_ball_dense(const DenseArgs a) {
 
     const int x0 = a.out_lo + (int)blockIdx.y * a.tx;         // first tile plane (buffer coordinates)
     const int y0 = (int)blockIdx.x * a.ty;
-    // stage the bit-rows of the tile + halo; rows outside the buffer / grid replicate the nearest row
-    for (int i = t; i < hx * hy * rw; i += kBlock) {
-        const int ww = i % rw;
-        const int rr = i / rw;
-        const int jy = rr % hy, jx = rr / hy;
-        const int gx = min(max(x0 + jx - kBallR, 0), a.rows_x - 1);
-        const int gy = min(max(y0 + jy - kBallR, 0), a.ny - 1);
-        const uint32_t* row = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
-        uint32_t v;
-        if (ww == 0) v = (row[0] & 1u) ? ~0u : 0u;                         // replicate the row's first voxel
-        else if (ww == rw - 1) v = (row[nzw - 1] >> 31) ? ~0u : 0u;         // ... and its last voxel
-        else v = row[ww - 1];
-        tile[i] = v;
+    // stage the bit-rows of the tile + halo; rows outside the buffer / grid replicate the nearest row.
+    // Lanes are laid out as (row-in-pass, word) with a power-of-two word pitch so no index needs a division.
+    {
+        const int lgp = max(lg + 1, 2);                       // 2^lgp >= nzw + 2 lanes per staged row
+        const int lw = t & ((1 << lgp) - 1), lr = t >> lgp;   // word slot, row-in-pass
+        const int rpp = kBlock >> lgp;                        // rows staged per pass
+        if (lw < rw) {
+            for (int jx = 0; jx < hx; ++jx) {
+                const int gx = min(max(x0 + jx - kBallR, 0), a.rows_x - 1);
+                for (int jy = lr; jy < hy; jy += rpp) {
+                    const int gy = min(max(y0 + jy - kBallR, 0), a.ny - 1);
+                    const uint32_t* row = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
+                    uint32_t v;
+                    if (lw == 0) v = (row[0] & 1u) ? ~0u : 0u;                     // replicate the row's first voxel
+                    else if (lw == rw - 1) v = (row[nzw - 1] >> 31) ? ~0u : 0u;     // ... and its last voxel
+                    else v = row[lw - 1];
+                    tile[(jx * hy + jy) * rw + lw] = v;
+                }
+            }
+        }
     }
     __syncthreads();
 
     const int r = t >> lg, w = t & (nzw - 1);                 // tile row, word in row
-    const int ty_ = r % a.ty, tx_ = r / a.ty;
+    const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
     const uint32_t* c0 = tile + ((tx_ + kBallR) * hy + (ty_ + kBallR)) * rw + (w + 1);
     const uint32_t O = c0[0];
     uint32_t acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_ball_dense(const DenseArgs a) {
     for (int j = 0; j < 8; ++j) {
         const int v = (j << 10) + (t << 2);                   // voxel index inside the tile (row-major)
         const int rr = v >> lgz, z = v & (nz - 1);
-        const int tyy = rr % a.ty, txx = rr / a.ty;
+        const int tyy = rr & (a.ty - 1), txx = rr >> a.log2_ty;
         const int gx = x0 + txx, gy = y0 + tyy;
         const uint4 pl = reinterpret_cast<const uint4*>(planes)[(rr << lg) + (z >> 5)];
         const int sh = z & 31;
@@ -205,9 +224,9 @@ __global__ __launch_bounds__(kBlock) void k_ball_dense(const DenseArgs a) {
     }
     const bool any_uncert = __any(uncert);
     if ((t & 63) == 0) {
-        if (mxF) atomicMax(a.maxdsq + 0, (uint32_t)mxF);
-        if (mxQ) atomicMax(a.maxdsq + 1, (uint32_t)mxQ);
-        if (any_uncert) atomicOr(a.uncertified, 1u);
+        if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
+        if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
+        if (any_uncert) atomic_or_if_new(a.uncertified, 1u);
     }
 }
 

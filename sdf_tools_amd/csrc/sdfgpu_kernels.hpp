@@ -39,6 +39,17 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// Grid-wide maxima / flags live in single words.  One same-address atomic costs ~12 ns at the L2, so a
+// wave per atomic (8-130 k waves per launch) would serialise for 0.2-1.5 ms -- longer than the kernels
+// themselves.  Read the word first (L2-coherent relaxed load) and only issue the atomic when it would
+// change the value: after the first few hundred waves the maxima are established and nothing is sent.
+__device__ __forceinline__ void atomic_max_if_larger(uint32_t* p, uint32_t v) {
+    if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+}
+__device__ __forceinline__ void atomic_or_if_new(uint32_t* p, uint32_t bits) {
+    if (bits & ~__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(p, bits);
+}
+
 constexpr int kInf16 = 32767;        // "no opposite voxel in this z row"
 constexpr int kInf32 = 1 << 30;      // "no opposite voxel" for squared distances
 constexpr int kFar = 1 << 20;        // position sentinel for the z sweep
@@ -469,9 +480,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
         }
         const bool any_unres = __any(unresolved);
         if ((threadIdx.x & 63) == 0) {
-            if (mxF) atomicMax(a.maxdsq + 0, (uint32_t)mxF);
-            if (mxQ) atomicMax(a.maxdsq + 1, (uint32_t)mxQ);
-            if (any_unres && a.status) atomicOr(a.status, 1u);
+            if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
+            if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
+            if (any_unres && a.status) atomic_or_if_new(a.status, 1u);
         }
     }
 }

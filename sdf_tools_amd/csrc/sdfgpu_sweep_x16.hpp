@@ -329,9 +329,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
     }
     const bool any_unres = __any(unresolved);
     if ((threadIdx.x & 63) == 0) {
-        if (mxF) atomicMax(a.maxdsq + 0, (uint32_t)mxF);
-        if (mxQ) atomicMax(a.maxdsq + 1, (uint32_t)mxQ);
-        if (any_unres && a.status) atomicOr(a.status, 1u);
+        if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
+        if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
+        if (any_unres && a.status) atomic_or_if_new(a.status, 1u);
     }
 }
 

@@ -2,35 +2,45 @@
 
 One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  The grid is cut
 along x, the slowest memory axis, so every rank owns a contiguous ``[nxs, ny, nz]`` block of the
-reference's VoxelGrid layout.  The z and y sweeps are slab-local; only the x sweep couples slabs:
+reference's VoxelGrid layout.  Two paths, tried in this order:
 
-  1. ``sweep_zy``   mask slab -> signed in-plane d^2 (int32), written straight into the middle of
-                    an extended buffer ``[halo_lo + nxs + halo_hi, ny, nz]``
-  2. halo exchange  the first / last ``halo`` planes go to the x-neighbours (grouped
-                    send/recv: one message per direct xGMI link, 4 MiB per plane at 1024^2); the
-                    boundary planes are swept first so the exchange overlaps the interior sweeps
-  3. ``sweep_x``    x sweep + signed merge over the extended buffer; the kernel itself checks that
-                    no voxel needed a plane beyond the halo and raises a status bit otherwise
-  4. all-reduce     (MAX) of {max d^2 free, max d^2 filled, status}: 3 integers
-  5. if any rank was unresolved (sparse scenes): all-gather the whole plane field along x and
-                    redo step 3 on complete lines -- exact for any input
+Dense path (scenes whose every voxel has an opposite-class voxel within squared distance 8)
+  1. ``pack_bits``   occupancy bytes -> 1 bit / voxel, boundary planes first
+  2. halo exchange   2 bit-planes (ny*nz/8 bytes each: 128 KiB at 1024^2) to / from each x neighbour,
+                     one grouped isend/irecv per direct xGMI link, overlapped with packing the interior
+  3. ``dense_ball``  bit-parallel ball kernel over the owned planes -> fp32 SDF, integer extrema, and an
+                     "uncertified" flag if some voxel is farther than d^2 = 8 from the other class
+  4. all-reduce(MAX) of {max d^2 free, max d^2 filled, -, uncertified}: 4 integers
 
-No CUDA-style ring emulation: the only bulk traffic is nearest-neighbour planes, which on xGMI's
-point-to-point links is one message per link and direction.
+General path (only if some rank raised the flag; exact for any input)
+  1. ``sweep_zy``    mask slab -> signed in-plane d^2 (int32) into an extended buffer with `halo` planes
+  2. halo exchange   `halo` int32 planes per neighbour, overlapped with the interior sweeps
+  3. ``sweep_x``     x sweep + signed merge; raises a status bit if a voxel needed planes beyond the halo
+  4. all-reduce(MAX); if the bit is set anywhere: all-gather the plane field along x, sweep whole lines
 
-The stage executor is pluggable: the product one (:class:`HipStages`) calls the C ABI
-(``sdfgpu_sweep_zy_device`` / ``sdfgpu_sweep_x_device``).  The CPU tests inject their own executor
-(built on the oracle) to exercise partitioning, halo exchange and the fallback with ``gloo``.
+A build is validated one step late (:meth:`SlabSdfBuilder.build_async` / :meth:`finish`): the
+all-reduced status lands in pinned host memory through a side stream, so the GPU never idles waiting
+for the host between consecutive builds; results are double-buffered.
+
+No CUDA-style ring emulation: the only bulk traffic is nearest-neighbour planes, one message per link
+and direction.  The stage executor is pluggable: the product one (:class:`HipStages`) calls the C ABI;
+the CPU tests inject an oracle-backed executor to exercise all of the logic above with ``gloo``.
 """
 import torch
 import torch.distributed as dist
 
 DSQ_INF = 1 << 30
+BALL_HALO = 2                   # planes of context the dense kernel needs on each side
 
 
 def slab_range(nx, rank, world):
     """Balanced contiguous x range of `rank`."""
     return (rank * nx) // world, ((rank + 1) * nx) // world
+
+
+def dense_shape_ok(nz):
+    nzw = nz // 32
+    return nz % 32 == 0 and 1 <= nzw <= 64 and (nzw & (nzw - 1)) == 0
 
 
 class HipStages:
@@ -45,6 +55,7 @@ class HipStages:
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    # ---- general path --------------------------------------------------------------------------
     def sweep_zy(self, mask_slab, plane_dsq_rows):
         assert mask_slab.is_contiguous() and plane_dsq_rows.is_contiguous()
         self.ctx.sweep_zy_device(mask_slab.data_ptr(), tuple(mask_slab.shape), plane_dsq_rows.data_ptr(),
@@ -57,16 +68,46 @@ class HipStages:
         self.ctx.sweep_x_device(ext.data_ptr(), halo_lo, nxs, halo_hi, ny, nz, lo_trunc, hi_trunc, x_global,
                                 nx_global, resolution, vb, out.data_ptr(), base, base + 8, self.stream())
 
+    # ---- dense path ----------------------------------------------------------------------------
+    def pack_bits(self, mask_rows, bits_rows):
+        """mask_rows [r, ny, nz] uint8 -> bits_rows [r, ny, nz/32] int32 (bit i of word w: z = 32w+i)."""
+        assert mask_rows.is_contiguous() and bits_rows.is_contiguous()
+        r, ny, nz = mask_rows.shape
+        self.ctx.pack_bits_device(mask_rows.data_ptr(), r * ny, nz, bits_rows.data_ptr(), self.stream())
+
+    def dense_ball(self, bits_ext, out_lo, out_hi, nz, resolution, out, small):
+        rows_x, ny = bits_ext.shape[0], bits_ext.shape[1]
+        base = small.data_ptr()
+        self.ctx.dense_ball_device(bits_ext.data_ptr(), rows_x, out_lo, out_hi, ny, nz, resolution,
+                                   out.data_ptr(), base, base + 12, self.stream())
+
+
+class _Slot:
+    """Per-build buffers (double-buffered so a build can be validated while the next one runs)."""
+
+    def __init__(self, nxs, ny, nz, device):
+        self.out = torch.empty((nxs, ny, nz), dtype=torch.float32, device=device)
+        self.small = torch.zeros(4, dtype=torch.int32, device=device)    # maxF, maxQ, status, uncertified
+        self.host = torch.zeros(4, dtype=torch.int32)
+        if device.type == "cuda":
+            self.host = self.host.pin_memory()
+        self.event = torch.cuda.Event() if device.type == "cuda" else None
+        self.mask = None
+        self.pending = False
+        self.dense = False
+
 
 class SlabSdfBuilder:
-    """Owns the per-rank buffers and runs steps 1-5 for one grid shape.
+    """Owns the per-rank buffers and runs the dense-first / general-fallback schedule for one grid shape.
 
     ``build(mask_slab)`` takes this rank's ``[nxs, ny, nz]`` uint8 occupancy (1 = filled) and returns
     ``(sdf_slab float32 [nxs, ny, nz], (max, min))`` with the extrema of the *whole* grid.
+    ``build_async`` / ``finish`` split that into enqueue and validate (see the module docstring); the
+    caller must keep ``mask_slab`` unchanged until the matching ``finish``.
     """
 
     def __init__(self, stages, shape, resolution=1.0, add_virtual_border=False, halo=3,
-                 rank=None, world=None, group=None, device=None):
+                 rank=None, world=None, group=None, device=None, dense=True):
         self.stages = stages
         self.nx, self.ny, self.nz = (int(s) for s in shape)
         self.resolution = float(resolution)
@@ -85,31 +126,64 @@ class SlabSdfBuilder:
         self.halo_lo = self.halo if self.rank > 0 else 0
         self.halo_hi = self.halo if self.rank < self.world - 1 else 0
         rows = self.halo_lo + self.nxs + self.halo_hi
-        self.ext = torch.empty((rows, self.ny, self.nz), dtype=torch.int32, device=self.device)
-        self.out = torch.empty((self.nxs, self.ny, self.nz), dtype=torch.float32, device=self.device)
-        self.small = torch.zeros(4, dtype=torch.int32, device=self.device)   # maxF, maxQ, status, pad
-        self.full = None            # all-gather target, allocated on first fallback
-        self.fallbacks = 0
+        self.ext = None                 # int32 plane field of the general path, allocated on first use
+        self.ext_rows = rows
+        self.full = None                # all-gather target, allocated on first whole-line fallback
+        self.fallbacks = 0              # whole-line (all-gather) re-sweeps of the general path
+        self.general_builds = 0         # builds the dense path could not certify
+        # dense path
+        self.dense = (bool(dense) and not self.vb and dense_shape_ok(self.nz) and min_slab >= BALL_HALO
+                      and hasattr(stages, "dense_ball"))
+        self.bh_lo = BALL_HALO if self.rank > 0 else 0
+        self.bh_hi = BALL_HALO if self.rank < self.world - 1 else 0
+        if self.dense:
+            self.bits = torch.zeros((self.bh_lo + self.nxs + self.bh_hi, self.ny, self.nz // 32),
+                                    dtype=torch.int32, device=self.device)
+        self.slots = [_Slot(self.nxs, self.ny, self.nz, self.device) for _ in range(2)]
+        self.cur = 0
+        self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
 
-    # -- step 2 ------------------------------------------------------------------------------
-    def _start_halo_exchange(self):
-        """Posts the grouped nearest-neighbour send/recv (asynchronous on RCCL's stream)."""
-        if self.world == 1 or self.halo == 0:
-            return []
-        h, lo, n = self.halo, self.halo_lo, self.nxs
-        ops = []
-        if self.rank > 0:          # lower neighbour: send my first h planes, receive its last h
-            ops.append(dist.P2POp(dist.isend, self.ext[lo:lo + h], self._peer(self.rank - 1), self.group))
-            ops.append(dist.P2POp(dist.irecv, self.ext[0:lo], self._peer(self.rank - 1), self.group))
-        if self.rank < self.world - 1:
-            ops.append(dist.P2POp(dist.isend, self.ext[lo + n - h:lo + n], self._peer(self.rank + 1), self.group))
-            ops.append(dist.P2POp(dist.irecv, self.ext[lo + n:lo + n + h], self._peer(self.rank + 1), self.group))
-        return dist.batch_isend_irecv(ops)
-
+    # -- communication helpers ---------------------------------------------------------------------
     def _peer(self, group_rank):
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
-    # -- step 5 ------------------------------------------------------------------------------
+    def _exchange(self, buf, lo, n, h):
+        """Grouped nearest-neighbour send/recv of `h` boundary planes of buf[lo:lo+n] (asynchronous)."""
+        if self.world == 1 or h == 0:
+            return []
+        ops = []
+        if self.rank > 0:          # lower neighbour: send my first h planes, receive its last h
+            ops.append(dist.P2POp(dist.isend, buf[lo:lo + h], self._peer(self.rank - 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, buf[lo - h:lo], self._peer(self.rank - 1), self.group))
+        if self.rank < self.world - 1:
+            ops.append(dist.P2POp(dist.isend, buf[lo + n - h:lo + n], self._peer(self.rank + 1), self.group))
+            ops.append(dist.P2POp(dist.irecv, buf[lo + n:lo + n + h], self._peer(self.rank + 1), self.group))
+        return dist.batch_isend_irecv(ops)
+
+    def _allreduce_small(self, small, async_op=False):
+        if self.world > 1:
+            return dist.all_reduce(small, op=dist.ReduceOp.MAX, group=self.group, async_op=async_op)
+        return None
+
+    # -- dense path --------------------------------------------------------------------------------
+    def _enqueue_dense(self, mask_slab, slot):
+        n, lo, h = self.nxs, self.bh_lo, BALL_HALO
+        own = self.bits[lo:lo + n]
+        if self.world > 1 and 2 * h < n:
+            self.stages.pack_bits(mask_slab[:h], own[:h])
+            self.stages.pack_bits(mask_slab[n - h:], own[n - h:])
+            works = self._exchange(self.bits, lo, n, h)
+            self.stages.pack_bits(mask_slab[h:n - h], own[h:n - h])
+        else:
+            self.stages.pack_bits(mask_slab, own)
+            works = self._exchange(self.bits, lo, n, h)
+        for w in works:
+            w.wait()
+        slot.small.zero_()
+        self.stages.dense_ball(self.bits, lo, lo + n, self.nz, self.resolution, slot.out, slot.small)
+        return self._allreduce_small(slot.small, async_op=True)
+
+    # -- general path (synchronous; exact for any input) -----------------------------------------------
     def _gather_full(self):
         if self.full is None:
             self.full = torch.empty((self.nx, self.ny, self.nz), dtype=torch.int32, device=self.device)
@@ -122,38 +196,89 @@ class SlabSdfBuilder:
             dist.all_gather(chunks, own.contiguous(), group=self.group)
         return self.full
 
-    def build(self, mask_slab):
-        assert tuple(mask_slab.shape) == (self.nxs, self.ny, self.nz), (mask_slab.shape, self.nxs)
+    def _build_general(self, mask_slab, slot):
+        if self.ext is None:
+            self.ext = torch.empty((self.ext_rows, self.ny, self.nz), dtype=torch.int32, device=self.device)
         lo, n, hi, h = self.halo_lo, self.nxs, self.halo_hi, self.halo
         own = self.ext[lo:lo + n]
         if self.world > 1 and 0 < h and 2 * h < n:
             # boundary planes first, so their exchange over xGMI overlaps the interior z/y sweeps
             self.stages.sweep_zy(mask_slab[:h], own[:h])
             self.stages.sweep_zy(mask_slab[n - h:], own[n - h:])
-            works = self._start_halo_exchange()
+            works = self._exchange(self.ext, lo, n, h)
             self.stages.sweep_zy(mask_slab[h:n - h], own[h:n - h])
         else:
             self.stages.sweep_zy(mask_slab, own)
-            works = self._start_halo_exchange()
+            works = self._exchange(self.ext, lo, n, h)
         for w in works:
             w.wait()
-        self.small.zero_()
+        small = slot.small
+        small.zero_()
         self.stages.sweep_x(self.ext, lo, n, hi, self.x0 - lo > 0, self.x1 + hi < self.nx, self.x0, self.nx,
-                            self.resolution, self.vb, self.out, self.small)
-        if self.world > 1:
-            dist.all_reduce(self.small, op=dist.ReduceOp.MAX, group=self.group)
-        max_f, max_q, status, _ = (int(v) for v in self.small.tolist())
+                            self.resolution, self.vb, slot.out, small)
+        self._allreduce_small(small)
+        max_f, max_q, status, _ = (int(v) for v in small.tolist())
         if status:
             # some voxel anywhere needed a plane beyond its halo: redo the x sweep on complete lines
             self.fallbacks += 1
             full = self._gather_full()
-            self.small.zero_()
+            small.zero_()
             self.stages.sweep_x(full, self.x0, n, self.nx - self.x1, False, False, self.x0, self.nx,
-                                self.resolution, self.vb, self.out, self.small)
-            if self.world > 1:
-                dist.all_reduce(self.small, op=dist.ReduceOp.MAX, group=self.group)
-            max_f, max_q, status, _ = (int(v) for v in self.small.tolist())
+                                self.resolution, self.vb, slot.out, small)
+            self._allreduce_small(small)
+            max_f, max_q, status, _ = (int(v) for v in small.tolist())
             assert status == 0
+        return max_f, max_q
+
+    # -- public API --------------------------------------------------------------------------------
+    def build_async(self, mask_slab):
+        """Enqueue one build; returns the slot index to pass to :meth:`finish`."""
+        assert tuple(mask_slab.shape) == (self.nxs, self.ny, self.nz), (mask_slab.shape, self.nxs)
+        idx = self.cur
+        self.cur ^= 1
+        slot = self.slots[idx]
+        if slot.pending:
+            self.finish(idx)                     # never overwrite an unvalidated result
+        slot.mask = mask_slab
+        slot.dense = self.dense
+        if self.dense:
+            work = self._enqueue_dense(mask_slab, slot)
+            if self.side is not None:
+                # all-reduced status -> pinned host memory through a side stream: the main stream never
+                # waits for the collective or the copy, so the next build's kernels follow back to back
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.side):
+                    if work is not None:
+                        work.wait()
+                    slot.host.copy_(slot.small, non_blocking=True)
+                    slot.event.record(self.side)
+            else:
+                if work is not None:
+                    work.wait()
+                slot.host.copy_(slot.small)
+        slot.pending = True
+        return idx
+
+    def finish(self, idx):
+        """Validate build `idx`: returns (sdf_slab, (max, min)).  Falls back to the general path if the
+        dense kernel could not certify every voxel (collective decision: all ranks take it together)."""
         from . import capi
 
-        return self.out, capi.extrema_from_dsq(max_f, max_q, self.resolution)
+        slot = self.slots[idx]
+        assert slot.pending
+        need_general = True
+        if slot.dense:
+            if slot.event is not None:
+                slot.event.synchronize()
+            max_f, max_q, _, uncert = (int(v) for v in slot.host.tolist())
+            need_general = uncert != 0
+        if need_general:
+            if slot.dense:
+                self.general_builds += 1
+            max_f, max_q = self._build_general(slot.mask, slot)
+        slot.pending = False
+        slot.mask = None
+        return slot.out, capi.extrema_from_dsq(max_f, max_q, self.resolution)
+
+    def build(self, mask_slab):
+        return self.finish(self.build_async(mask_slab))

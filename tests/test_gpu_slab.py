@@ -75,6 +75,41 @@ def test_single_rank_slab_equals_whole_path(gpu):
     assert status == 0 and np.array_equal(got, want) and ext == want_ext
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_dense_stages_on_slabs(gpu, world):
+    """sdfgpu_pack_bits_device + sdfgpu_dense_ball_device with bit-plane halos, one GPU playing every rank."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stages = slab.HipStages(0)
+    shape = (32, 24, 64)
+    nx, ny, nz = shape
+    for p, expect_cert in ((0.5, True), (0.003, False)):
+        m = synth.bernoulli_mask(shape, p, 6)
+        bits_all = torch.zeros((nx, ny, nz // 32), dtype=torch.int32, device=dev)
+        stages.pack_bits(torch.from_numpy(m).to(dev), bits_all)
+        out = np.empty(shape, np.float32)
+        small_all = np.zeros(4, np.int64)
+        for r in range(world):
+            a, b = slab.slab_range(nx, r, world)
+            lo = slab.BALL_HALO if r > 0 else 0
+            hi = slab.BALL_HALO if r < world - 1 else 0
+            ext = bits_all[a - lo:b + hi].contiguous()          # what the bit-plane exchange would deliver
+            o = torch.empty((b - a, ny, nz), dtype=torch.float32, device=dev)
+            small = torch.zeros(4, dtype=torch.int32, device=dev)
+            stages.dense_ball(ext, lo, lo + (b - a), nz, 0.5, o, small)
+            out[a:b] = o.cpu().numpy()
+            small_all = np.maximum(small_all, small.cpu().numpy())
+        assert bool(small_all[3] == 0) == expect_cert
+        if expect_cert:
+            want, want_ext = O.reference_sdf(m, 0.5)
+            assert np.array_equal(out, want)
+            assert capi.extrema_from_dsq(int(small_all[0]), int(small_all[1]), 0.5) == want_ext
+        else:
+            ex, _, dsq = O.exact_sdf(m, 0.5)                      # certified voxels (d^2 <= 8) are still exact
+            near = np.abs(dsq) <= 8
+            assert np.array_equal(out[near], ex[near])
+
+
 def test_gradient_matches_reference_definition(gpu):
     """N1: sdfgpu_gradient_device vs a numpy restatement of GetGridAlignedGradient (sdf.hpp:432-526)."""
     import torch

@@ -18,9 +18,44 @@ INF = 1 << 30
 
 
 class OracleStages:
-    """Test double with the contract of sdfgpu_sweep_zy_device / sdfgpu_sweep_x_device."""
+    """Test double with the contract of sdfgpu_sweep_zy_device / sdfgpu_sweep_x_device and of the dense
+    stages sdfgpu_pack_bits_device / sdfgpu_dense_ball_device."""
 
     device = torch.device("cpu")
+
+    def pack_bits(self, mask_rows, bits_rows):
+        m = (mask_rows.numpy() != 0)
+        packed = np.packbits(m, axis=-1, bitorder="little").view(np.uint32).view(np.int32)
+        bits_rows.copy_(torch.from_numpy(packed.reshape(bits_rows.shape)))
+
+    def dense_ball(self, bits_ext, out_lo, out_hi, nz, res, out, small):
+        b = bits_ext.numpy().view(np.uint32)
+        m = np.unpackbits(b.view(np.uint8).reshape(b.shape[0], b.shape[1], -1), axis=-1, bitorder="little")
+        m = m[..., :nz].astype(np.int8)
+        rows, ny = m.shape[0], m.shape[1]
+        xs = np.arange(out_lo, out_hi)
+        best = np.full((len(xs), ny, nz), 99, np.int64)
+        for dx in range(-2, 3):
+            for dy in range(-2, 3):
+                for dz in range(-2, 3):
+                    d2 = dx * dx + dy * dy + dz * dz
+                    if d2 == 0 or d2 > 8:
+                        continue
+                    gx = np.clip(xs + dx, 0, rows - 1)                 # edge replication, like the kernel
+                    gy = np.clip(np.arange(ny) + dy, 0, ny - 1)
+                    gz = np.clip(np.arange(nz) + dz, 0, nz - 1)
+                    other = m[gx][:, gy][:, :, gz]
+                    best = np.where(other != m[xs], np.minimum(best, d2), best)
+        own = m[xs] != 0
+        found = best < 99
+        f = (np.sqrt(np.where(found, best, 0).astype(np.float64)) * res).astype(np.float32)
+        out.copy_(torch.from_numpy(np.where(own, -f, f)))
+        if (found & ~own).any():
+            small[0] = max(int(small[0]), int(best[found & ~own].max()))
+        if (found & own).any():
+            small[1] = max(int(small[1]), int(best[found & own].max()))
+        if (~found).any():
+            small[3] = 1
 
     def sweep_zy(self, mask_slab, rows):
         m = mask_slab.numpy()
@@ -75,25 +110,35 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, p, seed, res, vb, halo, q):
+def _worker(rank, world, port, shape, p, seed, res, vb, halo, q, dense=False, steps=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         x0, x1 = slab.slab_range(shape[0], rank, world)
         mask = torch.from_numpy(synth.bernoulli_mask(shape, p, seed, x_range=(x0, x1)))
-        b = slab.SlabSdfBuilder(OracleStages(), shape, res, vb, halo=halo, rank=rank, world=world)
-        sdf, ext = b.build(mask)
-        q.put((rank, x0, x1, sdf.numpy().copy(), ext, b.fallbacks))
+        b = slab.SlabSdfBuilder(OracleStages(), shape, res, vb, halo=halo, rank=rank, world=world, dense=dense)
+        if steps == 1:
+            sdf, ext = b.build(mask)
+        else:                                   # pipelined use: validate one build behind
+            prev = None
+            for _ in range(steps):
+                t = b.build_async(mask)
+                if prev is not None:
+                    b.finish(prev)
+                prev = t
+            sdf, ext = b.finish(prev)
+        q.put((rank, x0, x1, sdf.numpy().copy(), ext, (b.fallbacks, b.general_builds, b.dense)))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, shape, p, seed, res=1.0, vb=False, halo=4):
+def _run(world, shape, p, seed, res=1.0, vb=False, halo=4, dense=False, steps=1):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, p, seed, res, vb, halo, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, p, seed, res, vb, halo, q, dense, steps))
+             for r in range(world)]
     for pr in procs:
         pr.start()
     results = [q.get(timeout=180) for _ in range(world)]
@@ -105,12 +150,14 @@ def _run(world, shape, p, seed, res=1.0, vb=False, halo=4):
         full[x0:x1] = sdf
     exts = {r[4] for r in results}
     assert len(exts) == 1                       # every rank reports the same global extrema
-    return full, exts.pop(), max(r[5] for r in results)
+    info = results[0][5]
+    assert all(r[5] == info for r in results)   # collective decisions: identical counters on every rank
+    return full, exts.pop(), info
 
 
 def test_two_ranks_dense_grid_halo_path():
     shape = (24, 10, 12)
-    got, ext, fallbacks = _run(2, shape, 0.5, 1, res=0.5)
+    got, ext, (fallbacks, _, _) = _run(2, shape, 0.5, 1, res=0.5)
     want, want_ext, _ = O.exact_sdf(synth.bernoulli_mask(shape, 0.5, 1), 0.5)
     assert np.array_equal(got, want) and ext == want_ext
     assert fallbacks == 0                       # d^2 <= halo^2 everywhere: the halo fast path suffices
@@ -127,7 +174,7 @@ def test_three_ranks_uneven_slabs_virtual_border():
 
 def test_two_ranks_sparse_grid_takes_allgather_fallback():
     shape = (32, 8, 8)
-    got, ext, fallbacks = _run(2, shape, 0.004, 5, halo=2)
+    got, ext, (fallbacks, _, _) = _run(2, shape, 0.004, 5, halo=2)
     m = synth.bernoulli_mask(shape, 0.004, 5)
     assert 0 < m.sum() < 16 and m[:13].sum() == 0      # rank 0's slab sees sites only far away
     want, want_ext, _ = O.exact_sdf(m, 1.0)
@@ -137,8 +184,28 @@ def test_two_ranks_sparse_grid_takes_allgather_fallback():
 
 def test_two_ranks_one_class_only():
     shape = (8, 4, 4)
-    got, ext, fallbacks = _run(2, shape, 0.0, 1, halo=2)
+    got, ext, (fallbacks, _, _) = _run(2, shape, 0.0, 1, halo=2)
     assert np.all(np.isposinf(got)) and ext == (math.inf, math.inf) and fallbacks == 1
+
+
+def test_dense_path_two_and_three_ranks():
+    """Bit-plane halo exchange + ball kernel contract: certified on every rank, no general build."""
+    for world, shape in ((2, (16, 9, 32)), (3, (20, 6, 64))):
+        m = synth.bernoulli_mask(shape, 0.5, 4)
+        got, ext, (fallbacks, general, dense) = _run(world, shape, 0.5, 4, res=0.25, dense=True, steps=3)
+        assert dense and general == 0 and fallbacks == 0
+        want, want_ext = O.reference_sdf(m, 0.25)
+        assert np.array_equal(got, want) and ext == want_ext
+
+
+def test_dense_path_uncertified_falls_back_collectively():
+    """One far voxel on one rank: every rank must take the general path for that build."""
+    shape = (24, 8, 32)
+    got, ext, (fallbacks, general, dense) = _run(2, shape, 0.004, 5, halo=2, dense=True, steps=2)
+    m = synth.bernoulli_mask(shape, 0.004, 5)
+    want, want_ext, _ = O.exact_sdf(m, 1.0)
+    assert dense and general == 2
+    assert np.array_equal(got, want) and ext == want_ext
 
 
 def test_slab_range_covers_grid():
