@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=320, help="edge of the cube timed on the CPU oracle")
     ap.add_argument("--tune", type=int, nargs=2, default=None, help="rows per chunk: y x")
+    ap.add_argument("--force-slab", action="store_true", help="run the multi-GPU slab builder even at N = 1")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (sdfgpu_set_option)")
     return ap.parse_args()
 
@@ -113,7 +114,8 @@ def main():
     res = args.resolution
     stream = torch.cuda.current_stream(dev)
 
-    if world == 1:
+    use_slab = world > 1 or args.force_slab
+    if not use_slab:
         ctx = capi.SdfGpu(local_rank)
         if args.tune:
             ctx.set_tuning(*args.tune)
@@ -149,7 +151,7 @@ def main():
                 builder.finish(pending.pop(0))
 
     def fence():
-        if world > 1:
+        if use_slab:
             drain()
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -159,9 +161,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if world == 1:
+    if not use_slab:
         ctx.get_stage_times()           # drop anything recorded so far
-        ctx.set_profiling(True)         # HIP events on the launch stream around K1/K2/K3
+        ctx.set_profiling(True)         # HIP events on the launch stream around every stage
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -188,7 +190,7 @@ def main():
                    % (world, args.halo)},
     }
 
-    if world == 1:
+    if not use_slab:
         ms_sum, builds = ctx.get_stage_times()
         ctx.set_profiling(False)
         mx, mn = ctx.get_extrema()
@@ -231,7 +233,7 @@ def main():
         result["config"]["builds_needing_general_path"] = builder.general_builds
         result["config"]["whole_line_fallbacks"] = builder.fallbacks
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_slab:
         result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.p, res)
     if rank == 0:
         print(json.dumps(result))

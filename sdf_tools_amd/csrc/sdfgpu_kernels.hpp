@@ -132,7 +132,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
     const int W = (nz + 63) >> 6;
     const int cpr = nz >> 4;                       // 16-voxel chunks per row
     const int spr = W * 4;                         // uint16 slots per row in the bitmap
-    const int64_t row0 = (int64_t)blockIdx.x * rpb;
+    // persistent loop over row groups: a small grid keeps the guard early-exit cheap
+    for (int64_t row0 = (int64_t)blockIdx.x * rpb; row0 < nrows; row0 += (int64_t)gridDim.x * rpb) {
     const int nr = (int)min((int64_t)rpb, nrows - row0);
     // phase A: pack
     for (int s = threadIdx.x; s < nr * spr; s += kBlock) {
@@ -167,6 +168,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
         dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     }
+    __syncthreads();                               // bitmap is reused by the next row group
+    }
 }
 
 // Generic path: any nz, any loader (mask bytes or COLLISION_CELL records).
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_generic(Loader ld, int16_t* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* bm = reinterpret_cast<uint64_t*>(smem_raw);
     const int W = (nz + 63) >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * rpb;
-    const int nr = (int)min((int64_t)rpb, nrows - row0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t row0 = (int64_t)blockIdx.x * rpb; row0 < nrows; row0 += (int64_t)gridDim.x * rpb) {
+    const int nr = (int)min((int64_t)rpb, nrows - row0);
     for (int s = wave; s < nr * W; s += kBlock / 64) {
         const int r = s / W, ww = s - r * W;
         const int z = 64 * ww + lane;
@@ -200,6 +203,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_generic(Loader ld, int16_t* 
         const int L = far_left(row, w, !own), R = far_right(row, w, W, nz, !own);
         const int d = z_signed_distance(word, valid_mask(w, nz), zb, z, L, L, R, R);
         out[(row0 + r) * nz + z] = (int16_t)d;
+    }
+    __syncthreads();
     }
 }
 

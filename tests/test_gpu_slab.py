@@ -110,6 +110,40 @@ def test_dense_stages_on_slabs(gpu, world):
             assert np.array_equal(out[near], ex[near])
 
 
+def test_slab_builder_single_rank_pipelined(gpu):
+    """SlabSdfBuilder + HipStages end to end at world = 1: dense path certified, deferred validation,
+    double-buffered slots; and a sparse grid that must take the general path."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stages = slab.HipStages(0)
+    shape = (24, 20, 64)
+    m = synth.bernoulli_mask(shape, 0.5, 8)
+    b = slab.SlabSdfBuilder(stages, shape, 0.1, False, rank=0, world=1)
+    assert b.dense
+    mt = torch.from_numpy(m).to(dev)
+    prev, outs = None, []
+    for _ in range(4):
+        t = b.build_async(mt)
+        if prev is not None:
+            outs.append(b.finish(prev))
+        prev = t
+    outs.append(b.finish(prev))
+    want, want_ext = O.reference_sdf(m, 0.1)
+    for o, ext in outs:
+        assert np.array_equal(o.cpu().numpy(), want) and ext == want_ext
+    assert b.general_builds == 0 and b.fallbacks == 0
+    ms = synth.bernoulli_mask(shape, 0.002, 8)
+    o, ext = b.build(torch.from_numpy(ms).to(dev))
+    ex, ex_ext, _ = O.exact_sdf(ms, 0.1)
+    assert np.array_equal(o.cpu().numpy(), ex) and ext == ex_ext and b.general_builds == 1
+    # virtual border disables the dense path inside the builder
+    bv = slab.SlabSdfBuilder(stages, shape, 0.1, True, rank=0, world=1)
+    assert not bv.dense
+    o, ext = bv.build(mt)
+    ex, ex_ext, _ = O.exact_sdf(m, 0.1, True)
+    assert np.array_equal(o.cpu().numpy(), ex) and ext == ex_ext
+
+
 def test_gradient_matches_reference_definition(gpu):
     """N1: sdfgpu_gradient_device vs a numpy restatement of GetGridAlignedGradient (sdf.hpp:432-526)."""
     import torch

@@ -11,6 +11,8 @@ from sdf_tools_amd import capi, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ctx = capi.SdfGpu(0)
+for kv in sys.argv[2:]:
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 mask = synth.bernoulli_mask_torch((n, n, n), 0.5, 1, device="cuda")
 out = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
 src = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()

@@ -22,7 +22,8 @@ def find(dirname, pattern):
 
 
 def short(name):
-    for key, label in (("k_sweep_z_vec16", "sweep_z"), ("k_sweep_z_generic", "sweep_z_generic"),
+    for key, label in (("k_pack_bits", "pack_bits"), ("k_ball_dense", "dense_ball"), ("k_sweep_zy_fused", "sweep_zy"),
+                       ("k_sweep_x16", "sweep_x16"), ("k_sweep_z_vec16", "sweep_z"), ("k_sweep_z_generic", "sweep_z_generic"),
                        ("k_sweep_march<2", "sweep_y"), ("k_sweep_march<3", "sweep_x"),
                        ("k_sweep_marchILi2", "sweep_y"), ("k_sweep_marchILi3", "sweep_x"),
                        ("k_fused", "fused"), ("k_gradient", "gradient")):
@@ -68,6 +69,7 @@ def pmc(dirs, out_json):
         wr = raw.get("WRITE_SIZE")
         if rd is not None and wr is not None:
             out[label] = round(2.0 * rd + wr)
+            out["_raw"][label]["corrected_read"] = round(2.0 * rd)
     json.dump(out, open(out_json, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
