@@ -221,6 +221,8 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": (traffic or {}).get(dom),
+                "hbm_frac_traffic": (round((traffic or {}).get(dom) / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                     if (traffic or {}).get(dom) and n_total == 512 ** 3 else None),
                 "alg_bytes_per_voxel": B_ALG[dom], "design_bytes_per_voxel": B_DESIGN[dom],
                 "avg_ms": round(stage_ms[dom], 4),
                 "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
