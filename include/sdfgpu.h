@@ -178,6 +178,16 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf,
                            double resolution, int enable_edge_gradients,
                            void* d_out_grad, int out_is_f64, void* stream);
 
+/* Next-row N2: point cloud -> occupancy grid, the convention of scripts/3d_sdf_demo_rviz.py:22-29:
+ * index = trunc((p - origin) / resolution) per axis (fp64 arithmetic on fp32 points), mask[ix][iy][iz] = 1
+ * with explicit x, y, z axis order; points outside the grid are dropped.  d_points: n_points x 3 floats
+ * (x, y, z interleaved).  clear_first != 0 zeroes the mask before scattering.  Feeds
+ * sdfgpu_build_device without leaving the GPU (the streaming configuration). */
+int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_t n_points,
+                                  const double* origin, double resolution,
+                                  int64_t nx, int64_t ny, int64_t nz,
+                                  uint8_t* d_mask, int clear_first, void* stream);
+
 /* Debug / test hooks: copy the intermediates of the most recent
  * sdfgpu_build*_device call to host buffers (N int16 / N int32). */
 int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n);

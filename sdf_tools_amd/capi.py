@@ -22,7 +22,7 @@ EXPORTS = [
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
-    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device",
+    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device",
 ]
 
 
@@ -69,6 +69,7 @@ def load_library():
     L.sdfgpu_sweep_x_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, ci, ci, i64, i64, dbl, ci, vp, vp, vp, vp]
     L.sdfgpu_pack_bits_device.argtypes = [vp, vp, i64, i64, vp, vp]
     L.sdfgpu_dense_ball_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, dbl, vp, vp, vp, vp]
+    L.sdfgpu_voxelize_points_device.argtypes = [vp, vp, i64, vp, dbl, i64, i64, i64, vp, ci, vp]
     L.sdfgpu_extrema_from_dsq.argtypes = [u32, u32, dbl, vp, vp]
     L.sdfgpu_gradient_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci, vp]
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
@@ -193,6 +194,12 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_dense_ball_device(self._h, d_bits, int(rows_x), int(out_lo), int(out_hi), int(ny),
                                                        int(nz), float(resolution), d_out, d_maxdsq, d_uncertified,
                                                        stream or None))
+
+    def voxelize_points_device(self, d_points, n_points, origin, resolution, shape, d_mask, clear_first=True, stream=0):
+        nx, ny, nz = (int(s) for s in shape)
+        o = (ctypes.c_double * 3)(*[float(v) for v in origin])
+        self._check(self._lib.sdfgpu_voxelize_points_device(self._h, d_points, int(n_points), o, float(resolution),
+                                                            nx, ny, nz, d_mask, int(bool(clear_first)), stream or None))
 
     def gradient_device(self, d_sdf, shape, d_out, resolution=1.0, enable_edge_gradients=True, f64=True, stream=0):
         nx, ny, nz = (int(s) for s in shape)

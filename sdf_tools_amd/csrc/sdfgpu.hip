@@ -596,6 +596,24 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
                              (hipStream_t)stream);
 }
 
+int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
+                                  double resolution, int64_t nx, int64_t ny, int64_t nz, uint8_t* d_mask, int clear_first,
+                                  void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_mask || !origin || (n_points > 0 && !d_points) || n_points < 0 || !(resolution > 0.0))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad voxelize arguments");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (clear_first) HIP_TRY(h, hipMemsetAsync(d_mask, 0, (size_t)(nx * ny * nz), s));
+    if (n_points > 0) {
+        hipLaunchKernelGGL(k_voxelize_points, dim3((unsigned)((n_points + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_points,
+                           n_points, origin[0], origin[1], origin[2], resolution, nx, ny, nz, d_mask);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return SDFGPU_OK;
+}
+
 int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz,
                            double resolution, int enable_edge_gradients, void* d_out_grad, int out_is_f64,
                            void* stream) {

@@ -493,6 +493,25 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// N2: point cloud -> occupancy (scripts/3d_sdf_demo_rviz.py:22-29): idx = trunc((p - origin) / res),
+// vg[ix, iy, iz] = 1.  Points whose index falls outside the grid are dropped.  fp32 points (the
+// PointCloud2 convention), index arithmetic in fp64 like numpy's.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_voxelize_points(const float* __restrict__ pts, int64_t n_points,
+                                                           double ox, double oy, double oz, double res,
+                                                           int64_t nx, int64_t ny, int64_t nz,
+                                                           uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_points) return;
+    const double fx = ((double)pts[3 * i + 0] - ox) / res;
+    const double fy = ((double)pts[3 * i + 1] - oy) / res;
+    const double fz = ((double)pts[3 * i + 2] - oz) / res;
+    if (!(fx > -1.0 && fy > -1.0 && fz > -1.0 && fx < (double)nx && fy < (double)ny && fz < (double)nz)) return;  // also NaN
+    const int64_t ix = (int64_t)fx, iy = (int64_t)fy, iz = (int64_t)fz;      // truncation toward zero, like astype(int64)
+    mask[(ix * ny + iy) * nz + iz] = 1;                                       // benign race: every writer stores 1
+}
+
+// ---------------------------------------------------------------------------
 // N1: grid-aligned gradient of the whole field, sdf.hpp:432-526.
 // ---------------------------------------------------------------------------
 template <typename OutT>

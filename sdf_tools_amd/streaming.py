@@ -1,0 +1,44 @@
+"""Streaming point cloud -> occupancy -> SDF (+ gradient) on one GPU (BASELINE.json configs[4]).
+
+Everything stays in HBM: the point cloud is voxelised on the device
+(``sdfgpu_voxelize_points_device``, the convention of the reference's scripts/3d_sdf_demo_rviz.py:22-29),
+the SDF is built by the same C-ABI entry point as everywhere else (dense kernel first, general sweeps
+behind it -- point clouds are sparse scenes, so the general path usually does the work) and the
+grid-aligned gradient (sdf.hpp:432-526) is computed for every voxel by one more kernel.  The context's
+scratch buffers are allocated once and re-used by every frame.
+"""
+import torch
+
+from . import capi
+
+
+class StreamingSdf:
+    def __init__(self, shape, resolution, origin=(0.0, 0.0, 0.0), device_index=0, gradient=True, grad_f64=False):
+        self.shape = tuple(int(s) for s in shape)
+        self.resolution = float(resolution)
+        self.origin = tuple(float(v) for v in origin)
+        self.device = torch.device("cuda", device_index)
+        self.ctx = capi.SdfGpu(device_index)
+        self.mask = torch.zeros(self.shape, dtype=torch.uint8, device=self.device)
+        self.sdf = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        self.gradient = None
+        self.grad_f64 = bool(grad_f64)
+        if gradient:
+            self.gradient = torch.empty(self.shape + (3,), dtype=torch.float64 if grad_f64 else torch.float32,
+                                        device=self.device)
+
+    def frame(self, points):
+        """points: [n, 3] float32 device tensor (x, y, z).  Returns (sdf, gradient or None); asynchronous on
+        the current stream."""
+        assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous() and points.shape[-1] == 3
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx.voxelize_points_device(points.data_ptr(), points.shape[0], self.origin, self.resolution, self.shape,
+                                        self.mask.data_ptr(), True, s)
+        self.ctx.build_device(self.mask.data_ptr(), self.shape, self.sdf.data_ptr(), self.resolution, False, s)
+        if self.gradient is not None:
+            self.ctx.gradient_device(self.sdf.data_ptr(), self.shape, self.gradient.data_ptr(), self.resolution, True,
+                                     self.grad_f64, s)
+        return self.sdf, self.gradient
+
+    def extrema(self):
+        return self.ctx.get_extrema()

@@ -1,0 +1,39 @@
+"""The C++ side of the drop-in boundary: examples/tutorial.cpp is written like reference client code
+(src/sdf_tools_tutorial.cpp) against include/sdf_tools/*.hpp and links libsdfgpu.so.
+CPU: it must compile, link and fail loudly without a GPU.  GPU: it must reproduce the pinned values."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "tutorial_example")
+
+
+def _build():
+    from sdf_tools_amd import build as b
+    b.build_libsdfgpu()
+    src = os.path.join(ROOT, "examples", "tutorial.cpp")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), src,
+                               "-o", EXE, "-L", os.path.join(ROOT, "sdf_tools_amd"), "-lsdfgpu",
+                               "-Wl,-rpath," + os.path.join(ROOT, "sdf_tools_amd"), "-lz"])
+    return EXE
+
+
+def test_cpp_client_compiles_links_and_refuses_without_gpu():
+    from sdf_tools_amd import capi
+    exe = _build()
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_client_reproduces_tutorial_scene():
+    exe = _build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "tutorial scene OK" in r.stdout
