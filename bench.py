@@ -30,11 +30,14 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # next to it as design_bytes_per_voxel.
 # The dense path does the whole mask -> fp32 job in K0 (pack) + KD (ball): K0 is priced at the 1 B/voxel
 # mask read, KD at the remaining 16 B of the separable formulation it replaces.
-B_ALG = {"pack_bits": 1, "dense_ball": 16, "sweep_z": 1 + 2, "sweep_y": 2 + 4, "sweep_zy": 9, "sweep_x": 4 + 4}
-B_DESIGN32 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8}
-B_DESIGN16 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 4, "sweep_zy": 3, "sweep_x": 6}
+B_ALG = {"pack_bits": 1, "dense_ball": 16, "sweep_z": 1 + 2, "sweep_y": 2 + 4, "sweep_zy": 9, "sweep_x": 4 + 4,
+         "envelope_y": 2 + 4, "envelope_x": 4 + 4}
+B_DESIGN32 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8,
+              "envelope_y": 8, "envelope_x": 10}
+B_DESIGN16 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 4, "sweep_zy": 3, "sweep_x": 6,
+              "envelope_y": 8, "envelope_x": 10}
 B_ALG_TOTAL = 17
-KERNEL_NAMES = {"pack_bits": "k_pack_bits_mask", "dense_ball": "k_ball_dense", "sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,...>",
+KERNEL_NAMES = {"envelope_y": "k_envelope<2>", "envelope_x": "k_envelope<3>", "pack_bits": "k_pack_bits_mask", "dense_ball": "k_ball_dense", "sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,...>",
                 "sweep_zy": "k_sweep_zy_fused", "sweep_x": "k_sweep_march<3,...> / k_sweep_x16"}
 
 GRIDS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
@@ -198,7 +201,7 @@ def main():
         if builds:
             info = ctx.last_build_info()
             B_DESIGN = B_DESIGN16 if info["plane16"] else B_DESIGN32
-            info["dense_certified"] = ctx.last_dense_certified() if info["dense"] else False
+            info.update(ctx.last_path())
             result["config"]["kernels"] = info
             avg = [v / builds for v in ms_sum]
             stage_ms = {}
@@ -209,9 +212,13 @@ def main():
                     stage_ms["sweep_zy"] = avg[3]
                 else:
                     stage_ms["sweep_z"], stage_ms["sweep_y"] = avg[2], avg[3]
-                stage_ms["sweep_x"] = avg[4]
+                stage_ms["sweep_x"] = avg[5]
+                if info["far_y"]:
+                    stage_ms["envelope_y"] = avg[4]
+                if info["far_x"]:
+                    stage_ms["envelope_x"] = avg[6]
             else:
-                result["config"]["guarded_general_pipeline_ms"] = round(avg[2] + avg[3] + avg[4], 4)
+                result["config"]["guarded_general_pipeline_ms"] = round(sum(avg[2:]), 4)
             dom = max(stage_ms, key=stage_ms.get)
             achieved = n_total * B_ALG[dom] / (stage_ms[dom] * 1e-3) / 1e9
             traffic = load_traffic()

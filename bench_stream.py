@@ -39,7 +39,7 @@ def main():
     print(json.dumps({"metric": "streaming frames/sec (points -> occupancy -> SDF%s)" % ("" if args.no_gradient else " + gradient"),
                       "value": round(args.frames / dt, 2), "unit": "Hz", "ms_per_frame": round(dt / args.frames * 1e3, 3),
                       "grid": [n, n, n], "points_per_frame": args.points, "occupancy": occ,
-                      "kernels": st.ctx.last_build_info(), "dense_certified": st.ctx.last_dense_certified(),
+                      "kernels": st.ctx.last_build_info(), "path": st.ctx.last_path(),
                       "extrema": st.extrema(), "target_hz": 30}))
 
 

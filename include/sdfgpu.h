@@ -194,10 +194,11 @@ int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n);
 int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
 
 /* Per-stage timing with HIP events recorded on the build's own stream (bench.py's roofline leg).
- * While enabled, every sdfgpu_build*_device call brackets its five stages with events:
- * [0] K0 pack, [1] KD dense ball kernel, [2] K1 z sweep, [3] K2 / K12 y (z+y) sweep, [4] K3 x sweep
- * (a stage that is not launched, or exits on its guard flag, shows ~0).  sdfgpu_get_stage_times
- * synchronises, adds the elapsed times since the last call into out_ms_sum[5] (milliseconds),
+ * While enabled, every sdfgpu_build*_device call brackets its seven stages with events:
+ * [0] K0 pack, [1] KD dense ball kernel, [2] K1 z sweep, [3] K2 / K12 y (z+y) sweep, [4] KE2 envelope y
+ * sweep, [5] K3 x sweep, [6] KE3 envelope x sweep (a stage that is not launched, or exits on its guard
+ * flag, shows ~0).  sdfgpu_get_stage_times
+ * synchronises, adds the elapsed times since the last call into out_ms_sum[7] (milliseconds),
  * returns the number of builds they cover in *out_builds and resets the accumulators. */
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
@@ -208,15 +209,17 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * nz = 512: 2 or 3), "plane16" (1 = int16 plane field + int32 side table between the y and x sweeps
  * when the shape allows, default; 0 = int32 plane field), "x16_voxels_per_lane" (4 or 8),
  * "x16_window" (2 or 3), "dense" (1 = try the bit-parallel dense kernel first, default; 0 = general
- * pipeline only). */
+ * pipeline only), "envelope" (1 = bound the outward scans of K2 / K3 and redo far-field sweeps with the
+ * lower-envelope kernels, default; 0 = unbounded scans). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),
  * bit 1 = 16-bit plane field (K3/16), bit 2 = dense kernel (K0 + KD) enqueued in front. */
 int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy);
 
-/* After a build that enqueued the dense kernel: *out_certified = 1 if it decided every voxel (the
- * general pipeline behind it exited immediately), 0 if the general pipeline did the work.  Synchronises. */
+/* Which path did the work of the last build (synchronises): bit 0 = the dense kernel decided every voxel
+ * (the general pipeline behind it exited immediately); bit 1 / bit 2 = the y / x sweep hit its scan bound
+ * and was redone by the lower-envelope kernel (far-field scene). */
 int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified);
 
 /* Tuning hook (benchmarks): rows marched per thread in the y / x sweeps

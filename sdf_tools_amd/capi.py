@@ -225,10 +225,14 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_last_build_info(self._h, ctypes.byref(v)))
         return {"fused_zy": bool(v.value & 1), "plane16": bool(v.value & 2), "dense": bool(v.value & 4)}
 
-    def last_dense_certified(self):
+    def last_path(self):
+        """{'dense_certified', 'far_y', 'far_x'} of the last build (synchronises)."""
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_last_dense_certified(self._h, ctypes.byref(v)))
-        return bool(v.value)
+        return {"dense_certified": bool(v.value & 1), "far_y": bool(v.value & 2), "far_x": bool(v.value & 4)}
+
+    def last_dense_certified(self):
+        return self.last_path()["dense_certified"]
 
     def last_build_fused_zy(self):
         return self.last_build_info()["fused_zy"]
@@ -237,8 +241,9 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_set_profiling(self._h, int(bool(enable))))
 
     def get_stage_times(self):
-        """(ms_sum[5] for pack / dense ball / z / y-or-zy / x, builds) since the last call; synchronises."""
-        ms = (ctypes.c_double * 5)()
+        """(ms_sum[7] for pack / dense ball / z / y-or-zy / envelope y / x / envelope x, builds) since the
+        last call; synchronises."""
+        ms = (ctypes.c_double * 7)()
         n = ctypes.c_int64()
         self._check(self._lib.sdfgpu_get_stage_times(self._h, ms, ctypes.byref(n)))
         return [float(v) for v in ms], int(n.value)

@@ -5,6 +5,7 @@
 #include "sdfgpu_sweep_x16.hpp"
 #include "sdfgpu_fused_zy.hpp"
 #include "sdfgpu_dense.hpp"
+#include "sdfgpu_envelope.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -40,9 +41,10 @@ struct sdfgpu_context {
     DeviceBuffer yzfield;    // int32 [N]   K2 output (32-bit pipeline) / side table (16-bit pipeline)
     DeviceBuffer plane16;    // int16 [N]   plane field of the 16-bit pipeline
     DeviceBuffer bits;       // uint32 [N/32] packed occupancy of the dense path
+    DeviceBuffer env;        // int2 [N] per-line stacks of the envelope kernels (far-field scenes)
     DeviceBuffer stage_in;   // host-API staging: mask / cells
     DeviceBuffer stage_out;  // host-API staging: sdf
-    uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] pad
+    uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] uncertified, [4] far_y, [5] far_x
     hipStream_t last_stream = nullptr;
     double last_resolution = 1.0;
     int64_t last_n = 0;
@@ -51,13 +53,20 @@ struct sdfgpu_context {
     int tune_ty = 0, tune_tx = 0, tune_tzy = 0, fused_h = 0;
     bool fused_zy = true;            // use K12 (z sweep fused into the y sweep) when the shape allows
     bool dense_on = true;            // try the bit-parallel dense kernel first when the shape allows
+    bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
+    uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
+    int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // scan bounds, adapted from the previous build
+    uint32_t* h_flags = nullptr;     // pinned host copy of d_small, filled asynchronously after every build
+    hipEvent_t flags_ev = nullptr;
+    bool flags_pending = false;
+    bool prev_dense = false;
     bool last_dense = false;
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     bool last_plane16 = false;
     bool profiling = false;
-    std::vector<hipEvent_t> events;   // 6 per profiled build: start, after pack, ball, K1, K2/K12, K3
+    std::vector<hipEvent_t> events;   // 8 per profiled build: start, after pack, ball, K1, K2/K12, KE2, K3, KE3
 };
 
 namespace {
@@ -170,6 +179,7 @@ int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, void* d_out, int32_t* d
     a.in = d_in; a.out = d_out;
     a.out16 = d_side ? 1 : 0; a.side = d_side;
     a.guard = h->guard;
+    if (d_side && h->far_y) { a.max_scan = h->scan_y; a.far_flag = h->far_y; }
     a.cpl = nz / V;
     a.ncols = nx * a.cpl;
     a.outer_stride = ny * nz;
@@ -243,6 +253,7 @@ int launch_sweep_x16(sdfgpu_handle h, const int16_t* d_in16, const int32_t* d_si
     a.x_global = x_global; a.nx_global = nx_global; a.ny = ny; a.nz = nz;
     a.maxdsq = d_maxdsq; a.status = d_status;
     a.guard = h->guard;
+    if (h->far_y) { a.max_scan = h->scan_x; a.far_flag = h->far_y + 1; }
     const int span = a.out_hi - a.out_lo;
     const int nchunks = (span + a.T - 1) / a.T;
     const int64_t nbx = (a.ncols + kBlock - 1) / kBlock;
@@ -280,6 +291,24 @@ int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t h
     a.maxdsq = d_maxdsq; a.status = d_status;
     a.guard = h->guard;
     return vb ? launch_march<3, true>(h, a, vec4, s) : launch_march<3, false>(h, a, vec4, s);
+}
+
+// KE2 / KE3: exact lower-envelope sweeps, run only when the bounded K2 / K3 raised their far flag
+int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int32_t* d_side_in, void* d_out,
+                    int32_t* d_side_out, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
+                    uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s) {
+    EnvArgs a{};
+    a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
+    a.scratch = (int2*)h->env.ptr;
+    if (stage == 2) { a.nlines = nx * nz; a.cpl = nz; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
+    else { a.nlines = ny * nz; a.cpl = a.nlines; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
+    a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
+    a.maxdsq = d_maxdsq; a.guard = guard;
+    dim3 grid((unsigned)((a.nlines + kBlock - 1) / kBlock)), block(kBlock);
+    if (stage == 2) hipLaunchKernelGGL(k_envelope<2>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_envelope<3>, grid, block, 0, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
 }
 
 // K0 + KD: pack to bits, then the bit-parallel ball kernel (sdfgpu_dense.hpp)
@@ -358,8 +387,19 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     const bool dense = dense_eligible(h, nz, vb) && ny <= 0x7fffffff;
     const bool fused = !dense && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 16, s));
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const bool envelope = p16 && h->envelope_on;
+    if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
+    // learn from the previous build (if its flags have arrived): far-field -> do not bother scanning
+    if (h->flags_pending && hipEventQuery(h->flags_ev) == hipSuccess) {
+        h->flags_pending = false;
+        const bool general_ran = !h->prev_dense || h->h_flags[3] != 0;
+        if (general_ran) {
+            h->scan_y = h->h_flags[4] ? kScanExpectFar : kScanExpectNear;
+            h->scan_x = h->h_flags[5] ? kScanExpectFar : kScanExpectNear;
+        }
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (h->profiling) {
         for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
         HIP_TRY(h, hipEventRecord(ev[0], s));
@@ -381,6 +421,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[2], s));
     h->last_fused = fused;
     h->last_plane16 = p16;
+    h->far_y = envelope ? h->d_small + 4 : nullptr;
     if (!fused)
         if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
                                     (int16_t*)h->zfield.ptr, s)) return rc;
@@ -391,6 +432,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s)) return rc;
     }
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[4], s));
+    if (envelope && !fused)      // (the fused kernel recomputes rows instead of scanning a z field: unbounded, no flag)
+        if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
+                                     nx, ny, nz, resolution, vb, h->d_small, h->d_small + 4, s)) return rc;
+    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[5], s));
     if (p16) {
         if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
                                       0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
@@ -398,9 +443,20 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
                                     resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
     }
+    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[6], s));
+    if (envelope)
+        if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
+                                     nx, ny, nz, resolution, vb, h->d_small, h->d_small + 5, s)) return rc;
     h->guard = nullptr;
+    h->far_y = nullptr;
+    if (envelope && h->h_flags) {      // asynchronous read-back of the flags for the next build's policy
+        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_small, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipEventRecord(h->flags_ev, s));
+        h->flags_pending = true;
+        h->prev_dense = dense;
+    }
     if (h->profiling) {
-        HIP_TRY(h, hipEventRecord(ev[5], s));
+        HIP_TRY(h, hipEventRecord(ev[7], s));
         for (auto e : ev) h->events.push_back(e);
     }
     h->last_stream = s;
@@ -465,6 +521,11 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
         delete ctx;
         return fail(nullptr, SDFGPU_ERR_HIP, "hipMalloc failed for context scratch");
     }
+    if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault) != hipSuccess) ctx->h_flags = nullptr;
+    if (ctx->h_flags && hipEventCreateWithFlags(&ctx->flags_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipHostFree(ctx->h_flags);
+        ctx->h_flags = nullptr;
+    }
     *out_handle = ctx;
     return SDFGPU_OK;
 }
@@ -472,9 +533,10 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
 int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
-    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->stage_in, &h->stage_out})
+    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->env, &h->stage_in, &h->stage_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
+    if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->flags_ev); }
     for (auto e : h->events) (void)hipEventDestroy(e);
     delete h;
     return SDFGPU_OK;
@@ -545,6 +607,7 @@ int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs
                            int32_t* d_plane_dsq, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     h->guard = nullptr;
+    h->far_y = nullptr;
     if (!d_filled || !d_plane_dsq) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
     if (int rc = check_dims(h, nxs, ny, nz)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -566,6 +629,7 @@ int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t h
     if (halo_lo < 0 || halo_hi < 0 || x_global < 0 || x_global + nxs > nx_global)
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "inconsistent slab geometry");
     h->guard = nullptr;
+    h->far_y = nullptr;
     if (int rc = check_dims(h, halo_lo + nxs + halo_hi, ny, nz)) return rc;
     if (int rc = check_dims(h, nx_global, ny, nz)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -672,12 +736,12 @@ int sdfgpu_set_profiling(sdfgpu_handle h, int enable) {
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds) {
     if (!h || !out_ms_sum || !out_builds) return SDFGPU_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    for (int k = 0; k < 5; ++k) out_ms_sum[k] = 0.0;
+    for (int k = 0; k < 7; ++k) out_ms_sum[k] = 0.0;
     *out_builds = 0;
     if (h->events.empty()) return SDFGPU_OK;
     HIP_TRY(h, hipEventSynchronize(h->events.back()));
-    for (size_t i = 0; i + 5 < h->events.size(); i += 6) {
-        for (int k = 0; k < 5; ++k) {
+    for (size_t i = 0; i + 7 < h->events.size(); i += 8) {
+        for (int k = 0; k < 7; ++k) {
             float ms = 0.f;
             HIP_TRY(h, hipEventElapsedTime(&ms, h->events[i + k], h->events[i + k + 1]));
             out_ms_sum[k] += ms;
@@ -699,6 +763,8 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "fused_window") h->fused_h = value;
     else if (n == "plane16") h->plane16_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
+    else if (n == "envelope") h->envelope_on = value != 0;
+    else if (n == "scan_bound") { h->scan_y = h->scan_x = value; h->flags_pending = false; }
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
@@ -715,10 +781,11 @@ int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified) {
     if (!h || !out_certified) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!h->have_result) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no build has been issued on this handle");
     HIP_TRY(h, hipSetDevice(h->device));
-    uint32_t v[4];
+    uint32_t v[8];
     HIP_TRY(h, hipMemcpyAsync(v, h->d_small, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
-    *out_certified = (h->last_dense && v[3] == 0) ? 1 : 0;
+    // bit 0: dense kernel decided everything; bit 1 / 2: the y / x sweep was redone by the envelope kernel
+    *out_certified = ((h->last_dense && v[3] == 0) ? 1 : 0) | (v[4] ? 2 : 0) | (v[5] ? 4 : 0);
     return SDFGPU_OK;
 }
 

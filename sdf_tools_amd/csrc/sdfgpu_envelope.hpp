@@ -1,0 +1,167 @@
+// sdfgpu_envelope.hpp -- KE2 / KE3: exact lower-envelope sweeps for far-field scenes.
+//
+// The marching kernels (K2, K3/16) decide every voxel whose nearest opposite-class site is close and
+// continue with an outward scan otherwise.  That scan costs O(distance) per voxel, which is fine for
+// moderately sparse scenes but not for the scenes robots actually see (a few objects in a large free
+// volume: distances of hundreds of voxels -- 512^3 from a 200 k point cloud took ~100 ms).  So the scan
+// is bounded (kMaxScan rows); a voxel that is still undecided raises a "far" flag and the sweep is redone
+// for the whole grid by the kernel below, which is O(line length) per line whatever the distances.
+//
+// One lane owns one line and runs the classic lower-envelope-of-parabolas algorithm (Felzenszwalb &
+// Huttenlocher / Meijster) in exact integer arithmetic: with A_i = f(i) + i^2, site q dominates the top
+// of the stack v_k over its whole interval iff (A_q - A_k)(v_k - v_{k-1}) <= (A_k - A_{k-1})(q - v_k)
+// (64-bit cross-multiplication, no divisions, no stored intersection points); the fill pass advances to
+// the next parabola when A_{k+1} - A_k <= 2 p (v_{k+1} - v_k).  Each line is processed twice, once per
+// class (sites of the "distance to filled" function, evaluated on free voxels, and vice versa) -- the
+// same signed-field convention as everywhere else.  Consecutive lanes own consecutive z, so every row
+// read and write is a coalesced segment; the per-line stacks live in a global scratch array laid out
+// [depth][line], so lanes at equal depth (the common case) access it coalesced as well and the two
+// hottest entries of each stack stay in registers.
+#pragma once
+#include "sdfgpu_kernels.hpp"
+#include "sdfgpu_sweep_x16.hpp"
+
+namespace sdfgpu {
+
+// Rows the marching kernels scan outward before handing the sweep to the envelope kernel.  Both settings
+// are exact; the context picks one per axis from what the previous build on the handle turned out to be
+// (flags read back asynchronously): after a far-field build the next one barely scans (it will be redone
+// anyway), after a near-field build it scans long enough that mid-sparse scenes never pay for an envelope
+// pass they do not need.
+constexpr int kScanExpectNear = 40;
+constexpr int kScanExpectFar = 4;
+
+struct EnvArgs {
+    const int16_t* in16;      // STAGE 2: z field (+-g, 32767 = none); STAGE 3: plane field p16
+    const int32_t* side_in;   // STAGE 3: exact values where p16 is saturated
+    void* out;                // STAGE 2: int16 plane field; STAGE 3: float sdf
+    int32_t* side_out;        // STAGE 2: exact plane values (written for every voxel)
+    int2* scratch;            // [L][nlines] stack entries (v, A)
+    int64_t nlines;           // lines = lanes
+    int64_t cpl;              // lines per outer unit (STAGE 2: nz per x-plane; STAGE 3: all)
+    int64_t outer_stride;     // elements between outer units (STAGE 2: ny*nz)
+    int64_t line_stride;      // elements between successive positions of a line
+    int L;
+    double resolution;        // STAGE 3
+    int vb;
+    int64_t nx, ny, nz;       // full extents (virtual border)
+    uint32_t* maxdsq;
+    const uint32_t* guard;    // run only if *guard != 0
+};
+
+template <int STAGE>
+__global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
+    if (a.guard && *a.guard == 0u) return;
+    int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = t < a.nlines;
+    if (!valid) t = a.nlines - 1;
+    const int64_t o = t / a.cpl;
+    const int64_t base = o * a.outer_stride + (t - o * a.cpl);
+    const int64_t ls = a.line_stride, nl = a.nlines;
+    const int L = a.L;
+    int mxF = 0, mxQ = 0;
+
+    // exact signed value at position p: + free / - filled, magnitude kInf32 = no site
+    auto load_signed = [&](int p) -> int {
+        const int v = a.in16[base + (int64_t)p * ls];
+        if constexpr (STAGE == 2) {
+            const int g = abs(v);
+            const int sq = g >= kInf16 ? kInf32 : g * g;
+            return v < 0 ? -sq : sq;
+        } else {
+            if (abs(v) >= kSat16) return a.side_in[base + (int64_t)p * ls];
+            return v;
+        }
+    };
+
+    // virtual-border coordinates of this line (STAGE 3: the line runs along x at fixed (y, z))
+    int vy = 0, vz = 0;
+    if constexpr (STAGE == 3) { vy = (int)(t / a.nz); vz = (int)(t - (int64_t)vy * a.nz); }
+
+    constexpr int CH = 8;                      // rows fetched per batch: 8 independent loads in flight per lane
+    if (valid) {                               // (lanes past the last line must not touch another line's stack)
+#pragma unroll 1
+    for (int cls = 0; cls < 2; ++cls) {        // 0: sites of "distance to filled" (for free voxels), 1: the other
+        // ---- forward: build the envelope -------------------------------------------------------------
+        int k = -1;
+        int vt = 0, At = 0, vs = 0, As = 0;     // top and second entry (copies of scratch[k], scratch[k-1])
+        for (int q0 = 0; q0 < L; q0 += CH) {
+            int sv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) sv[u] = (q0 + u < L) ? load_signed(q0 + u) : (cls == 0 ? kInf32 : -kInf32);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int q = q0 + u;
+                const int s = sv[u];
+                // value of this class's function at q: |s| on voxels of the class that looks for the other one,
+                // 0 on voxels that ARE the sought class
+                const int val = cls == 0 ? (s > 0 ? s : 0) : (s < 0 ? -s : 0);
+                if (val < kInf32) {             // else: no site of the sought class in this voxel's row / plane
+                    const int Aq = val + q * q;
+                    while (k >= 1 && (int64_t)(Aq - At) * (vt - vs) <= (int64_t)(At - As) * (q - vt)) {
+                        --k; vt = vs; At = As;
+                        if (k >= 1) { const int2 e = a.scratch[(int64_t)(k - 1) * nl + t]; vs = e.x; As = e.y; }
+                    }
+                    ++k;
+                    a.scratch[(int64_t)k * nl + t] = make_int2(q, Aq);
+                    vs = vt; As = At; vt = q; At = Aq;
+                }
+            }
+        }
+        // ---- backward: evaluate on the voxels that need this class --------------------------------------
+        int j = 0, v0 = 0, A0 = 0, v1 = 0, A1 = 0;
+        if (k >= 0) { const int2 e = a.scratch[t]; v0 = e.x; A0 = e.y; }
+        if (k >= 1) { const int2 e = a.scratch[nl + t]; v1 = e.x; A1 = e.y; }
+        for (int p0 = 0; p0 < L; p0 += CH) {
+            int16_t rawv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) rawv[u] = (p0 + u < L) ? a.in16[base + (int64_t)(p0 + u) * ls] : (int16_t)0;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int p = p0 + u;
+                if (p >= L) break;
+                while (j < k && (int64_t)(A1 - A0) <= (int64_t)2 * p * (v1 - v0)) {
+                    ++j; v0 = v1; A0 = A1;
+                    if (j < k) { const int2 e = a.scratch[(int64_t)(j + 1) * nl + t]; v1 = e.x; A1 = e.y; }
+                }
+                const bool filled = rawv[u] < 0;
+                if ((cls == 0) == filled) continue;                  // this voxel belongs to the other pass
+                int D = kInf32;
+                if (k >= 0) {
+                    const int64_t d = (int64_t)A0 + (int64_t)p * p - (int64_t)2 * p * v0;
+                    D = (int)min(d, (int64_t)kInf32);
+                }
+                const int64_t oi = base + (int64_t)p * ls;
+                if constexpr (STAGE == 2) {
+                    a.side_out[oi] = filled ? -D : D;
+                    reinterpret_cast<int16_t*>(a.out)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
+                } else {
+                    if (a.vb) {
+                        int64_t b = kInf32;
+                        if (a.nx > 1) b = min(b, min((int64_t)p + 1, a.nx - p));
+                        if (a.ny > 1) b = min(b, min((int64_t)vy + 1, a.ny - vy));
+                        if (a.nz > 1) b = min(b, min((int64_t)vz + 1, a.nz - vz));
+                        if (b < 32768) D = min(D, (int)(b * b));
+                    }
+                    if (filled) mxQ = max(mxQ, D); else mxF = max(mxF, D);
+                    const float f = (D >= kInf32) ? __builtin_inff() : (float)(sqrt((double)D) * a.resolution);
+                    reinterpret_cast<float*>(a.out)[oi] = filled ? -f : f;
+                }
+            }
+        }
+    }
+    }
+    if constexpr (STAGE == 3) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mxF = max(mxF, __shfl_xor(mxF, off));
+            mxQ = max(mxQ, __shfl_xor(mxQ, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
+            if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
+        }
+    }
+}
+
+}  // namespace sdfgpu

@@ -233,6 +233,9 @@ struct SweepArgs {
     int out16;
     int32_t* side;
     const uint32_t* guard;            // non-null: run only if *guard != 0 (dense path left voxels uncertified)
+    // bounded outward scan (far-field scenes are redone by the envelope kernel, sdfgpu_envelope.hpp)
+    int max_scan;                     // 0 = unbounded
+    uint32_t* far_flag;               // raised when a voxel was still undecided after max_scan rows
 };
 
 template <int STAGE, int V> struct InVecT;
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
     int win[R][V];                          // win[slot(row)] ; slot(row) = (row - p0 + H) mod R
     int mxF = 0, mxQ = 0;                   // K3: max d^2 over free / filled voxels
     bool unresolved = false;
+    bool far = false;
 
     // virtual-border coordinates of this lane's V voxels (K3 only)
     int vy[V], vz[V];
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) act |= dd < best[k];
                 if (!__any(act)) break;
+                if (a.max_scan && d > a.max_scan) { far |= act; break; }     // leave it to the envelope kernel
                 if (act) {
                     int s[V];
                     if (lo >= 0) {
@@ -476,6 +481,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
         }
     }
 
+    if (a.far_flag) {
+        if (__any(far) && (threadIdx.x & 63) == 0) atomic_or_if_new(a.far_flag, 1u);
+    }
     if constexpr (STAGE == 3) {
         // wave-level max, one atomic per wave per class
 #pragma unroll

@@ -63,12 +63,15 @@ struct SweepX16Args {
     uint32_t* maxdsq;        // [0] free, [1] filled
     uint32_t* status;        // bit 0: a voxel needed data beyond the buffer (slab mode)
     const uint32_t* guard;   // non-null: run only if *guard != 0
+    int max_scan;            // 0 = unbounded outward scan
+    uint32_t* far_flag;      // raised when a voxel was still undecided after max_scan rows
 };
 
 template <int V>
 struct ExactScan {
     int D[V];
     int unresolved;
+    int inexact;             // bit k: voxel k was still undecided when the bounded scan stopped
 };
 
 template <int V> struct Raw16T;
@@ -94,7 +97,7 @@ __device__ __noinline__ float finish_large(int D, double resolution) {
 template <int V>
 __device__ __noinline__ ExactScan<V> x16_exact_scan(const int16_t* __restrict__ in16, const int32_t* __restrict__ side32,
                                                     int64_t base, int64_t ls, int L, int side_lo, int side_hi,
-                                                    int p, int lim, ExactScan<V> st) {
+                                                    int p, int lim, int max_scan, ExactScan<V> st) {
     using RawT = typename Raw16T<V>::type;
     auto fetch_exact = [&](int q, int (&s)[V]) {
         const RawT raw = *reinterpret_cast<const RawT*>(in16 + base + (int64_t)q * ls);
@@ -132,6 +135,11 @@ __device__ __noinline__ ExactScan<V> x16_exact_scan(const int16_t* __restrict__ 
 #pragma unroll
         for (int k = 0; k < V; ++k) act |= dd < st.D[k];
         if (!__any(act)) break;
+        if (max_scan && d > max_scan) {           // far field: the envelope kernel redoes this sweep
+#pragma unroll
+            for (int k = 0; k < V; ++k) st.inexact |= (dd < st.D[k]) ? (1 << k) : 0;
+            break;
+        }
         if (act) {
             int s[V];
             if (lo >= 0) {
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
     uint32_t WP[R][NP], WQ[R][NP];       // window, packed u16 pairs
     int mxF = 0, mxQ = 0;
     bool unresolved = false;
+    bool far = false;
 
     int vy[V], vz[V];
     if constexpr (VB) {
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
         const bool need = ((worst & 0xffffu) >= kLim) || ((worst >> 16) >= kLim);
         int D[V];
         bool filled[V];
+        int inexact = 0;
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             D[k] = (int)((best[k >> 1] >> (16 * (k & 1))) & 0xffffu);
@@ -235,10 +245,13 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
 #pragma unroll
             for (int k = 0; k < V; ++k) st.D[k] = D[k];
             st.unresolved = 0;
-            st = x16_exact_scan<V>(a.in16, a.side32, base, ls, L, a.side_lo, a.side_hi, p, (int)kLim, st);
+            st.inexact = 0;
+            st = x16_exact_scan<V>(a.in16, a.side32, base, ls, L, a.side_lo, a.side_hi, p, (int)kLim, a.max_scan, st);
 #pragma unroll
             for (int k = 0; k < V; ++k) D[k] = st.D[k];
             unresolved |= st.unresolved != 0;
+            inexact = st.inexact;
+            far |= inexact != 0;
         }
         if constexpr (SLAB) {
             if (a.lo_truncated) {
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
                 if (a.nz > 1) b = min(b, min((int64_t)vz[k] + 1, a.nz - vz[k]));
                 if (b < 32768) Dk = min(Dk, (int)(b * b));
             }
-            if (filled[k]) mxQ = max(mxQ, Dk); else mxF = max(mxF, Dk);
+            if (!((inexact >> k) & 1)) { if (filled[k]) mxQ = max(mxQ, Dk); else mxF = max(mxF, Dk); }
             const float f = (Dk < kLutN) ? lut[Dk] : finish_large(Dk, a.resolution);
             o[k] = filled[k] ? -f : f;
         }
@@ -328,7 +341,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
         mxQ = max(mxQ, __shfl_xor(mxQ, off));
     }
     const bool any_unres = __any(unresolved);
+    const bool any_far = __any(far);
     if ((threadIdx.x & 63) == 0) {
+        if (any_far && a.far_flag) atomic_or_if_new(a.far_flag, 1u);
         if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
         if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
         if (any_unres && a.status) atomic_or_if_new(a.status, 1u);

@@ -1,0 +1,70 @@
+"""GPU: far-field scenes.  The marching kernels stop scanning after kMaxScan rows, raise a flag, and the
+lower-envelope kernels (KE2 / KE3) redo the sweep exactly.  Results must equal the exact oracle and the
+unbounded-scan path bit for bit."""
+import numpy as np
+import pytest
+
+import scenes
+from oracle import oracle as O
+from sdf_tools_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_boxes(shape):
+    nx, ny, nz = shape
+    m = np.zeros(shape, np.uint8)
+    m[nx // 10: nx // 10 + max(2, nx // 8), ny // 2: ny // 2 + max(2, ny // 6), : max(2, nz // 3)] = 1
+    m[nx // 2: nx // 2 + max(2, nx // 5), ny // 8: ny // 8 + max(2, ny // 5), nz // 4: nz // 4 + max(2, nz // 4)] = 1
+    return m
+
+
+CASES = [
+    ("two boxes 64^3", _two_boxes((64, 64, 64)), False),
+    ("two boxes 96x80x128 vb", _two_boxes((96, 80, 128)), True),
+    ("single voxel 40x48x512", scenes.single_voxel((40, 48, 512), (3, 40, 500)), False),
+    ("inverse single voxel", 1 - scenes.single_voxel((33, 20, 64)), False),
+    ("sparse cloud", synth.bernoulli_mask((80, 72, 64), 0.0003, 3), False),
+    ("sparse + dense half", np.concatenate([synth.bernoulli_mask((40, 48, 64), 0.5, 1), np.zeros((40, 48, 64), np.uint8)]), False),
+    ("thin wall far away", np.pad(np.ones((1, 50, 32), np.uint8), ((60, 0), (0, 0), (0, 0))), True),
+    ("2-D 300x400", synth.bernoulli_mask((1, 300, 400), 0.0002, 5), False),
+    ("all free", np.zeros((20, 24, 32), np.uint8), False),
+]
+
+
+@pytest.mark.parametrize("name,m,vb", CASES, ids=[c[0] for c in CASES])
+def test_far_field_scenes_are_exact(gpu, name, m, vb):
+    res = 0.02
+    sdf, ext = gpu.build(m, res, vb)
+    path = gpu.last_path()
+    ex, ex_ext, dsq = O.exact_sdf(m, res, vb)
+    bad = np.argwhere(sdf.view(np.uint32) != ex.view(np.uint32))
+    assert len(bad) == 0, "%s: %d voxels differ, first at %s got %r want %r (path %s)" % (
+        name, len(bad), bad[0].tolist(), sdf[tuple(bad[0])], ex[tuple(bad[0])], path)
+    assert ext == ex_ext, (name, ext, ex_ext, path)
+    if name.startswith(("two boxes", "single voxel", "thin wall")):
+        assert path["far_y"] or path["far_x"]              # these really exercise the envelope kernels
+    gpu.set_option("envelope", 0)
+    try:
+        sdf2, ext2 = gpu.build(m, res, vb)                  # unbounded scans
+        p2 = gpu.last_path()
+    finally:
+        gpu.set_option("envelope", 1)
+    assert not p2["far_y"] and not p2["far_x"]
+    assert np.array_equal(sdf.view(np.uint32), sdf2.view(np.uint32)) and ext == ext2
+
+
+def test_point_cloud_scene_512(gpu):
+    """The streaming configuration's scene: 200 k points in two boxes at 512^3."""
+    import torch
+    from sdf_tools_amd.streaming import StreamingSdf
+    n, res = 512, 0.01
+    st = StreamingSdf((n, n, n), res, (0.0, 0.0, 0.0), 0, gradient=False)
+    pc = synth.two_box_points(200000, seed=0, scale=n * res)
+    sdf, _ = st.frame(torch.from_numpy(pc).cuda())
+    torch.cuda.synchronize()
+    mask = st.mask.cpu().numpy()
+    ex, ex_ext, _ = O.exact_sdf(mask, res)
+    assert np.array_equal(sdf.cpu().numpy(), ex) and st.extrema() == ex_ext
+    path = st.ctx.last_path()
+    assert not path["dense_certified"] and (path["far_y"] or path["far_x"])
