@@ -60,6 +60,7 @@ struct sdfgpu_context {
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
     bool prev_dense = false;
+    bool expect_dense = false;
     bool last_dense = false;
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
@@ -387,17 +388,21 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     const bool dense = dense_eligible(h, nz, vb) && ny <= 0x7fffffff;
     const bool fused = !dense && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
-    const bool envelope = p16 && h->envelope_on;
-    if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
-    // learn from the previous build (if its flags have arrived): far-field -> do not bother scanning
+    // learn from the previous build (if its flags have arrived).  Every setting is exact; they only
+    // move work around: far-field -> do not bother scanning; dense-certified -> the general kernels will
+    // exit on their guard anyway, so do not enqueue the two envelope kernels behind them (and leave the
+    // scans unbounded in case this build is the exception).
     if (h->flags_pending && hipEventQuery(h->flags_ev) == hipSuccess) {
         h->flags_pending = false;
         const bool general_ran = !h->prev_dense || h->h_flags[3] != 0;
+        h->expect_dense = !general_ran;
         if (general_ran) {
             h->scan_y = h->h_flags[4] ? kScanExpectFar : kScanExpectNear;
             h->scan_x = h->h_flags[5] ? kScanExpectFar : kScanExpectNear;
         }
     }
+    const bool envelope = p16 && h->envelope_on && !(h->expect_dense && dense_eligible(h, nz, vb));
+    if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (h->profiling) {
@@ -449,7 +454,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                      nx, ny, nz, resolution, vb, h->d_small, h->d_small + 5, s)) return rc;
     h->guard = nullptr;
     h->far_y = nullptr;
-    if (envelope && h->h_flags) {      // asynchronous read-back of the flags for the next build's policy
+    if (p16 && h->envelope_on && h->h_flags) {      // asynchronous read-back of the flags for the next build's policy
         HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_small, 32, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipEventRecord(h->flags_ev, s));
         h->flags_pending = true;
@@ -764,7 +769,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "plane16") h->plane16_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;
-    else if (n == "scan_bound") { h->scan_y = h->scan_x = value; h->flags_pending = false; }
+    else if (n == "scan_bound") { h->scan_y = h->scan_x = value; h->flags_pending = false; h->expect_dense = false; }
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);

@@ -68,3 +68,23 @@ def test_point_cloud_scene_512(gpu):
     assert np.array_equal(sdf.cpu().numpy(), ex) and st.extrema() == ex_ext
     path = st.ctx.last_path()
     assert not path["dense_certified"] and (path["far_y"] or path["far_x"])
+
+
+def test_policy_transitions_stay_exact(gpu):
+    """The handle adapts its scan bounds / kernel list to the previous build; every combination of
+    previous and current scene type must still be exact."""
+    import torch
+    shape = (48, 40, 64)
+    scenes_ = {
+        "dense": synth.bernoulli_mask(shape, 0.5, 1),
+        "far": _two_boxes(shape),
+        "mid": synth.bernoulli_mask(shape, 0.01, 2),
+        "empty": np.zeros(shape, np.uint8),
+    }
+    want = {k: O.exact_sdf(m, 0.05) for k, m in scenes_.items()}
+    order = ["dense", "dense", "far", "far", "dense", "mid", "far", "mid", "mid", "empty", "dense", "far", "dense", "dense"]
+    for name in order:
+        sdf, ext = gpu.build(scenes_[name], 0.05)
+        torch.cuda.synchronize()
+        assert np.array_equal(sdf.view(np.uint32), want[name][0].view(np.uint32)), name
+        assert ext == want[name][1], name
