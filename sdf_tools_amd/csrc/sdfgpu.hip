@@ -53,6 +53,9 @@ struct sdfgpu_context {
     int tune_ty = 0, tune_tx = 0, tune_tzy = 0, fused_h = 0;
     bool fused_zy = true;            // use K12 (z sweep fused into the y sweep) when the shape allows
     bool dense_on = true;            // try the bit-parallel dense kernel first when the shape allows
+    int pack_variant = 0;
+    int ball_block = 0;
+    int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
     int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // scan bounds, adapted from the previous build
@@ -326,9 +329,16 @@ int launch_pack_bits(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells
                            ld, d_bits, n);
     } else if ((reinterpret_cast<uintptr_t>(d_mask) % 16) == 0) {
         const int64_t n16 = n / 16;
-        const int64_t per_block = (int64_t)kBlock * kPackChunks;
-        hipLaunchKernelGGL(k_pack_bits_mask, dim3((unsigned)((n16 + per_block - 1) / per_block)), dim3(kBlock), 0, s, d_mask,
-                           d_bits, n16);
+        auto blocks = [&](int chunks) { const int64_t pb = (int64_t)kBlock * chunks; return dim3((unsigned)((n16 + pb - 1) / pb)); };
+        switch (h->pack_variant) {
+            case 1: hipLaunchKernelGGL((k_pack_bits_mask<1, false>), blocks(1), dim3(kBlock), 0, s, d_mask, d_bits, n16); break;
+            case 2: hipLaunchKernelGGL((k_pack_bits_mask<2, false>), blocks(2), dim3(kBlock), 0, s, d_mask, d_bits, n16); break;
+            case 3: hipLaunchKernelGGL((k_pack_bits_mask<8, false>), blocks(8), dim3(kBlock), 0, s, d_mask, d_bits, n16); break;
+            case 4: hipLaunchKernelGGL((k_pack_bits_mask<4, true>), blocks(4), dim3(kBlock), 0, s, d_mask, d_bits, n16); break;
+            case 5: hipLaunchKernelGGL((k_pack_bits_mask<1, true>), blocks(1), dim3(kBlock), 0, s, d_mask, d_bits, n16); break;
+            case 6: hipLaunchKernelGGL((k_pack_bits_mask<4, false>), blocks(4), dim3(kBlock), 0, s, d_mask, d_bits, n16); break;
+            default: hipLaunchKernelGGL((k_pack_bits_mask<4, true>), blocks(4), dim3(kBlock), 0, s, d_mask, d_bits, n16); break;
+        }
     } else {
         MaskLoader ld{d_mask};
         hipLaunchKernelGGL(k_pack_bits_generic<MaskLoader>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
@@ -346,7 +356,10 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     a.log2_nzw = 0;
     while ((1 << a.log2_nzw) < a.nzw) ++a.log2_nzw;
     a.ny = (int)ny; a.rows_x = (int)rows_x; a.out_lo = (int)out_lo; a.out_hi = (int)out_hi;
-    const int rows = kBlock / a.nzw;                       // tile rows per workgroup
+    int bd = h->ball_block > 0 ? h->ball_block : 256;
+    if (bd != 256 && bd != 512 && bd != 1024) bd = 256;
+    while (bd / a.nzw < 1) bd *= 2;
+    const int rows = bd / a.nzw;                           // tile rows per workgroup
     int best_tx = 1, best_ty = rows, best_cost = 1 << 30;
     for (int ty = 1; ty <= rows; ty *= 2) {                // smallest halo-inclusive footprint
         const int tx = rows / ty;
@@ -358,11 +371,14 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     while ((1 << a.log2_ty) < a.ty) ++a.log2_ty;
     a.resolution = resolution;
     a.maxdsq = d_maxdsq; a.uncertified = d_uncert;
+    a.nt_store = h->nt_store;
     const int64_t gx = (ny + a.ty - 1) / a.ty, gy = (out_hi - out_lo + a.tx - 1) / a.tx;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
     const size_t tile_words = ((size_t)(a.tx + 2 * kBallR) * (a.ty + 2 * kBallR) * (a.nzw + 2) + 3) & ~(size_t)3;
-    const size_t lds = tile_words * 4 + kBlock * 16 + 64 * 8;
-    hipLaunchKernelGGL(k_ball_dense, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), lds, s, a);
+    const size_t lds = tile_words * 4 + (size_t)bd * 16 + 64 * 8;
+    if (bd == 1024) hipLaunchKernelGGL(k_ball_dense<1024>, dim3((unsigned)gx, (unsigned)gy), dim3(1024), lds, s, a);
+    else if (bd == 512) hipLaunchKernelGGL(k_ball_dense<512>, dim3((unsigned)gx, (unsigned)gy), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(k_ball_dense<256>, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, s, a);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -386,7 +402,9 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // When the dense kernel runs in front, the general pipeline only does work on scenes that are
     // not dense; there K1 + K2 (rows from the int16 z field) beat the fused kernel's recomputation.
     const bool dense = dense_eligible(h, nz, vb) && ny <= 0x7fffffff;
-    const bool fused = !dense && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
+    // ... except when the previous build was dense-certified: then the general kernels are expected to
+    // exit on their guard, and the fused kernel makes that one launch fewer (K12 instead of K1 + K2).
+    const bool fused = (!dense || h->expect_dense) && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     // learn from the previous build (if its flags have arrived).  Every setting is exact; they only
     // move work around: far-field -> do not bother scanning; dense-certified -> the general kernels will
@@ -769,6 +787,9 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "plane16") h->plane16_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;
+    else if (n == "pack_variant") h->pack_variant = value;
+    else if (n == "nt_store") h->nt_store = value;
+    else if (n == "ball_block") h->ball_block = value;
     else if (n == "scan_bound") { h->scan_y = h->scan_x = value; h->flags_pending = false; h->expect_dense = false; }
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;

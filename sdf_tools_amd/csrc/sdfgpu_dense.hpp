@@ -31,26 +31,38 @@ namespace sdfgpu {
 // K0: pack.  bits[(row) * nzw + w] bit i = voxel z = 32 w + i of that row is filled.
 // ---------------------------------------------------------------------------------------------
 
-// uint8 mask, nz % 32 == 0, 16-byte aligned: a lane folds 16 bytes, lane pairs form one 32-bit word.
-// Each lane handles kPackChunks chunks a whole grid apart, so four independent 16-byte loads are in
-// flight per lane and the launch has 4x fewer workgroups to schedule.
-constexpr int kPackChunks = 4;
+// uint8 mask, nz % 32 == 0, 16-byte aligned: a lane folds 16 bytes to 16 bits, lane pairs form one 32-bit
+// word (DPP quad permute, no LDS).  CHUNKS independent 16-byte loads per lane are in flight at once,
+// taken a whole grid apart so every load instruction stays a contiguous 1 KiB per wave.  The mask is read
+// exactly once, so the loads are non-temporal: measured 53 -> 31 us at 512^3, and the ball kernel behind
+// it gets faster too because the 134 MB mask no longer evicts the 17 MB bit field from L2 / MALL.
+template <int CHUNKS, bool NT>
 __global__ __launch_bounds__(kBlock) void k_pack_bits_mask(const uint8_t* __restrict__ mask,
                                                           uint32_t* __restrict__ bits, int64_t n16) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // 16-voxel chunk index
-    uint4 v[kPackChunks];
+    uint4 v[CHUNKS];
 #pragma unroll
-    for (int k = 0; k < kPackChunks; ++k) {
+    for (int k = 0; k < CHUNKS; ++k) {
         const int64_t i = i0 + k * stride;
-        v[k] = (i < n16) ? *reinterpret_cast<const uint4*>(mask + 16 * i) : make_uint4(0, 0, 0, 0);
+        if (i < n16) {
+            const uint4* src = reinterpret_cast<const uint4*>(mask + 16 * i);
+            if constexpr (NT) {
+                v[k].x = __builtin_nontemporal_load(&src->x); v[k].y = __builtin_nontemporal_load(&src->y);
+                v[k].z = __builtin_nontemporal_load(&src->z); v[k].w = __builtin_nontemporal_load(&src->w);
+            } else {
+                v[k] = *src;
+            }
+        } else {
+            v[k] = make_uint4(0, 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int k = 0; k < kPackChunks; ++k) {
+    for (int k = 0; k < CHUNKS; ++k) {
         const int64_t i = i0 + k * stride;
         const uint32_t b = nonzero_bits4(v[k].x) | (nonzero_bits4(v[k].y) << 4) | (nonzero_bits4(v[k].z) << 8) |
                            (nonzero_bits4(v[k].w) << 12);
-        const uint32_t other = __shfl_xor(b, 1);
+        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)b, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         if (i < n16 && (threadIdx.x & 1) == 0) bits[i >> 1] = b | (other << 16);
     }
 }
@@ -81,11 +93,12 @@ struct DenseArgs {
     int ny;
     int rows_x;             // x-planes present in `bits`
     int out_lo, out_hi;     // x-planes (buffer coordinates) whose voxels are written
-    int tx, ty;             // tile rows per workgroup along x / y (powers of two); tx * ty * nzw == 256
+    int tx, ty;             // tile rows per workgroup along x / y (powers of two); tx * ty * nzw == block size
     int log2_ty;
     double resolution;
     uint32_t* maxdsq;       // [0] free, [1] filled
     uint32_t* uncertified;  // set to 1 if some voxel has no opposite-class voxel within d^2 <= 8
+    int nt_store;           // write the output with non-temporal stores (it is never re-read here)
 };
 
 constexpr int kBallR = 2;                                    // |dx|,|dy|,|dz| <= 2
@@ -94,14 +107,15 @@ __host__ __device__ constexpr int ball_level(int d2) {       // d^2 -> level ind
 }
 __device__ constexpr int kLevelD2[7] = {1, 2, 3, 4, 5, 6, 8};
 
-__global__ __launch_bounds__(kBlock) void k_ball_dense(const DenseArgs a) {
+template <int BD>      // workgroup size: a larger tile amortises the 2-row halo (4x -> 3x -> 2.25x rows staged)
+__global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nzw = a.nzw, lg = a.log2_nzw;
     const int rw = nzw + 2;                                   // row pitch in words (edge words replicated)
     const int hx = a.tx + 2 * kBallR, hy = a.ty + 2 * kBallR;
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);               // [hx][hy][rw]
     uint32_t* planes = tile + ((hx * hy * rw + 3) & ~3);                  // [256][4]: b0, b1, b2, class (16-B aligned)
-    float2* lut2 = reinterpret_cast<float2*>(planes + kBlock * 4);        // [64] pair table
+    float2* lut2 = reinterpret_cast<float2*>(planes + BD * 4);            // [64] pair table
     const int t = threadIdx.x;
 
     // pair table: entry i6 holds the magnitudes of two voxels whose level indices are interleaved in i6
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_ball_dense(const DenseArgs a) {
     {
         const int lgp = max(lg + 1, 2);                       // 2^lgp >= nzw + 2 lanes per staged row
         const int lw = t & ((1 << lgp) - 1), lr = t >> lgp;   // word slot, row-in-pass
-        const int rpp = kBlock >> lgp;                        // rows staged per pass
+        const int rpp = BD >> lgp;                            // rows staged per pass
         if (lw < rw) {
             for (int jx = 0; jx < hx; ++jx) {
                 const int gx = min(max(x0 + jx - kBallR, 0), a.rows_x - 1);
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_ball_dense(const DenseArgs a) {
     const int lgz = lg + 5;
 #pragma unroll 2
     for (int j = 0; j < 8; ++j) {
-        const int v = (j << 10) + (t << 2);                   // voxel index inside the tile (row-major)
+        const int v = j * (BD * 4) + (t << 2);                // voxel index inside the tile (row-major)
         const int rr = v >> lgz, z = v & (nz - 1);
         const int tyy = rr & (a.ty - 1), txx = rr >> a.log2_ty;
         const int gx = x0 + txx, gy = y0 + tyy;
@@ -216,8 +230,14 @@ __global__ __launch_bounds__(kBlock) void k_ball_dense(const DenseArgs a) {
         o.y = __uint_as_float(__float_as_uint(fa.y) | ((ns << 2) & 0x80000000u));
         o.z = __uint_as_float(__float_as_uint(fb.x) | ((ns << 1) & 0x80000000u));
         o.w = __uint_as_float(__float_as_uint(fb.y) | (ns & 0x80000000u));
-        if (gx < a.out_hi && gy < a.ny)
-            *reinterpret_cast<float4*>(a.out + ((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z) = o;
+        if (gx < a.out_hi && gy < a.ny) {
+            float* dst = a.out + ((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z;
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v ov;
+            ov.x = o.x; ov.y = o.y; ov.z = o.z; ov.w = o.w;
+            if (a.nt_store) __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(dst));
+            else *reinterpret_cast<f4v*>(dst) = ov;
+        }
     }
 
 #pragma unroll

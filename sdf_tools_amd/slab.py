@@ -139,6 +139,7 @@ class SlabSdfBuilder:
         if self.dense:
             self.bits = torch.zeros((self.bh_lo + self.nxs + self.bh_hi, self.ny, self.nz // 32),
                                     dtype=torch.int32, device=self.device)
+        self._p2p_cache = {}
         self.slots = [_Slot(self.nxs, self.ny, self.nz, self.device) for _ in range(2)]
         self.cur = 0
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
@@ -148,16 +149,21 @@ class SlabSdfBuilder:
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank
 
     def _exchange(self, buf, lo, n, h):
-        """Grouped nearest-neighbour send/recv of `h` boundary planes of buf[lo:lo+n] (asynchronous)."""
+        """Grouped nearest-neighbour send/recv of `h` boundary planes of buf[lo:lo+n] (asynchronous).
+        The P2POp list of a buffer is built once and re-used by every build."""
         if self.world == 1 or h == 0:
             return []
-        ops = []
-        if self.rank > 0:          # lower neighbour: send my first h planes, receive its last h
-            ops.append(dist.P2POp(dist.isend, buf[lo:lo + h], self._peer(self.rank - 1), self.group))
-            ops.append(dist.P2POp(dist.irecv, buf[lo - h:lo], self._peer(self.rank - 1), self.group))
-        if self.rank < self.world - 1:
-            ops.append(dist.P2POp(dist.isend, buf[lo + n - h:lo + n], self._peer(self.rank + 1), self.group))
-            ops.append(dist.P2POp(dist.irecv, buf[lo + n:lo + n + h], self._peer(self.rank + 1), self.group))
+        key = (buf.data_ptr(), lo, n, h)
+        ops = self._p2p_cache.get(key)
+        if ops is None:
+            ops = []
+            if self.rank > 0:          # lower neighbour: send my first h planes, receive its last h
+                ops.append(dist.P2POp(dist.isend, buf[lo:lo + h], self._peer(self.rank - 1), self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[lo - h:lo], self._peer(self.rank - 1), self.group))
+            if self.rank < self.world - 1:
+                ops.append(dist.P2POp(dist.isend, buf[lo + n - h:lo + n], self._peer(self.rank + 1), self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[lo + n:lo + n + h], self._peer(self.rank + 1), self.group))
+            self._p2p_cache[key] = ops
         return dist.batch_isend_irecv(ops)
 
     def _allreduce_small(self, small, async_op=False):

@@ -70,11 +70,12 @@ def test_point_cloud_scene_512(gpu):
     assert not path["dense_certified"] and (path["far_y"] or path["far_x"])
 
 
-def test_policy_transitions_stay_exact(gpu):
-    """The handle adapts its scan bounds / kernel list to the previous build; every combination of
-    previous and current scene type must still be exact."""
+@pytest.mark.parametrize("shape", [(48, 40, 64), (6, 28, 512), (3, 20, 1024)])
+def test_policy_transitions_stay_exact(gpu, shape):
+    """The handle adapts its scan bounds / kernel list to the previous build (after a dense-certified build
+    the guarded general pipeline is K12 + K3 with unbounded scans and no envelope kernels); every
+    combination of previous and current scene type must still be exact."""
     import torch
-    shape = (48, 40, 64)
     scenes_ = {
         "dense": synth.bernoulli_mask(shape, 0.5, 1),
         "far": _two_boxes(shape),
