@@ -30,6 +30,23 @@ def main():
     for f in range(3):
         st.frame(clouds[f % 4])
     torch.cuda.synchronize()
+    # per-stage breakdown of one profiled frame (HIP events inside the library), outside the timed loop
+    st.ctx.get_stage_times()
+    st.ctx.set_profiling(True)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    st.ctx.voxelize_points_device(clouds[0].data_ptr(), clouds[0].shape[0], st.origin, st.resolution, st.shape,
+                                  st.mask.data_ptr(), True, torch.cuda.current_stream().cuda_stream)
+    e1.record()
+    st.frame(clouds[0])
+    e2.record()
+    torch.cuda.synchronize()
+    ms, _ = st.ctx.get_stage_times()
+    st.ctx.set_profiling(False)
+    names = ["pack_bits", "dense_ball", "sweep_z", "sweep_y", "envelope_y", "sweep_x", "envelope_x"]
+    breakdown = {k: round(v, 3) for k, v in zip(names, ms)}
+    breakdown["voxelize"] = round(e0.elapsed_time(e1), 3)
+    breakdown["frame_total_incl_gradient"] = round(e1.elapsed_time(e2), 3)
     t0 = time.perf_counter()
     for f in range(args.frames):
         st.frame(clouds[f % 4])
@@ -40,7 +57,8 @@ def main():
                       "value": round(args.frames / dt, 2), "unit": "Hz", "ms_per_frame": round(dt / args.frames * 1e3, 3),
                       "grid": [n, n, n], "points_per_frame": args.points, "occupancy": occ,
                       "kernels": st.ctx.last_build_info(), "path": st.ctx.last_path(),
-                      "extrema": st.extrema(), "target_hz": 30}))
+                      "extrema": st.extrema(), "target_hz": 30,
+                      "stage_ms_one_frame": breakdown}))
 
 
 if __name__ == "__main__":

@@ -203,14 +203,15 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
 
-/* Named integer options (benchmarks / A-B tests): "fused_zy" (1 = use the fused z+y kernel when the
- * shape allows, default; 0 = always run K1 + K2), "rows_per_chunk_y", "rows_per_chunk_x",
+/* Named integer options (benchmarks / A-B tests): "fused_zy" (1 = let the policy use the fused z+y kernel,
+ * default; 0 = never; 2 = always when the shape allows), "rows_per_chunk_y", "rows_per_chunk_x",
  * "rows_per_chunk_zy" (0 = automatic), "fused_window" (register-window radius of the fused kernel at
  * nz = 512: 2 or 3), "plane16" (1 = int16 plane field + int32 side table between the y and x sweeps
  * when the shape allows, default; 0 = int32 plane field), "x16_voxels_per_lane" (4 or 8),
  * "x16_window" (2 or 3), "dense" (1 = try the bit-parallel dense kernel first, default; 0 = general
  * pipeline only), "envelope" (1 = bound the outward scans of K2 / K3 and redo far-field sweeps with the
- * lower-envelope kernels, default; 0 = unbounded scans). */
+ * lower-envelope kernels, default; 0 = unbounded scans), "envelope_mode" (force / clear the per-axis
+ * "envelope kernel alone" policy state), "policy_reset" (forget what was learned from earlier builds). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),

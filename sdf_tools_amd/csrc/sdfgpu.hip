@@ -58,7 +58,10 @@ struct sdfgpu_context {
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
-    int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // scan bounds, adapted from the previous build
+    int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // outward-scan bounds of the marching kernels
+    bool env_mode_y = false, env_mode_x = false;               // policy: run the envelope kernel alone on that axis
+    bool prev_env_y = false, prev_env_x = false;
+    bool fused_always = false;
     uint32_t* h_flags = nullptr;     // pinned host copy of d_small, filled asynchronously after every build
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
@@ -399,27 +402,35 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (p16) if (int rc = ensure(h, h->plane16, (size_t)n * 2)) return rc;
     void* zy_out = p16 ? h->plane16.ptr : h->yzfield.ptr;
     int32_t* zy_side = p16 ? (int32_t*)h->yzfield.ptr : nullptr;
-    // When the dense kernel runs in front, the general pipeline only does work on scenes that are
-    // not dense; there K1 + K2 (rows from the int16 z field) beat the fused kernel's recomputation.
     const bool dense = dense_eligible(h, nz, vb) && ny <= 0x7fffffff;
-    // ... except when the previous build was dense-certified: then the general kernels are expected to
-    // exit on their guard, and the fused kernel makes that one launch fewer (K12 instead of K1 + K2).
-    const bool fused = (!dense || h->expect_dense) && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz);
-    if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
-    // learn from the previous build (if its flags have arrived).  Every setting is exact; they only
-    // move work around: far-field -> do not bother scanning; dense-certified -> the general kernels will
-    // exit on their guard anyway, so do not enqueue the two envelope kernels behind them (and leave the
-    // scans unbounded in case this build is the exception).
+    // Learn from the previous build on this handle, if its flags have arrived (never a wait).  Every
+    // setting below is exact; the policy only moves work around:
+    //   dense-certified  -> the general kernels will exit on their guard: enqueue the cheapest form of them
+    //                       (fused K12 + K3, unbounded scans, no envelope kernels)
+    //   far_y / far_x    -> the marching sweep of that axis would be thrown away: run the envelope kernel
+    //                       alone next time ("envelope mode"); leave that mode again once the result's
+    //                       largest squared distance is back inside the marching kernels' scan range
     if (h->flags_pending && hipEventQuery(h->flags_ev) == hipSuccess) {
         h->flags_pending = false;
         const bool general_ran = !h->prev_dense || h->h_flags[3] != 0;
         h->expect_dense = !general_ran;
         if (general_ran) {
-            h->scan_y = h->h_flags[4] ? kScanExpectFar : kScanExpectNear;
-            h->scan_x = h->h_flags[5] ? kScanExpectFar : kScanExpectNear;
+            const uint32_t max_d = std::max(h->h_flags[0], h->h_flags[1]);
+            const bool near = max_d <= (uint32_t)(kScanExpectNear * kScanExpectNear);
+            h->env_mode_y = h->prev_env_y ? !near : (h->h_flags[4] != 0);
+            h->env_mode_x = h->prev_env_x ? !near : (h->h_flags[5] != 0);
+        } else {
+            h->env_mode_y = h->env_mode_x = false;
         }
     }
-    const bool envelope = p16 && h->envelope_on && !(h->expect_dense && dense_eligible(h, nz, vb));
+    const bool envelope = p16 && h->envelope_on && !(h->expect_dense && dense);
+    const bool env_y = envelope && h->env_mode_y, env_x = envelope && h->env_mode_x;
+    // K12 (fused z+y) only as the guarded stand-by behind a dense build that is expected to be certified
+    // again; everywhere else K1 + K2 (rows from the int16 z field) scan much faster than the fused kernel
+    // recomputes, and only they can hand a far-field y sweep to the envelope kernel.
+    const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
+                       (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
+    if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -444,32 +455,40 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[2], s));
     h->last_fused = fused;
     h->last_plane16 = p16;
-    h->far_y = envelope ? h->d_small + 4 : nullptr;
+    h->far_y = (envelope && !fused) ? h->d_small + 4 : nullptr;
+    h->scan_y = h->scan_x = kScanExpectNear;
     if (!fused)
         if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
                                     (int16_t*)h->zfield.ptr, s)) return rc;
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[3], s));
+    // y sweep: marching (bounded scan, may raise far_y) + guarded envelope, or the envelope kernel alone
     if (fused) {
         if (int rc = launch_sweep_zy_fused(h, d_filled, zy_out, zy_side, nx, ny, nz, s)) return rc;
-    } else {
+    } else if (!env_y) {
         if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s)) return rc;
     }
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[4], s));
-    if (envelope && !fused)      // (the fused kernel recomputes rows instead of scanning a z field: unbounded, no flag)
+    if (envelope && !fused)
         if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
-                                     nx, ny, nz, resolution, vb, h->d_small, h->d_small + 4, s)) return rc;
+                                     nx, ny, nz, resolution, vb, h->d_small, env_y ? h->guard : h->d_small + 4, s)) return rc;
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[5], s));
+    // x sweep: same choice
+    if (!envelope || fused) h->far_y = nullptr;
+    else h->far_y = h->d_small + 4;             // (K3/16 raises far_y + 1 = far_x)
     if (p16) {
-        if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
-                                      0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+        if (!env_x)
+            if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
+                                          0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
     } else {
         if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
                                     resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
     }
     if (h->profiling) HIP_TRY(h, hipEventRecord(ev[6], s));
-    if (envelope)
+    if (envelope && !fused)
         if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
-                                     nx, ny, nz, resolution, vb, h->d_small, h->d_small + 5, s)) return rc;
+                                     nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s)) return rc;
+    h->prev_env_y = env_y && !fused;
+    h->prev_env_x = env_x;
     h->guard = nullptr;
     h->far_y = nullptr;
     if (p16 && h->envelope_on && h->h_flags) {      // asynchronous read-back of the flags for the next build's policy
@@ -779,7 +798,7 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     if (!h || !name) return SDFGPU_ERR_INVALID_ARGUMENT;
     const std::string n(name);
-    if (n == "fused_zy") h->fused_zy = value != 0;
+    if (n == "fused_zy") { h->fused_zy = value != 0; h->fused_always = value == 2; }
     else if (n == "rows_per_chunk_y") h->tune_ty = value;
     else if (n == "rows_per_chunk_x") h->tune_tx = value;
     else if (n == "rows_per_chunk_zy") h->tune_tzy = value;
@@ -790,7 +809,8 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
-    else if (n == "scan_bound") { h->scan_y = h->scan_x = value; h->flags_pending = false; h->expect_dense = false; }
+    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; }
+    else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; }
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);

@@ -23,13 +23,9 @@
 
 namespace sdfgpu {
 
-// Rows the marching kernels scan outward before handing the sweep to the envelope kernel.  Both settings
-// are exact; the context picks one per axis from what the previous build on the handle turned out to be
-// (flags read back asynchronously): after a far-field build the next one barely scans (it will be redone
-// anyway), after a near-field build it scans long enough that mid-sparse scenes never pay for an envelope
-// pass they do not need.
+// Rows the marching kernels scan outward before handing the sweep to the envelope kernel.  Long enough
+// that mid-sparse scenes (p = 0.01: distances up to ~30) never pay for an envelope pass they do not need.
 constexpr int kScanExpectNear = 40;
-constexpr int kScanExpectFar = 4;
 
 struct EnvArgs {
     const int16_t* in16;      // STAGE 2: z field (+-g, 32767 = none); STAGE 3: plane field p16

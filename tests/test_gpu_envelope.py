@@ -35,6 +35,7 @@ CASES = [
 @pytest.mark.parametrize("name,m,vb", CASES, ids=[c[0] for c in CASES])
 def test_far_field_scenes_are_exact(gpu, name, m, vb):
     res = 0.02
+    gpu.set_option("policy_reset", 1)
     sdf, ext = gpu.build(m, res, vb)
     path = gpu.last_path()
     ex, ex_ext, dsq = O.exact_sdf(m, res, vb)
@@ -44,6 +45,12 @@ def test_far_field_scenes_are_exact(gpu, name, m, vb):
     assert ext == ex_ext, (name, ext, ex_ext, path)
     if name.startswith(("two boxes", "single voxel", "thin wall")):
         assert path["far_y"] or path["far_x"]              # these really exercise the envelope kernels
+        gpu.set_option("envelope_mode", 1)                  # ... also as the only sweep of each axis
+        try:
+            sdf3, ext3 = gpu.build(m, res, vb)
+        finally:
+            gpu.set_option("envelope_mode", 0)
+        assert np.array_equal(sdf.view(np.uint32), sdf3.view(np.uint32)) and ext == ext3
     gpu.set_option("envelope", 0)
     try:
         sdf2, ext2 = gpu.build(m, res, vb)                  # unbounded scans
@@ -68,6 +75,10 @@ def test_point_cloud_scene_512(gpu):
     assert np.array_equal(sdf.cpu().numpy(), ex) and st.extrema() == ex_ext
     path = st.ctx.last_path()
     assert not path["dense_certified"] and (path["far_y"] or path["far_x"])
+    for _ in range(3):                                      # the handle is now in envelope mode: still exact
+        sdf, _ = st.frame(torch.from_numpy(pc).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(sdf.cpu().numpy(), ex) and st.extrema() == ex_ext
 
 
 @pytest.mark.parametrize("shape", [(48, 40, 64), (6, 28, 512), (3, 20, 1024)])

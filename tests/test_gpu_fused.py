@@ -14,7 +14,7 @@ def _both(gpu, m, res=1.0, vb=False, window=0):
     shape = m.shape
     try:
         gpu.set_option("dense", 0)
-        gpu.set_option("fused_zy", 1)
+        gpu.set_option("fused_zy", 2)                       # force K12 (the policy would pick K1 + K2 here)
         gpu.set_option("fused_window", window)
         a, ea = gpu.build(m, res, vb)
         assert gpu.last_build_fused_zy()
