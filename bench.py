@@ -213,9 +213,9 @@ def main():
                 else:
                     stage_ms["sweep_z"], stage_ms["sweep_y"] = avg[2], avg[3]
                 stage_ms["sweep_x"] = avg[5]
-                if info["far_y"]:
+                if info["far_y"] or avg[4] > 0.05:
                     stage_ms["envelope_y"] = avg[4]
-                if info["far_x"]:
+                if info["far_x"] or avg[6] > 0.05:
                     stage_ms["envelope_x"] = avg[6]
             else:
                 result["config"]["guarded_general_pipeline_ms"] = round(sum(avg[2:]), 4)

@@ -75,9 +75,13 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
     if constexpr (STAGE == 3) { vy = (int)(t / a.nz); vz = (int)(t - (int64_t)vy * a.nz); }
 
     constexpr int CH = 8;                      // rows fetched per batch: 8 independent loads in flight per lane
+    bool has_filled = false;                   // learned during pass 0: does this line hold any filled voxel?
     if (valid) {                               // (lanes past the last line must not touch another line's stack)
 #pragma unroll 1
     for (int cls = 0; cls < 2; ++cls) {        // 0: sites of "distance to filled" (for free voxels), 1: the other
+        // pass 1 only produces values for filled voxels: a line without any (most lines of a scene with a few
+        // objects in free space) skips it entirely
+        if (cls == 1 && !has_filled) break;
         // ---- forward: build the envelope -------------------------------------------------------------
         int k = -1;
         int vt = 0, At = 0, vs = 0, As = 0;     // top and second entry (copies of scratch[k], scratch[k-1])
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
             for (int u = 0; u < CH; ++u) {
                 const int q = q0 + u;
                 const int s = sv[u];
+                if (q < L) has_filled |= s < 0;
                 // value of this class's function at q: |s| on voxels of the class that looks for the other one,
                 // 0 on voxels that ARE the sought class
                 const int val = cls == 0 ? (s > 0 ? s : 0) : (s < 0 ? -s : 0);
