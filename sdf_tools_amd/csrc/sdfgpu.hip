@@ -377,7 +377,8 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     a.nt_store = h->nt_store;
     const int64_t gx = (ny + a.ty - 1) / a.ty, gy = (out_hi - out_lo + a.tx - 1) / a.tx;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
-    const size_t tile_words = ((size_t)(a.tx + 2 * kBallR) * (a.ty + 2 * kBallR) * (a.nzw + 2) + 3) & ~(size_t)3;
+    const size_t pitch = a.nzw < 32 ? a.nzw + 32 : a.nzw + 2;        // must match k_ball_dense
+    const size_t tile_words = ((size_t)(a.tx + 2 * kBallR) * (a.ty + 2 * kBallR) * pitch + 3) & ~(size_t)3;
     const size_t lds = tile_words * 4 + (size_t)bd * 16 + 64 * 8;
     if (bd == 1024) hipLaunchKernelGGL(k_ball_dense<1024>, dim3((unsigned)gx, (unsigned)gy), dim3(1024), lds, s, a);
     else if (bd == 512) hipLaunchKernelGGL(k_ball_dense<512>, dim3((unsigned)gx, (unsigned)gy), dim3(512), lds, s, a);
@@ -733,6 +734,9 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
     if (out_is_f64)
         hipLaunchKernelGGL(k_gradient<double>, grid, block, 0, s, d_sdf, (double*)d_out_grad, nx, ny, nz, resolution,
                            enable_edge_gradients);
+    else if ((nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_sdf) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out_grad) % 16) == 0)
+        hipLaunchKernelGGL(k_gradient_f32x4, dim3((unsigned)((n / 4 + kBlock - 1) / kBlock)), block, 0, s, d_sdf,
+                           (float*)d_out_grad, nx, ny, nz, resolution, enable_edge_gradients);
     else
         hipLaunchKernelGGL(k_gradient<float>, grid, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution,
                            enable_edge_gradients);

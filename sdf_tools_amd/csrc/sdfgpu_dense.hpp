@@ -111,7 +111,10 @@ template <int BD>      // workgroup size: a larger tile amortises the 2-row halo
 __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nzw = a.nzw, lg = a.log2_nzw;
-    const int rw = nzw + 2;                                   // row pitch in words (edge words replicated)
+    const int rwu = nzw + 2;                                  // words used per staged row (edge words replicated)
+    // row pitch: a wave reads 64/nzw tile rows at once; pitch = nzw (mod 32) puts them on disjoint banks
+    // (pitch nzw + 2 cost a 2-way conflict on every one of the 75 tile reads: 8.8 M conflict cycles at 512^3)
+    const int rw = nzw < 32 ? nzw + 32 : nzw + 2;
     const int hx = a.tx + 2 * kBallR, hy = a.ty + 2 * kBallR;
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);               // [hx][hy][rw]
     uint32_t* planes = tile + ((hx * hy * rw + 3) & ~3);                  // [256][4]: b0, b1, b2, class (16-B aligned)
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
         const int lgp = max(lg + 1, 2);                       // 2^lgp >= nzw + 2 lanes per staged row
         const int lw = t & ((1 << lgp) - 1), lr = t >> lgp;   // word slot, row-in-pass
         const int rpp = BD >> lgp;                            // rows staged per pass
-        if (lw < rw) {
+        if (lw < rwu) {
             for (int jx = 0; jx < hx; ++jx) {
                 const int gx = min(max(x0 + jx - kBallR, 0), a.rows_x - 1);
                 for (int jy = lr; jy < hy; jy += rpp) {
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
                     const uint32_t* row = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
                     uint32_t v;
                     if (lw == 0) v = (row[0] & 1u) ? ~0u : 0u;                     // replicate the row's first voxel
-                    else if (lw == rw - 1) v = (row[nzw - 1] >> 31) ? ~0u : 0u;     // ... and its last voxel
+                    else if (lw == rwu - 1) v = (row[nzw - 1] >> 31) ? ~0u : 0u;    // ... and its last voxel
                     else v = row[lw - 1];
                     tile[(jx * hy + jy) * rw + lw] = v;
                 }

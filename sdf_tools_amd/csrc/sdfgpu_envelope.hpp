@@ -85,10 +85,16 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
         // ---- forward: build the envelope -------------------------------------------------------------
         int k = -1;
         int vt = 0, At = 0, vs = 0, As = 0;     // top and second entry (copies of scratch[k], scratch[k-1])
-        for (int q0 = 0; q0 < L; q0 += CH) {
-            int sv[CH];
+        int sv[CH], sn[CH];                     // current batch and the one in flight behind it
 #pragma unroll
-            for (int u = 0; u < CH; ++u) sv[u] = (q0 + u < L) ? load_signed(q0 + u) : (cls == 0 ? kInf32 : -kInf32);
+        for (int u = 0; u < CH; ++u) sn[u] = (u < L) ? load_signed(u) : (cls == 0 ? kInf32 : -kInf32);
+        for (int q0 = 0; q0 < L; q0 += CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) sv[u] = sn[u];
+            if (q0 + CH < L) {                  // issue the next batch's loads before working on this one
+#pragma unroll
+                for (int u = 0; u < CH; ++u) sn[u] = (q0 + CH + u < L) ? load_signed(q0 + CH + u) : (cls == 0 ? kInf32 : -kInf32);
+            }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int q = q0 + u;
@@ -113,10 +119,16 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
         int j = 0, v0 = 0, A0 = 0, v1 = 0, A1 = 0;
         if (k >= 0) { const int2 e = a.scratch[t]; v0 = e.x; A0 = e.y; }
         if (k >= 1) { const int2 e = a.scratch[nl + t]; v1 = e.x; A1 = e.y; }
-        for (int p0 = 0; p0 < L; p0 += CH) {
-            int16_t rawv[CH];
+        int16_t rawv[CH], rawn[CH];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) rawv[u] = (p0 + u < L) ? a.in16[base + (int64_t)(p0 + u) * ls] : (int16_t)0;
+        for (int u = 0; u < CH; ++u) rawn[u] = (u < L) ? a.in16[base + (int64_t)u * ls] : (int16_t)0;
+        for (int p0 = 0; p0 < L; p0 += CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) rawv[u] = rawn[u];
+            if (p0 + CH < L) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) rawn[u] = (p0 + CH + u < L) ? a.in16[base + (int64_t)(p0 + CH + u) * ls] : (int16_t)0;
+            }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int p = p0 + u;

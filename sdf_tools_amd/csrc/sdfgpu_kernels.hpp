@@ -557,4 +557,71 @@ __global__ __launch_bounds__(kBlock) void k_gradient(const float* __restrict__ f
     g[3 * i + 2] = (OutT)gz;
 }
 
+// fp32 output, 4 consecutive z per lane (nz % 4 == 0, 16-byte aligned): interior groups take 16-byte
+// loads of the six neighbour rows and write 48 contiguous bytes; groups touching a grid face use the
+// per-voxel formulas above.  Same arithmetic as k_gradient<float> (float subtraction then double scale in
+// the interior, double subtraction on the boundary shell), narrowed to float once.
+__device__ __forceinline__ void gradient_one(const float* __restrict__ f, int64_t i, int64_t x, int64_t y, int64_t z,
+                                             int64_t nx, int64_t ny, int64_t nz, double res, int edge, float (&g)[3]) {
+    const int64_t sx = ny * nz, sy = nz;
+    const bool interior = x > 0 && y > 0 && z > 0 && x < nx - 1 && y < ny - 1 && z < nz - 1;
+    double gx, gy, gz;
+    if (interior) {
+        const double inv2 = 1.0 / (2.0 * res);
+        gx = (double)(f[i + sx] - f[i - sx]) * inv2;
+        gy = (double)(f[i + sy] - f[i - sy]) * inv2;
+        gz = (double)(f[i + 1] - f[i - 1]) * inv2;
+    } else if (edge) {
+        const int64_t lx = max((int64_t)0, x - 1), hx = min(nx - 1, x + 1);
+        const int64_t ly = max((int64_t)0, y - 1), hy = min(ny - 1, y + 1);
+        const int64_t lz = max((int64_t)0, z - 1), hz = min(nz - 1, z + 1);
+        const double ix = (double)(hx - lx) * res, iy = (double)(hy - ly) * res, iz = (double)(hz - lz) * res;
+        gx = gy = gz = 0.0;
+        if (ix > 0.0) gx = ((double)f[i + (hx - x) * sx] - (double)f[i - (x - lx) * sx]) * (1.0 / ix);
+        if (iy > 0.0) gy = ((double)f[i + (hy - y) * sy] - (double)f[i - (y - ly) * sy]) * (1.0 / iy);
+        if (iz > 0.0) gz = ((double)f[i + (hz - z)] - (double)f[i - (z - lz)]) * (1.0 / iz);
+    } else {
+        gx = gy = gz = __builtin_nan("");
+    }
+    g[0] = (float)gx; g[1] = (float)gy; g[2] = (float)gz;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restrict__ f, float* __restrict__ g,
+                                                          int64_t nx, int64_t ny, int64_t nz, double res, int edge) {
+    const int64_t n4 = nx * ny * nz / 4;
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= n4) return;
+    const int64_t i = 4 * q;
+    const int64_t z = i % nz, y = (i / nz) % ny, x = i / (nz * ny);
+    const int64_t sx = ny * nz, sy = nz;
+    float o[12];
+    if (x > 0 && x < nx - 1 && y > 0 && y < ny - 1 && z > 0 && z + 4 < nz) {
+        const double inv2 = 1.0 / (2.0 * res);
+        const float4 c = *reinterpret_cast<const float4*>(f + i);
+        const float4 xp = *reinterpret_cast<const float4*>(f + i + sx), xm = *reinterpret_cast<const float4*>(f + i - sx);
+        const float4 yp = *reinterpret_cast<const float4*>(f + i + sy), ym = *reinterpret_cast<const float4*>(f + i - sy);
+        const float zm = f[i - 1], zp = f[i + 4];
+        const float cz[6] = {zm, c.x, c.y, c.z, c.w, zp};
+        const float xpv[4] = {xp.x, xp.y, xp.z, xp.w}, xmv[4] = {xm.x, xm.y, xm.z, xm.w};
+        const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[3 * k + 0] = (float)((double)(xpv[k] - xmv[k]) * inv2);
+            o[3 * k + 1] = (float)((double)(ypv[k] - ymv[k]) * inv2);
+            o[3 * k + 2] = (float)((double)(cz[k + 2] - cz[k]) * inv2);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t[3];
+            gradient_one(f, i + k, x, y, z + k, nx, ny, nz, res, edge, t);
+            o[3 * k] = t[0]; o[3 * k + 1] = t[1]; o[3 * k + 2] = t[2];
+        }
+    }
+    float4* dst = reinterpret_cast<float4*>(g + 3 * i);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+}
+
 }  // namespace sdfgpu
