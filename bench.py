@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=320, help="edge of the cube timed on the CPU oracle")
     ap.add_argument("--tune", type=int, nargs=2, default=None, help="rows per chunk: y x")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-GPU slab builder even at N = 1")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (sdfgpu_set_option)")
     return ap.parse_args()
@@ -166,7 +167,7 @@ def main():
     fence()
     if not use_slab:
         ctx.get_stage_times()           # drop anything recorded so far
-        ctx.set_profiling(True)         # HIP events on the launch stream around every stage
+        ctx.set_profiling(not args.no_profile)   # HIP events on the launch stream around every stage
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -372,6 +372,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     a.tx = best_tx; a.ty = best_ty;
     a.log2_ty = 0;
     while ((1 << a.log2_ty) < a.ty) ++a.log2_ty;
+    a.inv_hy = (65536 + (a.ty + 2 * kBallR) - 1) / (a.ty + 2 * kBallR);
     a.resolution = resolution;
     a.maxdsq = d_maxdsq; a.uncertified = d_uncert;
     a.nt_store = h->nt_store;
@@ -434,11 +435,19 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
     HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
+    // profiling marks: an event is recorded only behind a stage that launched something; a stage that
+    // was not launched shares the previous mark (elapsed 0), so profiling adds as few packets as possible
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (h->profiling) {
-        for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
-        HIP_TRY(h, hipEventRecord(ev[0], s));
-    }
+    bool launched_since_mark = true;
+    auto mark = [&](int k) -> hipError_t {
+        if (!h->profiling) return hipSuccess;
+        if (k > 0 && !launched_since_mark) { ev[k] = ev[k - 1]; return hipSuccess; }
+        hipError_t e = hipEventCreate(&ev[k]);
+        if (e != hipSuccess) return e;
+        launched_since_mark = false;
+        return hipEventRecord(ev[k], s);
+    };
+    HIP_TRY(h, mark(0));
     // Dense path first: exact wherever the nearest opposite voxel is within d^2 <= 8; raises
     // d_small[3] otherwise, in which case (and only then) the general pipeline below does any work.
     h->last_dense = dense;
@@ -446,48 +455,61 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (dense) {
         if (int rc = ensure(h, h->bits, (size_t)n / 8)) return rc;
         if (int rc = launch_pack_bits(h, d_filled, d_cells, stride, off, unknown, n, (uint32_t*)h->bits.ptr, s)) return rc;
-        if (h->profiling) HIP_TRY(h, hipEventRecord(ev[1], s));
+        launched_since_mark = true;
+        HIP_TRY(h, mark(1));
         if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
                                        h->d_small + 3, s)) return rc;
+        launched_since_mark = true;
         h->guard = h->d_small + 3;
-    } else if (h->profiling) {
-        HIP_TRY(h, hipEventRecord(ev[1], s));
+    } else {
+        HIP_TRY(h, mark(1));
     }
-    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[2], s));
+    HIP_TRY(h, mark(2));
     h->last_fused = fused;
     h->last_plane16 = p16;
     h->far_y = (envelope && !fused) ? h->d_small + 4 : nullptr;
     h->scan_y = h->scan_x = kScanExpectNear;
-    if (!fused)
+    if (!fused) {
         if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
                                     (int16_t*)h->zfield.ptr, s)) return rc;
-    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[3], s));
+        launched_since_mark = true;
+    }
+    HIP_TRY(h, mark(3));
     // y sweep: marching (bounded scan, may raise far_y) + guarded envelope, or the envelope kernel alone
     if (fused) {
         if (int rc = launch_sweep_zy_fused(h, d_filled, zy_out, zy_side, nx, ny, nz, s)) return rc;
+        launched_since_mark = true;
     } else if (!env_y) {
         if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s)) return rc;
+        launched_since_mark = true;
     }
-    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[4], s));
-    if (envelope && !fused)
+    HIP_TRY(h, mark(4));
+    if (envelope && !fused) {
         if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
                                      nx, ny, nz, resolution, vb, h->d_small, env_y ? h->guard : h->d_small + 4, s)) return rc;
-    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[5], s));
+        launched_since_mark = true;
+    }
+    HIP_TRY(h, mark(5));
     // x sweep: same choice
     if (!envelope || fused) h->far_y = nullptr;
     else h->far_y = h->d_small + 4;             // (K3/16 raises far_y + 1 = far_x)
     if (p16) {
-        if (!env_x)
+        if (!env_x) {
             if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
                                           0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+            launched_since_mark = true;
+        }
     } else {
         if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
                                     resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+        launched_since_mark = true;
     }
-    if (h->profiling) HIP_TRY(h, hipEventRecord(ev[6], s));
-    if (envelope && !fused)
+    HIP_TRY(h, mark(6));
+    if (envelope && !fused) {
         if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
                                      nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s)) return rc;
+        launched_since_mark = true;
+    }
     h->prev_env_y = env_y && !fused;
     h->prev_env_x = env_x;
     h->guard = nullptr;
@@ -499,7 +521,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->prev_dense = dense;
     }
     if (h->profiling) {
-        HIP_TRY(h, hipEventRecord(ev[7], s));
+        HIP_TRY(h, mark(7));
         for (auto e : ev) h->events.push_back(e);
     }
     h->last_stream = s;
@@ -580,7 +602,8 @@ int sdfgpu_destroy(sdfgpu_handle h) {
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
     if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->flags_ev); }
-    for (auto e : h->events) (void)hipEventDestroy(e);
+    for (size_t i = 0; i < h->events.size(); ++i)
+        if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);
     delete h;
     return SDFGPU_OK;
 }
@@ -794,7 +817,8 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
         }
         ++*out_builds;
     }
-    for (auto e : h->events) (void)hipEventDestroy(e);
+    for (size_t i = 0; i < h->events.size(); ++i)
+        if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);   // marks may be shared
     h->events.clear();
     return SDFGPU_OK;
 }
