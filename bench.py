@@ -197,6 +197,15 @@ def main():
     if not use_slab:
         ms_sum, builds = ctx.get_stage_times()
         ctx.set_profiling(False)
+        if not args.no_profile:
+            # the same K steps again without the per-stage HIP events (they cost a few us per build):
+            # reported next to `value`, never instead of it
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            result["value_without_stage_events"] = round(n_total / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
         mx, mn = ctx.get_extrema()
         result["extrema"] = [mx, mn]
         if builds:
