@@ -8,6 +8,7 @@
 
 #include "sdf_tools/collision_map.hpp"
 #include "sdf_tools/sdf.hpp"
+#include "sdf_tools/tagged_object_collision_map.hpp"
 
 int main(int argc, char** argv) {
     const bool compile_only_smoke = argc > 1 && std::string(argv[1]) == "--no-gpu";
@@ -63,6 +64,28 @@ int main(int argc, char** argv) {
     sdf_tools::SignedDistanceField::SaveToFile(sdf, "/tmp/tutorial.sdf", true);
     const sdf_tools::SignedDistanceField back = sdf_tools::SignedDistanceField::LoadFromFile("/tmp/tutorial.sdf");
     ok = ok && back.GetImmutableRawData() == sdf.GetImmutableRawData() && back.GetFrame() == frame;
+    // tagged-object map (reference tagged_object_collision_map.hpp): object 1 = the same box, object 2 = one far cell,
+    // and one occupied cell without an object id
+    const sdf_tools::TAGGED_OBJECT_COLLISION_CELL free_cell(0.0f, 0u);
+    sdf_tools::TaggedObjectCollisionMapGrid tagged(origin_transform, frame, resolution, 40, 40, 40, free_cell);
+    for (int64_t x = 0; x < 20; x++)
+        for (int64_t y = 0; y < 20; y++)
+            for (int64_t z = 0; z < 20; z++) tagged.SetValue(x, y, z, sdf_tools::TAGGED_OBJECT_COLLISION_CELL(1.0f, 1u));
+    tagged.SetValue(30, 30, 30, sdf_tools::TAGGED_OBJECT_COLLISION_CELL(1.0f, 2u));
+    tagged.SetValue(35, 5, 5, sdf_tools::TAGGED_OBJECT_COLLISION_CELL(1.0f, 0u));
+    const auto only_box = tagged.ExtractSignedDistanceField(oob_value, std::vector<uint32_t>{1u}, false, false);
+    ok = ok && only_box.first.GetImmutableRawData() == sdf.GetImmutableRawData();      // object filter: the box alone
+    const auto all_objects = tagged.ExtractSignedDistanceField(oob_value, std::vector<uint32_t>{}, false, false);
+    const auto combined = tagged.ExtractFreeAndNamedObjectsSignedDistanceField(oob_value, false);
+    ok = ok && combined.first.GetImmutable((int64_t)35, (int64_t)5, (int64_t)5).first == 0.0f            // unnamed filled
+            && combined.first.GetImmutable((int64_t)30, (int64_t)30, (int64_t)30).first == -0.25f        // named, 1 cell
+            && combined.first.GetImmutable((int64_t)34, (int64_t)5, (int64_t)5).first == 0.25f           // free, next to it
+            && combined.first.GetImmutable((int64_t)10, (int64_t)10, (int64_t)10).first == -2.5f
+            && all_objects.first.GetImmutable((int64_t)35, (int64_t)5, (int64_t)5).first == -0.25f;
+    const auto per_object = tagged.MakeAllObjectSDFs(false, false);
+    ok = ok && per_object.size() == 2 && per_object.at(1u).GetImmutableRawData() == sdf.GetImmutableRawData() &&
+         per_object.at(2u).GetImmutable((int64_t)30, (int64_t)30, (int64_t)30).first == -0.25f &&
+         per_object.at(2u).GetImmutable((int64_t)10, (int64_t)10, (int64_t)10).first > 0.0f;
     std::printf(ok ? "tutorial scene OK\n" : "tutorial scene MISMATCH\n");
     return ok ? 0 : 1;
 }

@@ -85,6 +85,22 @@ int sdfgpu_build_cells(sdfgpu_handle h, const void* cells,
                        double resolution, int add_virtual_border,
                        float* out_sdf, double* out_max, double* out_min);
 
+/* Next-row N4: the predicates of TaggedObjectCollisionMapGrid (tagged_object_collision_map.hpp:730-856)
+ * on raw TAGGED_OBJECT_COLLISION_CELL records {float occupancy; uint32 component; uint32 object_id;
+ * uint32 convex_segment}.  A cell is filled iff its occupancy says so AND its object id passes:
+ *   object_mode 0: any object                    (free_sdf_filled_fn :736-749)
+ *   object_mode 1: object_id > 0                 (object_filled_fn :757-775, "named objects")
+ *   object_mode 2: object_id in object_ids[0..n) (ExtractSignedDistanceField(objects_to_use) :817-827;
+ *                                                 n == 0 means any object, like :826)
+ * Classified on the device, then the same build as sdfgpu_build. */
+int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells,
+                              size_t cell_stride, size_t occupancy_offset, size_t object_id_offset,
+                              int object_mode, const uint32_t* object_ids, int64_t n_object_ids,
+                              int unknown_is_filled,
+                              int64_t nx, int64_t ny, int64_t nz,
+                              double resolution, int add_virtual_border,
+                              float* out_sdf, double* out_max, double* out_min);
+
 /* ---------------------------------------------------------------------------
  * Device-pointer variants (benchmark / streaming / multi-GPU callers).
  * All pointers are device pointers on the handle's GPU; `stream` is a

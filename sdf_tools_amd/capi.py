@@ -22,7 +22,7 @@ EXPORTS = [
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
-    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device",
+    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells",
 ]
 
 
@@ -62,6 +62,7 @@ def load_library():
     L.sdfgpu_last_error.restype = ctypes.c_char_p
     L.sdfgpu_build.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_build_cells.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_build_tagged_cells.argtypes = [vp, vp, sz, sz, sz, ci, vp, i64, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
@@ -153,6 +154,22 @@ class SdfGpu:
                                                  int(bool(unknown_is_filled)), nx, ny, nz, float(resolution),
                                                  int(bool(add_virtual_border)), out.ctypes.data,
                                                  ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return out, (float(ext[0]), float(ext[1]))
+
+    def build_tagged_cells(self, cells, shape, object_mode=0, object_ids=(), unknown_is_filled=False, resolution=1.0,
+                           add_virtual_border=False, cell_stride=16, occupancy_offset=0, object_id_offset=8):
+        """cells: raw TAGGED_OBJECT_COLLISION_CELL records; object_mode 0 any / 1 named (id > 0) / 2 id list."""
+        c = np.ascontiguousarray(cells)
+        nx, ny, nz = (int(s) for s in shape)
+        if c.nbytes != nx * ny * nz * cell_stride:
+            raise ValueError("cells buffer size does not match shape * cell_stride")
+        ids = np.ascontiguousarray(np.asarray(object_ids, dtype=np.uint32))
+        out = np.empty((nx, ny, nz), dtype=np.float32)
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_build_tagged_cells(
+            self._h, c.ctypes.data, cell_stride, occupancy_offset, object_id_offset, int(object_mode),
+            ids.ctypes.data if ids.size else None, int(ids.size), int(bool(unknown_is_filled)), nx, ny, nz,
+            float(resolution), int(bool(add_virtual_border)), out.ctypes.data, ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
         return out, (float(ext[0]), float(ext[1]))
 
     # ---- device-pointer API (raw integers: tensor.data_ptr(), stream.cuda_stream) -------------

@@ -42,6 +42,8 @@ struct sdfgpu_context {
     DeviceBuffer plane16;    // int16 [N]   plane field of the 16-bit pipeline
     DeviceBuffer bits;       // uint32 [N/32] packed occupancy of the dense path
     DeviceBuffer env;        // int2 [N] per-line stacks of the envelope kernels (far-field scenes)
+    DeviceBuffer tagmask;    // uint8 [N] mask produced by the tagged-object classify kernel
+    DeviceBuffer tagids;     // uint32 object id filter
     DeviceBuffer stage_in;   // host-API staging: mask / cells
     DeviceBuffer stage_out;  // host-API staging: sdf
     uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] uncertified, [4] far_y, [5] far_x
@@ -598,7 +600,8 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
 int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
-    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->env, &h->stage_in, &h->stage_out})
+    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->env, &h->tagmask, &h->tagids, &h->stage_in,
+                            &h->stage_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
     if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->flags_ev); }
@@ -724,6 +727,44 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
     HIP_TRY(h, hipSetDevice(h->device));
     return launch_ball_dense(h, d_bits, d_out_sdf, rows_x, out_lo, out_hi, ny, nz, resolution, d_maxdsq, d_uncertified,
                              (hipStream_t)stream);
+}
+
+int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                              size_t object_id_offset, int object_mode, const uint32_t* object_ids, int64_t n_object_ids,
+                              int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                              int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!cells || !out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
+    if (cell_stride < 8 || (cell_stride % 4) || (occupancy_offset % 4) || (object_id_offset % 4) ||
+        occupancy_offset + 4 > cell_stride || object_id_offset + 4 > cell_stride)
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell layout must be 4-byte aligned and in range");
+    if (object_mode < 0 || object_mode > 2 || n_object_ids < 0 || n_object_ids > 4096 || (object_mode == 2 && n_object_ids > 0 && !object_ids))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad object filter");
+    if (object_mode == 2 && n_object_ids == 0) object_mode = 0;       // "no objects supplied" = any object (:826)
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t n = nx * ny * nz;
+    if (int rc = ensure(h, h->stage_in, (size_t)n * cell_stride)) return rc;
+    if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
+    if (int rc = ensure(h, h->tagmask, (size_t)n)) return rc;
+    if (int rc = ensure(h, h->tagids, (size_t)std::max<int64_t>(n_object_ids, 1) * 4)) return rc;
+    HIP_TRY(h, hipMemcpy(h->stage_in.ptr, cells, (size_t)n * cell_stride, hipMemcpyHostToDevice));
+    if (n_object_ids > 0) HIP_TRY(h, hipMemcpy(h->tagids.ptr, object_ids, (size_t)n_object_ids * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_classify_tagged, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+                       (const char*)h->stage_in.ptr, (int64_t)cell_stride, (int64_t)occupancy_offset, (int64_t)object_id_offset,
+                       unknown_is_filled, object_mode, (const uint32_t*)h->tagids.ptr, (int)n_object_ids, n,
+                       (uint8_t*)h->tagmask.ptr);
+    HIP_TRY(h, hipGetLastError());
+    int rc = build_device_impl(h, (const uint8_t*)h->tagmask.ptr, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border,
+                               (float*)h->stage_out.ptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(out_sdf, h->stage_out.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    double mx, mn;
+    rc = sdfgpu_get_extrema(h, &mx, &mn);
+    if (rc) return rc;
+    if (out_max) *out_max = mx;
+    if (out_min) *out_min = mn;
+    return SDFGPU_OK;
 }
 
 int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,

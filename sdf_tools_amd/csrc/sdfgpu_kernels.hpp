@@ -501,6 +501,29 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// N4: TaggedObjectCollisionMapGrid predicates (tagged_object_collision_map.hpp:730-856) on raw
+// TAGGED_OBJECT_COLLISION_CELL records -> byte mask.  A cell is filled iff its occupancy says so
+// (occ > 0.5, or == 0.5 when unknown_is_filled) AND its object id passes the filter:
+//   mode 0: any object                      (free_sdf_filled_fn :736-749, and objects_to_use empty :826)
+//   mode 1: object_id > 0                   (object_filled_fn :757-775, "named objects")
+//   mode 2: object_id in the given id list  (object_use_map :817-827)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_classify_tagged(const char* __restrict__ cells, int64_t stride,
+                                                           int64_t occ_off, int64_t obj_off, int unknown_is_filled,
+                                                           int mode, const uint32_t* __restrict__ ids, int n_ids,
+                                                           int64_t n, uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float occ = *reinterpret_cast<const float*>(cells + i * stride + occ_off);
+    const uint32_t obj = *reinterpret_cast<const uint32_t*>(cells + i * stride + obj_off);
+    bool pass = mode == 0 || (mode == 1 && obj > 0u);
+    if (mode == 2)
+        for (int k = 0; k < n_ids; ++k) pass |= ids[k] == obj;
+    const bool occupied = (occ > 0.5f) || (unknown_is_filled && (occ == 0.5f));
+    mask[i] = (pass && occupied) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
 // N2: point cloud -> occupancy (scripts/3d_sdf_demo_rviz.py:22-29): idx = trunc((p - origin) / res),
 // vg[ix, iy, iz] = 1.  Points whose index falls outside the grid are dropped.  fp32 points (the
 // PointCloud2 convention), index arithmetic in fp64 like numpy's.

@@ -92,3 +92,28 @@ def test_file_and_message_round_trip(tmp_path):
     assert np.array_equal(back.GetRawDataNumpy(), sdf.GetRawDataNumpy())
     with pytest.raises(ValueError):
         m.SignedDistanceField.LoadFromFile(os.path.join(str(tmp_path), "missing.sdf"))
+
+
+def test_tagged_object_cells_match_oracle_per_filter():
+    """N4: the three TaggedObjectCollisionMapGrid predicates (tagged_object_collision_map.hpp:736-749,
+    :757-775, :817-827) evaluated on the device from raw 16-byte cells == the oracle on the numpy mask."""
+    from sdf_tools_amd import capi
+    rng = np.random.default_rng(11)
+    shape = (24, 20, 28)
+    cells = np.zeros(shape, dtype=np.dtype([("occupancy", "<f4"), ("component", "<u4"), ("object_id", "<u4"),
+                                            ("convex_segment", "<u4")]))
+    cells["occupancy"] = rng.choice(np.array([0.0, 0.5, 1.0], dtype=np.float32), size=shape, p=[0.6, 0.1, 0.3])
+    cells["object_id"] = rng.integers(0, 5, size=shape)
+    cells["component"] = rng.integers(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
+    g = capi.SdfGpu(0)
+    for unknown in (False, True):
+        occ = (cells["occupancy"] > 0.5) | (unknown & (cells["occupancy"] == 0.5))
+        for mode, ids, mask in ((0, (), occ), (1, (), occ & (cells["object_id"] > 0)),
+                                (2, (2, 4), occ & np.isin(cells["object_id"], (2, 4))), (2, (), occ),
+                                (2, (77,), np.zeros(shape, bool))):
+            for vb in (False, True):
+                got, ext = g.build_tagged_cells(cells, shape, object_mode=mode, object_ids=ids, unknown_is_filled=unknown,
+                                                resolution=0.25, add_virtual_border=vb)
+                want, want_ext, _ = O.exact_sdf(mask.astype(np.uint8), 0.25, vb)
+                np.testing.assert_array_equal(got, want)
+                assert ext == tuple(float(v) for v in want_ext)
