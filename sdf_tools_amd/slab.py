@@ -8,9 +8,11 @@ Dense path (scenes whose every voxel has an opposite-class voxel within squared 
   1. ``pack_bits``   occupancy bytes -> 1 bit / voxel, boundary planes first
   2. halo exchange   2 bit-planes (ny*nz/8 bytes each: 128 KiB at 1024^2) to / from each x neighbour,
                      one grouped isend/irecv per direct xGMI link, overlapped with packing the interior
-  3. ``dense_ball``  bit-parallel ball kernel over the owned planes -> fp32 SDF, integer extrema, and an
-                     "uncertified" flag if some voxel is farther than d^2 = 8 from the other class
-  4. all-reduce(MAX) of {max d^2 free, max d^2 filled, -, uncertified}: 4 integers
+  3. ``dense_ball``  bit-parallel ball kernel -> fp32 SDF, integer extrema, and an "uncertified" flag if some
+                     voxel is farther than d^2 = 8 from the other class; the planes that need no neighbour
+                     data are launched before the exchange completes, the 2 + 2 border planes after it
+  4. all-reduce(MAX) of {max d^2 free, max d^2 filled, -, uncertified}: 4 integers, posted behind the NEXT
+                     build's halo exchange (or by ``finish``) so it never delays that exchange
 
 General path (only if some rank raised the flag; exact for any input)
   1. ``sweep_zy``    mask slab -> signed in-plane d^2 (int32) into an extended buffer with `halo` planes
@@ -95,6 +97,7 @@ class _Slot:
         self.mask = None
         self.pending = False
         self.dense = False
+        self.reduce_deferred = False
 
 
 class SlabSdfBuilder:
@@ -175,19 +178,58 @@ class SlabSdfBuilder:
     def _enqueue_dense(self, mask_slab, slot):
         n, lo, h = self.nxs, self.bh_lo, BALL_HALO
         own = self.bits[lo:lo + n]
-        if self.world > 1 and 2 * h < n:
+        slot.small.zero_()
+        if self.world > 1 and 4 * h < n:
+            # boundary planes first: their exchange over xGMI runs while the interior is packed AND while the
+            # ball kernel works on every plane that needs no neighbour data; only the 2 + 2 border planes
+            # wait for the messages
             self.stages.pack_bits(mask_slab[:h], own[:h])
             self.stages.pack_bits(mask_slab[n - h:], own[n - h:])
             works = self._exchange(self.bits, lo, n, h)
+            self._flush_deferred(exclude=slot)      # previous build's all-reduce goes behind this exchange
             self.stages.pack_bits(mask_slab[h:n - h], own[h:n - h])
+            i_lo = h if self.bh_lo else 0
+            i_hi = n - h if self.bh_hi else n
+            self.stages.dense_ball(self.bits, lo + i_lo, lo + i_hi, self.nz, self.resolution, slot.out[i_lo:i_hi],
+                                   slot.small)
+            for w in works:
+                w.wait()
+            if i_lo:
+                self.stages.dense_ball(self.bits, lo, lo + i_lo, self.nz, self.resolution, slot.out[:i_lo], slot.small)
+            if i_hi < n:
+                self.stages.dense_ball(self.bits, lo + i_hi, lo + n, self.nz, self.resolution, slot.out[i_hi:], slot.small)
         else:
             self.stages.pack_bits(mask_slab, own)
             works = self._exchange(self.bits, lo, n, h)
-        for w in works:
-            w.wait()
-        slot.small.zero_()
-        self.stages.dense_ball(self.bits, lo, lo + n, self.nz, self.resolution, slot.out, slot.small)
-        return self._allreduce_small(slot.small, async_op=True)
+            self._flush_deferred(exclude=slot)
+            for w in works:
+                w.wait()
+            self.stages.dense_ball(self.bits, lo, lo + n, self.nz, self.resolution, slot.out, slot.small)
+        slot.reduce_deferred = True
+
+    def _flush_deferred(self, exclude=None):
+        """Issue the status all-reduce (+ copy to pinned host memory) of every build that still owes one.
+        It is deferred until the NEXT build has posted its halo exchange, so that on the communicator's
+        stream the latency-critical exchange is never queued behind the previous build's all-reduce; every
+        rank defers identically, so the collective order stays the same everywhere."""
+        for slot in self.slots:
+            if slot is exclude or not slot.reduce_deferred:
+                continue
+            slot.reduce_deferred = False
+            work = self._allreduce_small(slot.small, async_op=True)
+            if self.side is not None:
+                # through a side stream: the main stream never waits for the collective or the copy, so the
+                # next build's kernels follow back to back
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.side):
+                    if work is not None:
+                        work.wait()
+                    slot.host.copy_(slot.small, non_blocking=True)
+                    slot.event.record(self.side)
+            else:
+                if work is not None:
+                    work.wait()
+                slot.host.copy_(slot.small)
 
     # -- general path (synchronous; exact for any input) -----------------------------------------------
     def _gather_full(self):
@@ -248,20 +290,9 @@ class SlabSdfBuilder:
         slot.mask = mask_slab
         slot.dense = self.dense
         if self.dense:
-            work = self._enqueue_dense(mask_slab, slot)
-            if self.side is not None:
-                # all-reduced status -> pinned host memory through a side stream: the main stream never
-                # waits for the collective or the copy, so the next build's kernels follow back to back
-                self.side.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(self.side):
-                    if work is not None:
-                        work.wait()
-                    slot.host.copy_(slot.small, non_blocking=True)
-                    slot.event.record(self.side)
-            else:
-                if work is not None:
-                    work.wait()
-                slot.host.copy_(slot.small)
+            self._enqueue_dense(mask_slab, slot)
+            if self.world == 1:
+                self._flush_deferred()           # nothing to order against: read the flags back right away
         slot.pending = True
         return idx
 
@@ -274,6 +305,7 @@ class SlabSdfBuilder:
         assert slot.pending
         need_general = True
         if slot.dense:
+            self._flush_deferred()               # no later build posted it for us (e.g. build(), last step)
             if slot.event is not None:
                 slot.event.synchronize()
             max_f, max_q, _, uncert = (int(v) for v in slot.host.tolist())

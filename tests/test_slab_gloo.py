@@ -190,7 +190,7 @@ def test_two_ranks_one_class_only():
 
 def test_dense_path_two_and_three_ranks():
     """Bit-plane halo exchange + ball kernel contract: certified on every rank, no general build."""
-    for world, shape in ((2, (16, 9, 32)), (3, (20, 6, 64))):
+    for world, shape in ((2, (16, 9, 32)), (2, (24, 9, 32)), (3, (20, 6, 64)), (3, (36, 6, 64))):   # small / split ball launches
         m = synth.bernoulli_mask(shape, 0.5, 4)
         got, ext, (fallbacks, general, dense) = _run(world, shape, 0.5, 4, res=0.25, dense=True, steps=3)
         assert dense and general == 0 and fallbacks == 0
