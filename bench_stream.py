@@ -53,6 +53,17 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     occ = float(st.mask.float().mean())
+    # batched EstimateDistance + gradient queries on the last field (what a planner does with it): 1 M points
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    q = torch.rand((1 << 20, 3), dtype=torch.float64, device="cuda", generator=gen) * (n * st.resolution)
+    st.query(q)
+    q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    q0.record()
+    for _ in range(10):
+        st.query(q)
+    q1.record()
+    torch.cuda.synchronize()
+    breakdown["query_1M_points"] = round(q0.elapsed_time(q1) / 10, 3)
     print(json.dumps({"metric": "streaming frames/sec (points -> occupancy -> SDF%s)" % ("" if args.no_gradient else " + gradient"),
                       "value": round(args.frames / dt, 2), "unit": "Hz", "ms_per_frame": round(dt / args.frames * 1e3, 3),
                       "grid": [n, n, n], "points_per_frame": args.points, "occupancy": occ,

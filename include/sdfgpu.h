@@ -194,6 +194,23 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf,
                            double resolution, int enable_edge_gradients,
                            void* d_out_grad, int out_is_f64, void* stream);
 
+/* Next-row N1, query side: batched SignedDistanceField::EstimateDistance4d (sdf.hpp:947-961: trilinear
+ * inter/extrapolation :836-902 of the 8 surrounding cell centres, each shrunk by half a cell toward the
+ * surface :773-796, neighbour pairs per axis :798-833) and GetGradient4d (:383-430) at n world-frame
+ * points (d_points: n x 3 doubles).  world_to_grid: 12 host doubles, row-major 3x4 = inverse origin
+ * transform (NULL = identity); grid_to_world_rotation: 9 host doubles, row-major (NULL = identity).
+ * Outputs (device, any may be NULL):
+ *   d_distance[n]  the estimate, or oob_value where the point is outside the grid
+ *   d_gradient[3n] world-frame gradient of the cell holding the point; NaN where the reference returns
+ *                  an empty vector (outside, or boundary shell without enable_edge_gradients)
+ *   d_flags[n]     bit0 = point inside the grid, bit1 = gradient available */
+int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf,
+                               int64_t nx, int64_t ny, int64_t nz, double resolution,
+                               const double* world_to_grid, const double* grid_to_world_rotation,
+                               float oob_value, const double* d_points, int64_t n_points,
+                               int enable_edge_gradients,
+                               double* d_distance, double* d_gradient, uint8_t* d_flags, void* stream);
+
 /* Next-row N2: point cloud -> occupancy grid, the convention of scripts/3d_sdf_demo_rviz.py:22-29:
  * index = trunc((p - origin) / resolution) per axis (fp64 arithmetic on fp32 points), mask[ix][iy][iz] = 1
  * with explicit x, y, z axis order; points outside the grid are dropped.  d_points: n_points x 3 floats

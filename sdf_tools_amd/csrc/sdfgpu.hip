@@ -808,6 +808,31 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
     return SDFGPU_OK;
 }
 
+int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                               const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
+                               const double* d_points, int64_t n_points, int enable_edge_gradients, double* d_distance,
+                               double* d_gradient, uint8_t* d_flags, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_sdf || (n_points > 0 && !d_points)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (n_points < 0 || !(resolution > 0.0)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad point count or resolution");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    if (n_points == 0 || (!d_distance && !d_gradient && !d_flags)) return SDFGPU_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    QueryArgs a{};
+    a.sdf = d_sdf; a.points = d_points; a.distance = d_distance; a.gradient = d_gradient; a.flags = d_flags;
+    a.n = n_points; a.nx = nx; a.ny = ny; a.nz = nz;
+    a.res = resolution; a.inv_res = 1.0 / resolution; a.oob = (double)oob_value;
+    static const double ident34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    static const double ident33[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 12; ++i) a.w2g[i] = world_to_grid ? world_to_grid[i] : ident34[i];
+    for (int i = 0; i < 9; ++i) a.rot[i] = grid_to_world_rotation ? grid_to_world_rotation[i] : ident33[i];
+    a.edge = enable_edge_gradients;
+    hipLaunchKernelGGL(k_query_points, dim3((unsigned)((n_points + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
 int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {
     if (!h || !out_host) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!h->have_result || n > h->last_n) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no matching build");

@@ -647,4 +647,113 @@ __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restri
     dst[2] = make_float4(o[8], o[9], o[10], o[11]);
 }
 
+// ---------------------------------------------------------------------------
+// N1 (query side): batched SignedDistanceField::EstimateDistance4d (sdf.hpp:947-961) and GetGradient4d
+// (:383-430) at arbitrary world-frame points, one lane per point.  The estimate is the reference's trilinear
+// inter/extrapolation of the 8 surrounding cell centres (:836-902) whose values are first shrunk by half a
+// cell toward the surface (:773-796); the neighbour pair per axis follows :798-833 (shifted inward at a grid
+// face, collapsed on a singleton axis).  Double arithmetic throughout, like the reference.
+// ---------------------------------------------------------------------------
+struct QueryArgs {
+    const float* sdf;
+    const double* points;      // [n][3]
+    double* distance;          // [n] or null
+    double* gradient;          // [n][3] or null
+    uint8_t* flags;            // [n] or null: bit0 inside, bit1 gradient available
+    int64_t n, nx, ny, nz;
+    double res, inv_res, oob;
+    double w2g[12];            // row-major 3x4 inverse origin transform
+    double rot[9];             // row-major 3x3 rotation grid -> world
+    int edge;
+};
+
+__device__ __forceinline__ void query_axis_pair(int64_t i, int64_t n, double offset, int64_t& lower, int64_t& upper) {
+    lower = i; upper = i;
+    if (offset >= 0.0) {
+        upper = i + 1;
+        if (upper >= n) { upper = i; lower = i - 1; if (lower < 0) lower = i; }
+    } else {
+        lower = i - 1;
+        if (lower < 0) { upper = i + 1; lower = i; if (upper >= n) upper = i; }
+    }
+}
+
+__device__ __forceinline__ double query_bilinear(double l1, double h1, double l2, double h2, double q1, double q2,
+                                                 double ll, double lh, double hl, double hh) {
+    const double multiplier = 1.0 / ((h1 - l1) * (h2 - l2));
+    const double a0 = multiplier * (h1 - q1), a1 = multiplier * (q1 - l1);
+    const double r0 = a0 * ll + a1 * hl, r1 = a0 * lh + a1 * hh;
+    return r0 * (h2 - q2) + r1 * (q2 - l2);
+}
+
+__global__ __launch_bounds__(kBlock) void k_query_points(const QueryArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= a.n) return;
+    const double px = a.points[3 * t], py = a.points[3 * t + 1], pz = a.points[3 * t + 2];
+    const double gx = a.w2g[0] * px + a.w2g[1] * py + a.w2g[2] * pz + a.w2g[3];
+    const double gy = a.w2g[4] * px + a.w2g[5] * py + a.w2g[6] * pz + a.w2g[7];
+    const double gz = a.w2g[8] * px + a.w2g[9] * py + a.w2g[10] * pz + a.w2g[11];
+    const double fx = floor(gx * a.inv_res), fy = floor(gy * a.inv_res), fz = floor(gz * a.inv_res);
+    const bool inside = fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)a.nx && fy < (double)a.ny && fz < (double)a.nz;
+    const double nan = __builtin_nan("");
+    if (!inside) {
+        if (a.distance) a.distance[t] = a.oob;
+        if (a.gradient) { a.gradient[3 * t] = nan; a.gradient[3 * t + 1] = nan; a.gradient[3 * t + 2] = nan; }
+        if (a.flags) a.flags[t] = 0;
+        return;
+    }
+    const int64_t x = (int64_t)fx, y = (int64_t)fy, z = (int64_t)fz;
+    const int64_t sx = a.ny * a.nz, sy = a.nz;
+    const float* f = a.sdf;
+    if (a.distance) {
+        const double half = a.res * 0.5;
+        auto D = [&](int64_t xi, int64_t yi, int64_t zi) -> double {
+            const double d = (double)f[xi * sx + yi * sy + zi];
+            return d >= 0.0 ? d - half : d + half;
+        };
+        int64_t x0, x1, y0, y1, z0, z1;
+        query_axis_pair(x, a.nx, gx - a.res * ((double)x + 0.5), x0, x1);
+        query_axis_pair(y, a.ny, gy - a.res * ((double)y + 0.5), y0, y1);
+        query_axis_pair(z, a.nz, gz - a.res * ((double)z + 0.5), z0, z1);
+        const double lx = a.res * ((double)x0 + 0.5), ly = a.res * ((double)y0 + 0.5), lz = a.res * ((double)z0 + 0.5);
+        const double mz = query_bilinear(lx, lx + a.res, ly, ly + a.res, gx, gy, D(x0, y0, z0), D(x0, y1, z0), D(x1, y0, z0), D(x1, y1, z0));
+        const double pzv = query_bilinear(lx, lx + a.res, ly, ly + a.res, gx, gy, D(x0, y0, z1), D(x0, y1, z1), D(x1, y0, z1), D(x1, y1, z1));
+        const double slope = (pzv - mz) * (1.0 / a.res);
+        a.distance[t] = mz + ((gz - lz) * slope);
+    }
+    bool have_grad = false;
+    if (a.gradient || a.flags) {
+        const int64_t i = x * sx + y * sy + z;
+        double g0 = nan, g1 = nan, g2 = nan;
+        const bool interior = x > 0 && y > 0 && z > 0 && x < a.nx - 1 && y < a.ny - 1 && z < a.nz - 1;
+        if (interior) {
+            const double inv2 = 1.0 / (2.0 * a.res);
+            g0 = (double)(f[i + sx] - f[i - sx]) * inv2;
+            g1 = (double)(f[i + sy] - f[i - sy]) * inv2;
+            g2 = (double)(f[i + 1] - f[i - 1]) * inv2;
+            have_grad = true;
+        } else if (a.edge) {
+            const int64_t lx = max((int64_t)0, x - 1), hx = min(a.nx - 1, x + 1);
+            const int64_t ly = max((int64_t)0, y - 1), hy = min(a.ny - 1, y + 1);
+            const int64_t lz = max((int64_t)0, z - 1), hz = min(a.nz - 1, z + 1);
+            const double ix = (double)(hx - lx) * a.res, iy = (double)(hy - ly) * a.res, iz = (double)(hz - lz) * a.res;
+            g0 = g1 = g2 = 0.0;
+            if (ix > 0.0) g0 = ((double)f[i + (hx - x) * sx] - (double)f[i - (x - lx) * sx]) * (1.0 / ix);
+            if (iy > 0.0) g1 = ((double)f[i + (hy - y) * sy] - (double)f[i - (y - ly) * sy]) * (1.0 / iy);
+            if (iz > 0.0) g2 = ((double)f[i + (hz - z)] - (double)f[i - (z - lz)]) * (1.0 / iz);
+            have_grad = true;
+        }
+        if (a.gradient) {
+            if (have_grad) {
+                a.gradient[3 * t + 0] = a.rot[0] * g0 + a.rot[1] * g1 + a.rot[2] * g2;
+                a.gradient[3 * t + 1] = a.rot[3] * g0 + a.rot[4] * g1 + a.rot[5] * g2;
+                a.gradient[3 * t + 2] = a.rot[6] * g0 + a.rot[7] * g1 + a.rot[8] * g2;
+            } else {
+                a.gradient[3 * t] = nan; a.gradient[3 * t + 1] = nan; a.gradient[3 * t + 2] = nan;
+            }
+        }
+    }
+    if (a.flags) a.flags[t] = (uint8_t)(1 | (have_grad ? 2 : 0));
+}
+
 }  // namespace sdfgpu

@@ -40,5 +40,22 @@ class StreamingSdf:
                                      self.grad_f64, s)
         return self.sdf, self.gradient
 
+    def query(self, points, enable_edge_gradients=True):
+        """Batched EstimateDistance + GetGradient (sdf.hpp:947-961, :383-430) on the current field.
+        points: [n, 3] float64 device tensor in the world frame (grid origin = self.origin, axis-aligned).
+        Returns (distance [n] f64, gradient [n, 3] f64, flags [n] u8: bit0 inside, bit1 gradient available)."""
+        assert points.is_cuda and points.dtype == torch.float64 and points.is_contiguous() and points.shape[-1] == 3
+        n = points.shape[0]
+        dist = torch.empty(n, dtype=torch.float64, device=self.device)
+        grad = torch.empty((n, 3), dtype=torch.float64, device=self.device)
+        flags = torch.empty(n, dtype=torch.uint8, device=self.device)
+        ox, oy, oz = self.origin
+        w2g = (1, 0, 0, -ox, 0, 1, 0, -oy, 0, 0, 1, -oz)
+        self.ctx.query_points_device(self.sdf.data_ptr(), self.shape, self.resolution, points.data_ptr(), n,
+                                     dist.data_ptr(), grad.data_ptr(), flags.data_ptr(), world_to_grid=w2g,
+                                     enable_edge_gradients=enable_edge_gradients,
+                                     stream=torch.cuda.current_stream(self.device).cuda_stream)
+        return dist, grad, flags
+
     def extrema(self):
         return self.ctx.get_extrema()
