@@ -36,7 +36,7 @@ def build_libsdfgpu(force=False, verbose=False):
             os.path.join(INCLUDE, "sdfgpu.h")]
     if not force and not _newer(LIB, srcs):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
            "-I", INCLUDE, srcs[0], "-o", LIB]
     if verbose:
         print(" ".join(cmd))
