@@ -62,6 +62,7 @@ struct sdfgpu_context {
     bool dense_on = true;            // try the bit-parallel dense kernel first when the shape allows
     int pack_variant = 0;
     int ball_block = 0;
+    int ball_variant = 0;         // debugging: bit0 = bounds-checked expansion, bit1 = generic (non-ZINV) expansion
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
@@ -69,6 +70,7 @@ struct sdfgpu_context {
     bool env_mode_y = false, env_mode_x = false;               // policy: run the envelope kernel alone on that axis
     bool prev_env_y = false, prev_env_x = false;
     bool fused_always = false;
+    uint32_t* d_slots = nullptr;     // [kDenseSlots][kSlotWords] extrema / flag slots of the dense kernel (kept zero between launches)
     uint32_t* h_flags = nullptr;     // pinned host copy of d_small, filled asynchronously after every build
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
@@ -380,17 +382,24 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     a.log2_ty = 0;
     while ((1 << a.log2_ty) < a.ty) ++a.log2_ty;
     a.inv_hy = (65536 + (a.ty + 2 * kBallR) - 1) / (a.ty + 2 * kBallR);
-    a.resolution = resolution;
-    a.maxdsq = d_maxdsq; a.uncertified = d_uncert;
+    static const int level_d2[7] = {1, 2, 3, 4, 5, 6, 8};
+    for (int l = 0; l < 7; ++l) a.mag[l] = (float)(std::sqrt((double)level_d2[l]) * resolution);
+    a.mag[7] = 0.0f;
+    a.slots = h->d_slots;
     a.nt_store = h->nt_store;
     const int64_t gx = (ny + a.ty - 1) / a.ty, gy = (out_hi - out_lo + a.tx - 1) / a.tx;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
     const size_t pitch = a.nzw < 32 ? a.nzw + 32 : a.nzw + 2;        // must match k_ball_dense
     const size_t tile_words = ((size_t)(a.tx + 2 * kBallR) * (a.ty + 2 * kBallR) * pitch + 3) & ~(size_t)3;
-    const size_t lds = tile_words * 4 + (size_t)bd * 16 + 64 * 8;
-    if (bd == 1024) hipLaunchKernelGGL(k_ball_dense<1024>, dim3((unsigned)gx, (unsigned)gy), dim3(1024), lds, s, a);
-    else if (bd == 512) hipLaunchKernelGGL(k_ball_dense<512>, dim3((unsigned)gx, (unsigned)gy), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(k_ball_dense<256>, dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, s, a);
+    const size_t lds = tile_words * 4 + (size_t)bd * 16 + 256 * 8 + 64;
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    const bool zinv = nz <= (int64_t)bd * 4 && !(h->ball_variant & 2);   // an expansion pass covers whole z-rows
+    a.checked = h->ball_variant & ~2;
+    if (bd == 1024) hipLaunchKernelGGL((k_ball_dense<1024, true>), grid, dim3(1024), lds, s, a);
+    else if (bd == 512) hipLaunchKernelGGL((k_ball_dense<512, true>), grid, dim3(512), lds, s, a);
+    else if (zinv) hipLaunchKernelGGL((k_ball_dense<256, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((k_ball_dense<256, false>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kDenseSlots), 0, s, h->d_slots, d_maxdsq, d_uncert);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -638,6 +647,12 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
     sdfgpu_context* ctx = new (std::nothrow) sdfgpu_context();
     if (!ctx) return fail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
     ctx->device = device;
+    if (hipMalloc((void**)&ctx->d_slots, (size_t)kDenseSlots * kSlotWords * 4) != hipSuccess ||
+        hipMemset(ctx->d_slots, 0, (size_t)kDenseSlots * kSlotWords * 4) != hipSuccess) {
+        if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+        delete ctx;
+        return SDFGPU_ERR_HIP;
+    }
     if (hipMalloc((void**)&ctx->d_small, 256) != hipSuccess) {
         delete ctx;
         return fail(nullptr, SDFGPU_ERR_HIP, "hipMalloc failed for context scratch");
@@ -658,6 +673,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
                             &h->stage_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
+    if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->flags_ev); }
     for (size_t i = 0; i < h->events.size(); ++i)
         if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);
@@ -960,6 +976,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
+    else if (n == "ball_variant") h->ball_variant = value;
     else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; }
     else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; }
     else if (n == "x16_voxels_per_lane") h->x16_v = value;

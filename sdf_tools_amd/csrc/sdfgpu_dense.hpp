@@ -96,11 +96,42 @@ struct DenseArgs {
     int tx, ty;             // tile rows per workgroup along x / y (powers of two); tx * ty * nzw == block size
     int log2_ty;
     int inv_hy;             // ceil(65536 / (ty + 4)): row / hy = (row * inv_hy) >> 16 for row < 4096
-    double resolution;
-    uint32_t* maxdsq;       // [0] free, [1] filled
-    uint32_t* uncertified;  // set to 1 if some voxel has no opposite-class voxel within d^2 <= 8
+    float mag[8];           // float(sqrt(double(level d^2)) * resolution) per level; [7] = 0 (not found)
+    uint32_t* slots;        // [kDenseSlots][32]: per-slot {max d^2 free, max d^2 filled, uncertified}, see k_fold_slots
+    int checked;            // debugging: take the bounds-checked expansion even for interior tiles
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
 };
+
+// Extrema / flag accumulation.  Every wave ends with up to three atomics.  Sent to ONE address they serialise in
+// the L2 atomic unit at ~12 ns each, and the read-before-atomic filter cannot help the first generation of
+// waves: all ~8000 resident waves still see the initial 0 and fire, a ~200 us backlog that the kernel has to
+// drain before it completes -- and the better the waves are synchronised (i.e. the FASTER the code in front),
+// the more of them fire.  (Measured: removing half of the kernel's VALU work made it 35 us slower; removing the
+// expansion phase altogether made it 45 us slower.)  So a wave updates one of kDenseSlots 128-byte slots chosen
+// by its global wave index (neighbouring waves -> different L2 channels, ~16 waves per slot), and a one-block
+// kernel folds the slots into the caller's {max free, max filled, uncertified} words and clears them again.
+constexpr int kDenseSlots = 512;
+constexpr int kSlotWords = 32;
+
+__global__ __launch_bounds__(kDenseSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
+                                                            uint32_t* __restrict__ uncertified) {
+    uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
+    uint32_t f = p[0], q = p[1], u = p[2];
+    if (f) p[0] = 0;
+    if (q) p[1] = 0;
+    if (u) p[2] = 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        f = max(f, (uint32_t)__shfl_xor((int)f, off));
+        q = max(q, (uint32_t)__shfl_xor((int)q, off));
+        u |= (uint32_t)__shfl_xor((int)u, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (f) atomic_max_if_larger(maxdsq + 0, f);
+        if (q) atomic_max_if_larger(maxdsq + 1, q);
+        if (u) atomic_or_if_new(uncertified, 1u);
+    }
+}
 
 constexpr int kBallR = 2;                                    // |dx|,|dy|,|dz| <= 2
 __host__ __device__ constexpr int ball_level(int d2) {       // d^2 -> level index, -1 = not in the ball
@@ -133,7 +164,9 @@ __device__ __forceinline__ uint32_t ball_level_pass(const uint32_t* c0, int hy, 
     return acc;
 }
 
-template <int BD>      // workgroup size: a larger tile amortises the 2-row halo (4x -> 3x -> 2.25x rows staged)
+// BD = workgroup size: a larger tile amortises the 2-row halo (4x -> 3x -> 2.25x rows staged)
+// ZINV = nz <= BD * 4 (every expansion pass covers whole z-rows)
+template <int BD, bool ZINV>
 __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int nzw = a.nzw, lg = a.log2_nzw;
@@ -142,18 +175,28 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     // (pitch nzw + 2 cost a 2-way conflict on every one of the 75 tile reads: 8.8 M conflict cycles at 512^3)
     const int rw = nzw < 32 ? nzw + 32 : nzw + 2;
     const int hx = a.tx + 2 * kBallR, hy = a.ty + 2 * kBallR;
-    uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);               // [hx][hy][rw]
-    uint32_t* planes = tile + ((hx * hy * rw + 3) & ~3);                  // [256][4]: b0, b1, b2, class (16-B aligned)
-    float2* lut2 = reinterpret_cast<float2*>(planes + BD * 4);            // [64] pair table
+    // LDS: [signed pair table 2 KiB][planes BD x 16 B][tile] -- the two fixed-size parts first, so their
+    // addresses are compile-time constants (folded into the ds_read offsets)
+    float2* lut2 = reinterpret_cast<float2*>(smem_raw);                   // [256] signed pair table
+    float* magl = reinterpret_cast<float*>(smem_raw + 256 * 8);           // [8] level magnitudes (64 B slot)
+    uint32_t* planes = reinterpret_cast<uint32_t*>(smem_raw + 256 * 8 + 64);   // [BD][4]: b0, b1, b2, class
+    uint32_t* tile = planes + BD * 4;                                     // [hx][hy][rw]
     const int t = threadIdx.x;
 
-    // pair table: entry i6 holds the magnitudes of two voxels whose level indices are interleaved in i6
-    if (t < 64) {
-        const int ia = (t & 1) | ((t >> 1) & 2) | ((t >> 2) & 4);
-        const int ib = ((t >> 1) & 1) | ((t >> 2) & 2) | ((t >> 3) & 4);
-        const float fa = ia < 7 ? (float)(sqrt((double)kLevelD2[ia]) * a.resolution) : 0.0f;
-        const float fb = ib < 7 ? (float)(sqrt((double)kLevelD2[ib]) * a.resolution) : 0.0f;
-        lut2[t] = make_float2(fa, fb);
+    // signed pair table: bits {0,1} = class of voxels a,b (1 = filled -> negative); {2,3} = level bit 0;
+    // {4,5} = level bit 1; {6,7} = level bit 2.  Level 7 = "not found" -> +-0 (the general pipeline rewrites
+    // it).  Class in the LOW bits: dense scenes use levels 0..1, i.e. entries 0..15 = 32 distinct banks (with
+    // the class on top the 4 class combinations would fall on the same banks).
+    // The 7 magnitudes float(sqrt(double d^2) * resolution) come from the host as scalar kernel arguments (no
+    // f64 work per workgroup).  Lanes 0..7 pick theirs with a select chain -- indexing the argument array with
+    // a lane-varying index makes the compiler issue VECTOR loads from the kernarg segment, measured +15 us
+    // per launch -- and park them in LDS; the table itself is built behind the first barrier.
+    if (t < 8) {
+        float m = a.mag[0];
+        m = t == 1 ? a.mag[1] : m; m = t == 2 ? a.mag[2] : m; m = t == 3 ? a.mag[3] : m;
+        m = t == 4 ? a.mag[4] : m; m = t == 5 ? a.mag[5] : m; m = t == 6 ? a.mag[6] : m;
+        m = t == 7 ? 0.0f : m;
+        magl[t] = m;
     }
 
     const int x0 = a.out_lo + (int)blockIdx.y * a.tx;         // first tile plane (buffer coordinates)
@@ -233,13 +276,15 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     int mxF = 0, mxQ = 0;
     {
         uint32_t prevc = 0;
-#pragma unroll
-        for (int l = 0; l < 7; ++l) {
-            const uint32_t first = acc[l] & ~prevc;
-            if (first & ~O) mxF = kLevelD2[l];
-            if (first & O) mxQ = kLevelD2[l];
-            prevc = acc[l];
-        }
+        static_for<7>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            {
+                const uint32_t first = acc[l] & ~prevc;
+                if (first & ~O) mxF = kLevelD2[l];
+                if (first & O) mxQ = kLevelD2[l];
+                prevc = acc[l];
+            }
+        });
     }
     const bool row_in_grid = (x0 + tx_ < a.out_hi) && (y0 + ty_ < a.ny);
     const bool uncert = row_in_grid && (~acc[6] != 0u);
@@ -255,39 +300,72 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
         pl.w = O;
         reinterpret_cast<uint4*>(planes)[t] = pl;
     }
+    if (t < 256) {
+        const float lut_a = magl[((t >> 2) & 1) | ((t >> 3) & 2) | ((t >> 4) & 4)];
+        const float lut_b = magl[((t >> 3) & 1) | ((t >> 4) & 2) | ((t >> 5) & 4)];
+        lut2[t] = make_float2(__uint_as_float(__float_as_uint(lut_a) | ((uint32_t)(t & 1) << 31)),
+                              __uint_as_float(__float_as_uint(lut_b) | ((uint32_t)(t & 2) << 30)));
+    }
     __syncthreads();
 
     // expansion: a lane finishes 4 consecutive voxels per pass -> every store instruction writes one
     // fully contiguous 1 KiB segment per wave (8 voxels per lane halves the instruction count but
-    // makes each store half-strided: measured 20 % slower)
+    // makes each store half-strided: measured 20 % slower).  Two signed pair-table lookups give the 4
+    // finished floats; with ZINV (a pass of BD*4 voxels is a whole number of z-rows, nz <= BD*4) the lane's
+    // z, its bit position and the plane address are loop-invariant, and the destination is a wave-uniform
+    // tile pointer plus a 32-bit lane offset.
     const int nz = nzw << 5;
     const int lgz = lg + 5;
+    char* const tile_out = reinterpret_cast<char*>(a.out + ((int64_t)(x0 - a.out_lo) * a.ny + y0) * nz);
+    const uint4* planes4 = reinterpret_cast<const uint4*>(planes);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    auto expand = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;        // whole tile inside the output range: no bounds checks
+        const int v0 = t << 2;
+        const int zi = v0 & (nz - 1), r0 = v0 >> lgz;         // ZINV: this lane's z and first row
+        const int rs = (BD * 4) >> lgz;                       //       rows per pass
+        const uint4* pbase = planes4 + (r0 << lg) + (zi >> 5);
+        // ZINV: row r0 + j*rs splits into (tx, ty) without carries between the lane part r0 (< rs) and the
+        // wave-uniform part j*rs, so the byte offset is a per-lane constant plus a scalar per pass
+        const int ty0 = r0 & (a.ty - 1), tx0 = r0 >> a.log2_ty;
+        const uint32_t lane_off = (uint32_t)(((((int)__umul24(tx0, a.ny) + ty0) << lgz) + zi) << 2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {                             // fully unrolled: 8 independent LDS->LUT->store chains
-        const int v = j * (BD * 4) + (t << 2);                // voxel index inside the tile (row-major)
-        const int rr = v >> lgz, z = v & (nz - 1);
-        const int tyy = rr & (a.ty - 1), txx = rr >> a.log2_ty;
-        const int gx = x0 + txx, gy = y0 + tyy;
-        const uint4 pl = reinterpret_cast<const uint4*>(planes)[(rr << lg) + (z >> 5)];
-        const int sh = z & 31;
-        const uint32_t n0 = (pl.x >> sh) & 0xFu, n1 = (pl.y >> sh) & 0xFu, n2 = (pl.z >> sh) & 0xFu;
-        const uint32_t ns = (pl.w >> sh) << 28;              // class bits of the 4 voxels at bits 28..31
-        const float2 fa = lut2[(n0 & 3u) | ((n1 & 3u) << 2) | ((n2 & 3u) << 4)];
-        const float2 fb = lut2[(n0 >> 2) | ((n1 >> 2) << 2) | ((n2 >> 2) << 4)];
-        float4 o;
-        o.x = __uint_as_float(__float_as_uint(fa.x) | ((ns << 3) & 0x80000000u));
-        o.y = __uint_as_float(__float_as_uint(fa.y) | ((ns << 2) & 0x80000000u));
-        o.z = __uint_as_float(__float_as_uint(fb.x) | ((ns << 1) & 0x80000000u));
-        o.w = __uint_as_float(__float_as_uint(fb.y) | (ns & 0x80000000u));
-        if (gx < a.out_hi && gy < a.ny) {
-            float* dst = a.out + ((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z;
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            f4v ov;
-            ov.x = o.x; ov.y = o.y; ov.z = o.z; ov.w = o.w;
-            if (a.nt_store) __builtin_nontemporal_store(ov, reinterpret_cast<f4v*>(dst));
-            else *reinterpret_cast<f4v*>(dst) = ov;
+        for (int j = 0; j < 8; ++j) {                         // fully unrolled: 8 independent LDS->LUT->store chains
+            int rr, z;
+            uint4 pl;
+            if constexpr (ZINV) {
+                rr = r0 + j * rs; z = zi;
+                pl = pbase[j * (BD / 8)];                     // (rs << lg) == BD / 8 plane entries per pass
+            } else {
+                const int v = j * (BD * 4) + v0;              // voxel index inside the tile (row-major)
+                rr = v >> lgz; z = v & (nz - 1);
+                pl = planes4[(rr << lg) + (z >> 5)];
+            }
+            const uint32_t sh = (uint32_t)z & 31u;
+            const uint32_t ia = __builtin_amdgcn_ubfe(pl.w, sh, 2u) | (__builtin_amdgcn_ubfe(pl.x, sh, 2u) << 2) |
+                                (__builtin_amdgcn_ubfe(pl.y, sh, 2u) << 4) | (__builtin_amdgcn_ubfe(pl.z, sh, 2u) << 6);
+            const uint32_t ib = __builtin_amdgcn_ubfe(pl.w, sh + 2u, 2u) | (__builtin_amdgcn_ubfe(pl.x, sh + 2u, 2u) << 2) |
+                                (__builtin_amdgcn_ubfe(pl.y, sh + 2u, 2u) << 4) | (__builtin_amdgcn_ubfe(pl.z, sh + 2u, 2u) << 6);
+            const float2 fa = lut2[ia], fb = lut2[ib];
+            const int tyy = rr & (a.ty - 1), txx = rr >> a.log2_ty;
+            if (FULL || (x0 + txx < a.out_hi && y0 + tyy < a.ny)) {
+                f4v ov;
+                ov.x = fa.x; ov.y = fa.y; ov.z = fb.x; ov.w = fb.y;
+                f4v* dst;
+                if constexpr (ZINV) {
+                    const int rj = j * rs;                                                    // wave-uniform
+                    const int64_t uoff = (((int64_t)(rj >> a.log2_ty) * a.ny + (rj & (a.ty - 1))) << lgz) << 2;
+                    dst = reinterpret_cast<f4v*>(tile_out + uoff + lane_off);
+                } else {
+                    dst = reinterpret_cast<f4v*>(tile_out + (uint32_t)((((int)__umul24(txx, a.ny) + tyy) << lgz) + z) * 4u);
+                }
+                if (a.nt_store) __builtin_nontemporal_store(ov, dst);
+                else *dst = ov;
+            }
         }
-    }
+    };
+    if (!(a.checked & 1) && (x0 + a.tx <= a.out_hi) && (y0 + a.ty <= a.ny)) expand(std::true_type{});
+    else expand(std::false_type{});
 
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -296,9 +374,11 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     }
     const bool any_uncert = __any(uncert);
     if ((t & 63) == 0) {
-        if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
-        if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
-        if (any_uncert) atomic_or_if_new(a.uncertified, 1u);
+        const uint32_t wave = ((uint32_t)blockIdx.y * gridDim.x + blockIdx.x) * (BD / 64) + ((uint32_t)t >> 6);
+        uint32_t* p = a.slots + (size_t)(wave & (kDenseSlots - 1)) * kSlotWords;
+        if (mxF) atomic_max_if_larger(p + 0, (uint32_t)mxF);
+        if (mxQ) atomic_max_if_larger(p + 1, (uint32_t)mxQ);
+        if (any_uncert) atomic_or_if_new(p + 2, 1u);
     }
 }
 
