@@ -70,7 +70,7 @@ struct sdfgpu_context {
     bool env_mode_y = false, env_mode_x = false;               // policy: run the envelope kernel alone on that axis
     bool prev_env_y = false, prev_env_x = false;
     bool fused_always = false;
-    uint32_t* d_slots = nullptr;     // [kDenseSlots][kSlotWords] extrema / flag slots of the dense kernel (kept zero between launches)
+    uint32_t* d_slots = nullptr;     // [kSlots][kSlotWords] extrema / flag slots of the dense kernel (kept zero between launches)
     uint32_t* h_flags = nullptr;     // pinned host copy of d_small, filled asynchronously after every build
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
@@ -267,7 +267,8 @@ int launch_sweep_x16(sdfgpu_handle h, const int16_t* d_in16, const int32_t* d_si
     a.resolution = resolution;
     a.lo_truncated = lo_trunc; a.hi_truncated = hi_trunc;
     a.x_global = x_global; a.nx_global = nx_global; a.ny = ny; a.nz = nz;
-    a.maxdsq = d_maxdsq; a.status = d_status;
+    (void)d_maxdsq;                             // maxima go to the slot array; the caller folds them (fold_slots)
+    a.maxdsq = h->d_slots; a.status = d_status;
     a.guard = h->guard;
     if (h->far_y) { a.max_scan = h->scan_x; a.far_flag = h->far_y + 1; }
     const int span = a.out_hi - a.out_lo;
@@ -304,7 +305,8 @@ int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t h
     a.resolution = resolution;
     a.lo_truncated = lo_trunc; a.hi_truncated = hi_trunc;
     a.x_global = x_global; a.nx_global = nx_global; a.ny = ny; a.nz = nz;
-    a.maxdsq = d_maxdsq; a.status = d_status;
+    (void)d_maxdsq;                             // maxima go to the slot array; the caller folds them (fold_slots)
+    a.maxdsq = h->d_slots; a.status = d_status;
     a.guard = h->guard;
     return vb ? launch_march<3, true>(h, a, vec4, s) : launch_march<3, false>(h, a, vec4, s);
 }
@@ -319,7 +321,8 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
     if (stage == 2) { a.nlines = nx * nz; a.cpl = nz; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
     else { a.nlines = ny * nz; a.cpl = a.nlines; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
     a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
-    a.maxdsq = d_maxdsq; a.guard = guard;
+    (void)d_maxdsq;
+    a.maxdsq = h->d_slots; a.guard = guard;
     dim3 grid((unsigned)((a.nlines + kBlock - 1) / kBlock)), block(kBlock);
     if (stage == 2) hipLaunchKernelGGL(k_envelope<2>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(k_envelope<3>, grid, block, 0, s, a);
@@ -360,6 +363,13 @@ int launch_pack_bits(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells
     return SDFGPU_OK;
 }
 
+// Folds the per-slot maxima of the final-stage kernels launched so far into d_maxdsq[0..1] and clears the slots.
+int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_maxdsq);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
 int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int64_t rows_x, int64_t out_lo, int64_t out_hi,
                       int64_t ny, int64_t nz, double resolution, uint32_t* d_maxdsq, uint32_t* d_uncert, hipStream_t s) {
     DenseArgs a{};
@@ -385,7 +395,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     static const int level_d2[7] = {1, 2, 3, 4, 5, 6, 8};
     for (int l = 0; l < 7; ++l) a.mag[l] = (float)(std::sqrt((double)level_d2[l]) * resolution);
     a.mag[7] = 0.0f;
-    a.slots = h->d_slots;
+    a.slots = h->d_slots; a.uncertified = d_uncert;
     a.nt_store = h->nt_store;
     const int64_t gx = (ny + a.ty - 1) / a.ty, gy = (out_hi - out_lo + a.tx - 1) / a.tx;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
@@ -399,7 +409,6 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     else if (bd == 512) hipLaunchKernelGGL((k_ball_dense<512, true>), grid, dim3(512), lds, s, a);
     else if (zinv) hipLaunchKernelGGL((k_ball_dense<256, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((k_ball_dense<256, false>), grid, dim3(256), lds, s, a);
-    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kDenseSlots), 0, s, h->d_slots, d_maxdsq, d_uncert);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -526,6 +535,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                      nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s)) return rc;
         launched_since_mark = true;
     }
+    if (int rc = fold_slots(h, h->d_small, s)) return rc;
     h->prev_env_y = env_y && !fused;
     h->prev_env_x = env_x;
     h->guard = nullptr;
@@ -647,8 +657,8 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
     sdfgpu_context* ctx = new (std::nothrow) sdfgpu_context();
     if (!ctx) return fail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
     ctx->device = device;
-    if (hipMalloc((void**)&ctx->d_slots, (size_t)kDenseSlots * kSlotWords * 4) != hipSuccess ||
-        hipMemset(ctx->d_slots, 0, (size_t)kDenseSlots * kSlotWords * 4) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->d_slots, (size_t)kSlots * kSlotWords * 4) != hipSuccess ||
+        hipMemset(ctx->d_slots, 0, (size_t)kSlots * kSlotWords * 4) != hipSuccess) {
         if (ctx->d_slots) (void)hipFree(ctx->d_slots);
         delete ctx;
         return SDFGPU_ERR_HIP;
@@ -772,9 +782,10 @@ int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t h
     if (int rc = check_dims(h, halo_lo + nxs + halo_hi, ny, nz)) return rc;
     if (int rc = check_dims(h, nx_global, ny, nz)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    return launch_sweep_x(h, d_plane_dsq, d_out_sdf, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated,
-                          x_global, nx_global, resolution, add_virtual_border, d_maxdsq, d_status,
-                          (hipStream_t)stream);
+    if (int rc = launch_sweep_x(h, d_plane_dsq, d_out_sdf, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated,
+                                x_global, nx_global, resolution, add_virtual_border, d_maxdsq, d_status,
+                                (hipStream_t)stream)) return rc;
+    return fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
 
 int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_rows, int64_t nz, uint32_t* d_bits,
@@ -795,8 +806,9 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
     if (int rc = check_dims(h, rows_x, ny, nz)) return rc;
     if (!dense_eligible(h, nz, 0)) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense kernel needs nz = 32 * 2^k <= 2048");
     HIP_TRY(h, hipSetDevice(h->device));
-    return launch_ball_dense(h, d_bits, d_out_sdf, rows_x, out_lo, out_hi, ny, nz, resolution, d_maxdsq, d_uncertified,
-                             (hipStream_t)stream);
+    if (int rc = launch_ball_dense(h, d_bits, d_out_sdf, rows_x, out_lo, out_hi, ny, nz, resolution, d_maxdsq,
+                                   d_uncertified, (hipStream_t)stream)) return rc;
+    return fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
 
 int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,

@@ -97,41 +97,11 @@ struct DenseArgs {
     int log2_ty;
     int inv_hy;             // ceil(65536 / (ty + 4)): row / hy = (row * inv_hy) >> 16 for row < 4096
     float mag[8];           // float(sqrt(double(level d^2)) * resolution) per level; [7] = 0 (not found)
-    uint32_t* slots;        // [kDenseSlots][32]: per-slot {max d^2 free, max d^2 filled, uncertified}, see k_fold_slots
+    uint32_t* slots;        // [kSlots][kSlotWords]: per-slot {max d^2 free, max d^2 filled}, see slot_max2 / k_fold_slots
+    uint32_t* uncertified;  // set to 1 if some voxel has no opposite-class voxel within d^2 <= 8
     int checked;            // debugging: take the bounds-checked expansion even for interior tiles
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
 };
-
-// Extrema / flag accumulation.  Every wave ends with up to three atomics.  Sent to ONE address they serialise in
-// the L2 atomic unit at ~12 ns each, and the read-before-atomic filter cannot help the first generation of
-// waves: all ~8000 resident waves still see the initial 0 and fire, a ~200 us backlog that the kernel has to
-// drain before it completes -- and the better the waves are synchronised (i.e. the FASTER the code in front),
-// the more of them fire.  (Measured: removing half of the kernel's VALU work made it 35 us slower; removing the
-// expansion phase altogether made it 45 us slower.)  So a wave updates one of kDenseSlots 128-byte slots chosen
-// by its global wave index (neighbouring waves -> different L2 channels, ~16 waves per slot), and a one-block
-// kernel folds the slots into the caller's {max free, max filled, uncertified} words and clears them again.
-constexpr int kDenseSlots = 512;
-constexpr int kSlotWords = 32;
-
-__global__ __launch_bounds__(kDenseSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
-                                                            uint32_t* __restrict__ uncertified) {
-    uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
-    uint32_t f = p[0], q = p[1], u = p[2];
-    if (f) p[0] = 0;
-    if (q) p[1] = 0;
-    if (u) p[2] = 0;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        f = max(f, (uint32_t)__shfl_xor((int)f, off));
-        q = max(q, (uint32_t)__shfl_xor((int)q, off));
-        u |= (uint32_t)__shfl_xor((int)u, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (f) atomic_max_if_larger(maxdsq + 0, f);
-        if (q) atomic_max_if_larger(maxdsq + 1, q);
-        if (u) atomic_or_if_new(uncertified, 1u);
-    }
-}
 
 constexpr int kBallR = 2;                                    // |dx|,|dy|,|dz| <= 2
 __host__ __device__ constexpr int ball_level(int d2) {       // d^2 -> level index, -1 = not in the ball
@@ -374,11 +344,8 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     }
     const bool any_uncert = __any(uncert);
     if ((t & 63) == 0) {
-        const uint32_t wave = ((uint32_t)blockIdx.y * gridDim.x + blockIdx.x) * (BD / 64) + ((uint32_t)t >> 6);
-        uint32_t* p = a.slots + (size_t)(wave & (kDenseSlots - 1)) * kSlotWords;
-        if (mxF) atomic_max_if_larger(p + 0, (uint32_t)mxF);
-        if (mxQ) atomic_max_if_larger(p + 1, (uint32_t)mxQ);
-        if (any_uncert) atomic_or_if_new(p + 2, 1u);
+        slot_max2(a.slots, ((uint32_t)blockIdx.y * gridDim.x + blockIdx.x) * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
+        if (any_uncert) raise_flag(a.uncertified);
     }
 }
 

@@ -170,10 +170,8 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
             mxF = max(mxF, __shfl_xor(mxF, off));
             mxQ = max(mxQ, __shfl_xor(mxQ, off));
         }
-        if ((threadIdx.x & 63) == 0) {
-            if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
-            if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
-        }
+        if ((threadIdx.x & 63) == 0)
+            slot_max2(a.maxdsq, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), mxF, mxQ);      // a.maxdsq = slot array
     }
 }
 

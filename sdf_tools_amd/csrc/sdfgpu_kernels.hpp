@@ -49,6 +49,44 @@ __device__ __forceinline__ void atomic_max_if_larger(uint32_t* p, uint32_t v) {
 __device__ __forceinline__ void atomic_or_if_new(uint32_t* p, uint32_t bits) {
     if (bits & ~__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(p, bits);
 }
+// A flag whose only non-zero value is 1 needs no read-modify-write at all: every writer stores the same word.
+__device__ __forceinline__ void raise_flag(uint32_t* p) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        __hip_atomic_store(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Extrema accumulation.  Every wave of a final-stage kernel ends with up to two atomic max operations.  Sent to
+// ONE address they serialise in the L2 atomic unit at ~12 ns each, and the read-before-atomic filter cannot help
+// the first generation of waves: all ~8000 resident waves still see the initial 0 and fire -- a backlog of up to
+// ~200 us that the kernel has to drain before it completes, and the better the waves are synchronised (i.e. the
+// FASTER the code in front of the atomics), the more of them fire.  (Measured on the dense kernel: removing half
+// of its VALU work made it 35 us slower; removing its store phase altogether made it 45 us slower.)  So a wave
+// updates one of kSlots 128-byte slots chosen by its global wave index (neighbouring waves -> different L2
+// channels, ~16 first-generation waves per slot), and the one-block k_fold_slots launched at the end of every
+// ABI call folds the slots into the caller's {max free, max filled} words and clears them again.
+constexpr int kSlots = 512;
+constexpr int kSlotWords = 32;
+__device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mxF, int mxQ) {
+    uint32_t* p = slots + (size_t)(wave & (kSlots - 1)) * kSlotWords;
+    if (mxF) atomic_max_if_larger(p + 0, (uint32_t)mxF);
+    if (mxQ) atomic_max_if_larger(p + 1, (uint32_t)mxQ);
+}
+
+__global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq) {
+    uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
+    uint32_t f = p[0], q = p[1];
+    if (f) p[0] = 0;
+    if (q) p[1] = 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        f = max(f, (uint32_t)__shfl_xor((int)f, off));
+        q = max(q, (uint32_t)__shfl_xor((int)q, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (f) atomic_max_if_larger(maxdsq + 0, f);
+        if (q) atomic_max_if_larger(maxdsq + 1, q);
+    }
+}
 
 constexpr int kInf16 = 32767;        // "no opposite voxel in this z row"
 constexpr int kInf32 = 1 << 30;      // "no opposite voxel" for squared distances
@@ -482,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
     }
 
     if (a.far_flag) {
-        if (__any(far) && (threadIdx.x & 63) == 0) atomic_or_if_new(a.far_flag, 1u);
+        if (__any(far) && (threadIdx.x & 63) == 0) raise_flag(a.far_flag);
     }
     if constexpr (STAGE == 3) {
         // wave-level max, one atomic per wave per class
@@ -493,9 +531,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
         }
         const bool any_unres = __any(unresolved);
         if ((threadIdx.x & 63) == 0) {
-            if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
-            if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
-            if (any_unres && a.status) atomic_or_if_new(a.status, 1u);
+            slot_max2(a.maxdsq, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), mxF, mxQ);   // a.maxdsq = slot array
+            if (any_unres && a.status) raise_flag(a.status);
         }
     }
 }

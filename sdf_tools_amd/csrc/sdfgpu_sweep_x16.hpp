@@ -343,10 +343,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
     const bool any_unres = __any(unresolved);
     const bool any_far = __any(far);
     if ((threadIdx.x & 63) == 0) {
-        if (any_far && a.far_flag) atomic_or_if_new(a.far_flag, 1u);
-        if (mxF) atomic_max_if_larger(a.maxdsq + 0, (uint32_t)mxF);
-        if (mxQ) atomic_max_if_larger(a.maxdsq + 1, (uint32_t)mxQ);
-        if (any_unres && a.status) atomic_or_if_new(a.status, 1u);
+        if (any_far && a.far_flag) raise_flag(a.far_flag);
+        slot_max2(a.maxdsq, blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6), mxF, mxQ);      // a.maxdsq = slot array
+        if (any_unres && a.status) raise_flag(a.status);
     }
 }
 
