@@ -232,7 +232,9 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
  * sweep, [5] K3 x sweep, [6] KE3 envelope x sweep (a stage that is not launched, or exits on its guard
  * flag, shows ~0).  sdfgpu_get_stage_times
  * synchronises, adds the elapsed times since the last call into out_ms_sum[7] (milliseconds),
- * returns the number of builds they cover in *out_builds and resets the accumulators. */
+ * returns the number of builds they cover in *out_builds and resets the accumulators.
+ * enable = 2 brackets only the dominant kernel of the dense path (stage [1]; the other stages then read 0):
+ * two events per build instead of five, for timed benchmark loops. */
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
 

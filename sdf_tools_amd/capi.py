@@ -267,7 +267,8 @@ class SdfGpu:
         return self.last_build_info()["fused_zy"]
 
     def set_profiling(self, enable=True):
-        self._check(self._lib.sdfgpu_set_profiling(self._h, int(bool(enable))))
+        """False/0 off, True/1 every stage, 2 only the dense ball kernel (two events per build)."""
+        self._check(self._lib.sdfgpu_set_profiling(self._h, int(enable)))
 
     def get_stage_times(self):
         """(ms_sum[7] for pack / dense ball / z / y-or-zy / envelope y / x / envelope x, builds) since the

@@ -81,7 +81,8 @@ struct sdfgpu_context {
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     bool last_plane16 = false;
-    bool profiling = false;
+    int profiling = 0;            // 0 off, 1 an event behind every stage, 2 events around the dense ball kernel only
+    std::vector<hipEvent_t> event_pool;   // recycled profiling events
     std::vector<hipEvent_t> events;   // 8 per profiled build: start, after pack, ball, K1, K2/K12, KE2, K3, KE3
 };
 
@@ -466,9 +467,23 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     bool launched_since_mark = true;
     auto mark = [&](int k) -> hipError_t {
         if (!h->profiling) return hipSuccess;
-        if (k > 0 && !launched_since_mark) { ev[k] = ev[k - 1]; return hipSuccess; }
-        hipError_t e = hipEventCreate(&ev[k]);
-        if (e != hipSuccess) return e;
+        if (h->profiling == 2 && dense) {
+            // only the dominant kernel of the dense path is bracketed: stage 1 = [ev1, ev2], every other stage
+            // shares a mark with its neighbour (elapsed 0)
+            if (k == 0) return hipSuccess;
+            if (k > 2) { ev[k] = ev[k - 1]; return hipSuccess; }
+        } else if (k > 0 && !launched_since_mark) {
+            ev[k] = ev[k - 1];
+            return hipSuccess;
+        }
+        if (h->event_pool.empty()) {
+            hipError_t e = hipEventCreate(&ev[k]);
+            if (e != hipSuccess) return e;
+        } else {
+            ev[k] = h->event_pool.back();
+            h->event_pool.pop_back();
+        }
+        if (k == 1 && ev[0] == nullptr) ev[0] = ev[1];
         launched_since_mark = false;
         return hipEventRecord(ev[k], s);
     };
@@ -687,6 +702,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
     if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->flags_ev); }
     for (size_t i = 0; i < h->events.size(); ++i)
         if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     delete h;
     return SDFGPU_OK;
 }
@@ -949,7 +965,7 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n) {
 
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
-    h->profiling = enable != 0;
+    h->profiling = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return SDFGPU_OK;
 }
 
@@ -969,7 +985,7 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
         ++*out_builds;
     }
     for (size_t i = 0; i < h->events.size(); ++i)
-        if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);   // marks may be shared
+        if (i % 8 == 0 || h->events[i] != h->events[i - 1]) h->event_pool.push_back(h->events[i]);   // marks may be shared
     h->events.clear();
     return SDFGPU_OK;
 }
