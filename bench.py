@@ -92,6 +92,7 @@ def load_traffic():
 
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL between processes here
     import torch
     import torch.distributed as dist
 
@@ -165,6 +166,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if use_slab and not args.no_profile:
+        builder.time_ball_kernel(4)     # events around the dominant kernel of every 4th build, on its launch stream
     if not use_slab:
         ctx.get_stage_times()           # drop anything recorded so far
         # HIP events on the launch stream inside the timed region: around the dominant kernel only when the
@@ -267,6 +270,22 @@ def main():
                              "frac": round(n_total * B_ALG_TOTAL / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             }
     else:
+        launches, ms_total, vox = builder.pop_ball_timings()
+        if launches and rank == 0:
+            avg_ms = ms_total / launches
+            achieved = vox * B_ALG["dense_ball"] / (avg_ms * 1e-3) / 1e9
+            traffic = load_traffic()
+            per_voxel = ((traffic or {}).get("dense_ball") or 0) / float(512 ** 3)
+            result["roofline"] = {
+                "bound": "hbm", "kernel": KERNEL_NAMES["dense_ball"], "stage": "dense_ball",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": int(per_voxel * vox) if per_voxel else None,
+                "hbm_frac_traffic": round(per_voxel * vox / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if per_voxel else None,
+                "alg_bytes_per_voxel": B_ALG["dense_ball"], "avg_ms": round(avg_ms, 4),
+                "launches_timed": launches, "voxels_per_launch": vox,
+                "note": "rank 0, interior planes of its slab, every 4th build; traffic scaled from the 512^3 PMC pass",
+            }
         result["config"]["dense_path"] = builder.dense
         result["config"]["builds_needing_general_path"] = builder.general_builds
         result["config"]["whole_line_fallbacks"] = builder.fallbacks

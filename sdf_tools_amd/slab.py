@@ -143,6 +143,9 @@ class SlabSdfBuilder:
             self.bits = torch.zeros((self.bh_lo + self.nxs + self.bh_hi, self.ny, self.nz // 32),
                                     dtype=torch.int32, device=self.device)
         self._p2p_cache = {}
+        self._timing_every = 0          # > 0: bracket the interior ball launch of every k-th build with events
+        self._timings = []              # (event0, event1, voxels)
+        self._builds = 0
         self.slots = [_Slot(self.nxs, self.ny, self.nz, self.device) for _ in range(2)]
         self.cur = 0
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
@@ -190,8 +193,15 @@ class SlabSdfBuilder:
             self.stages.pack_bits(mask_slab[h:n - h], own[h:n - h])
             i_lo = h if self.bh_lo else 0
             i_hi = n - h if self.bh_hi else n
+            timed = self._timing_every > 0 and self._builds % self._timing_every == 0
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.stages.dense_ball(self.bits, lo + i_lo, lo + i_hi, self.nz, self.resolution, slot.out[i_lo:i_hi],
                                    slot.small)
+            if timed:
+                e1.record()
+                self._timings.append((e0, e1, (i_hi - i_lo) * self.ny * self.nz))
             for w in works:
                 w.wait()
             if i_lo:
@@ -204,7 +214,15 @@ class SlabSdfBuilder:
             self._flush_deferred(exclude=slot)
             for w in works:
                 w.wait()
+            timed = self._timing_every > 0 and self._builds % self._timing_every == 0
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.stages.dense_ball(self.bits, lo, lo + n, self.nz, self.resolution, slot.out, slot.small)
+            if timed:
+                e1.record()
+                self._timings.append((e0, e1, n * self.ny * self.nz))
+        self._builds += 1
         slot.reduce_deferred = True
 
     def _flush_deferred(self, exclude=None):
@@ -230,6 +248,21 @@ class SlabSdfBuilder:
                 if work is not None:
                     work.wait()
                 slot.host.copy_(slot.small)
+
+    def time_ball_kernel(self, every):
+        """Bracket the (interior) ball launch of every `every`-th build with events on the launch stream
+        (0 = off).  GPU only."""
+        self._timing_every = int(every) if self.device.type == "cuda" else 0
+        self._timings = []
+
+    def pop_ball_timings(self):
+        """(launches, total ms, voxels per launch) of the bracketed launches since the last call; synchronises."""
+        t = self._timings
+        self._timings = []
+        if not t:
+            return 0, 0.0, 0
+        t[-1][1].synchronize()
+        return len(t), sum(e0.elapsed_time(e1) for e0, e1, _ in t), t[0][2]
 
     # -- general path (synchronous; exact for any input) -----------------------------------------------
     def _gather_full(self):
