@@ -174,6 +174,11 @@ int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_
 int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t rows_x, int64_t out_lo,
                              int64_t out_hi, int64_t ny, int64_t nz, double resolution,
                              float* d_out_sdf, uint32_t* d_maxdsq, uint32_t* d_uncertified, void* stream);
+/* The kernels behind sdfgpu_sweep_x_device / sdfgpu_dense_ball_device collect their maxima in a slot array
+ * (see sdfgpu_kernels.hpp: slot_max2) and each call ends with a one-block fold into d_maxdsq[2].  A caller
+ * that issues several such calls per build (interior + border planes of a slab) can set the option
+ * "defer_fold" = 1 and fold once itself: */
+int sdfgpu_fold_extrema_device(sdfgpu_handle h, uint32_t* d_maxdsq, void* stream);
 
 /* (max, min) from the two integer maxima (0 = class absent, >= SDFGPU_DSQ_INF =
  * infinite), reproducing sdf_generation.hpp:246-269 / :416-418. */

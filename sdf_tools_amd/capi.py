@@ -22,7 +22,7 @@ EXPORTS = [
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
-    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device",
+    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device",
 ]
 
 
@@ -64,6 +64,7 @@ def load_library():
     L.sdfgpu_build_cells.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_build_tagged_cells.argtypes = [vp, vp, sz, sz, sz, ci, vp, i64, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_query_points_device.argtypes = [vp, vp, i64, i64, i64, dbl, vp, vp, ctypes.c_float, vp, i64, ci, vp, vp, vp, vp]
+    L.sdfgpu_fold_extrema_device.argtypes = [vp, vp, vp]
     L.sdfgpu_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
@@ -183,6 +184,9 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_query_points_device(
             self._h, d_sdf, nx, ny, nz, float(resolution), w, r, float(oob_value), d_points, int(n_points),
             int(bool(enable_edge_gradients)), d_distance or None, d_gradient or None, d_flags or None, stream or None))
+
+    def fold_extrema_device(self, d_maxdsq, stream=0):
+        self._check(self._lib.sdfgpu_fold_extrema_device(self._h, d_maxdsq, stream or None))
 
     # ---- device-pointer API (raw integers: tensor.data_ptr(), stream.cuda_stream) -------------
     def build_device(self, d_filled, shape, d_out, resolution=1.0, add_virtual_border=False, stream=0):

@@ -62,6 +62,7 @@ struct sdfgpu_context {
     bool dense_on = true;            // try the bit-parallel dense kernel first when the shape allows
     int pack_variant = 0;
     int ball_block = 0;
+    int defer_fold = 0;           // stage entry points leave their maxima in the slot array until sdfgpu_fold_extrema_device
     int ball_variant = 0;         // debugging: bit0 = bounds-checked expansion, bit1 = generic (non-ZINV) expansion
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
@@ -801,7 +802,7 @@ int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t h
     if (int rc = launch_sweep_x(h, d_plane_dsq, d_out_sdf, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated,
                                 x_global, nx_global, resolution, add_virtual_border, d_maxdsq, d_status,
                                 (hipStream_t)stream)) return rc;
-    return fold_slots(h, d_maxdsq, (hipStream_t)stream);
+    return h->defer_fold ? SDFGPU_OK : fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
 
 int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_rows, int64_t nz, uint32_t* d_bits,
@@ -824,6 +825,13 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = launch_ball_dense(h, d_bits, d_out_sdf, rows_x, out_lo, out_hi, ny, nz, resolution, d_maxdsq,
                                    d_uncertified, (hipStream_t)stream)) return rc;
+    return h->defer_fold ? SDFGPU_OK : fold_slots(h, d_maxdsq, (hipStream_t)stream);
+}
+
+int sdfgpu_fold_extrema_device(sdfgpu_handle h, uint32_t* d_maxdsq, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_maxdsq) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
     return fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
 
@@ -1004,6 +1012,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
+    else if (n == "defer_fold") h->defer_fold = value != 0;
     else if (n == "ball_variant") h->ball_variant = value;
     else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; }
     else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; }

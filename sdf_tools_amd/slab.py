@@ -52,6 +52,7 @@ class HipStages:
         from . import capi
 
         self.ctx = capi.SdfGpu(device_index)
+        self.ctx.set_option("defer_fold", 1)      # several stage calls per build: fold their maxima once (fold())
         self.device = torch.device("cuda", device_index)
 
     def stream(self):
@@ -69,6 +70,10 @@ class HipStages:
         base = small.data_ptr()
         self.ctx.sweep_x_device(ext.data_ptr(), halo_lo, nxs, halo_hi, ny, nz, lo_trunc, hi_trunc, x_global,
                                 nx_global, resolution, vb, out.data_ptr(), base, base + 8, self.stream())
+
+    def fold(self, small):
+        """Fold the maxima the stage kernels left in the context's slot array into small[0:2]."""
+        self.ctx.fold_extrema_device(small.data_ptr(), self.stream())
 
     # ---- dense path ----------------------------------------------------------------------------
     def pack_bits(self, mask_rows, bits_rows):
@@ -222,6 +227,8 @@ class SlabSdfBuilder:
             if timed:
                 e1.record()
                 self._timings.append((e0, e1, n * self.ny * self.nz))
+        if hasattr(self.stages, "fold"):
+            self.stages.fold(slot.small)
         self._builds += 1
         slot.reduce_deferred = True
 
@@ -297,6 +304,8 @@ class SlabSdfBuilder:
         small.zero_()
         self.stages.sweep_x(self.ext, lo, n, hi, self.x0 - lo > 0, self.x1 + hi < self.nx, self.x0, self.nx,
                             self.resolution, self.vb, slot.out, small)
+        if hasattr(self.stages, "fold"):
+            self.stages.fold(small)
         self._allreduce_small(small)
         max_f, max_q, status, _ = (int(v) for v in small.tolist())
         if status:
@@ -306,6 +315,8 @@ class SlabSdfBuilder:
             small.zero_()
             self.stages.sweep_x(full, self.x0, n, self.nx - self.x1, False, False, self.x0, self.nx,
                                 self.resolution, self.vb, slot.out, small)
+            if hasattr(self.stages, "fold"):
+                self.stages.fold(small)
             self._allreduce_small(small)
             max_f, max_q, status, _ = (int(v) for v in small.tolist())
             assert status == 0
