@@ -86,6 +86,13 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
         int k = -1;
         int vt = 0, At = 0, vs = 0, As = 0;     // top and second entry (copies of scratch[k], scratch[k-1])
         int sv[CH], sn[CH];                     // current batch and the one in flight behind it
+        // Site pruning.  The voxels that ARE the sought class have value 0, and along a line only the two ends
+        // of a run of them can ever be nearest to a voxel outside the run: (p - end)^2 < (p - interior)^2.
+        // So such a voxel is pushed only if one of its line neighbours has the other class.  For pass 1 on a
+        // scene with a few objects this turns "every free voxel of the line is a site" (a 512-deep stack and an
+        // advance per step of the backward pass) into two sites per object crossing.
+        const int none = cls == 0 ? -1 : 1;     // stands for a neighbour beyond the line ends: "same class as the run"
+        int sprev = none;
 #pragma unroll
         for (int u = 0; u < CH; ++u) sn[u] = (u < L) ? load_signed(u) : (cls == 0 ? kInf32 : -kInf32);
         for (int q0 = 0; q0 < L; q0 += CH) {
@@ -100,10 +107,14 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
                 const int q = q0 + u;
                 const int s = sv[u];
                 if (q < L) has_filled |= s < 0;
+                const int left = u > 0 ? sv[u - 1] : sprev;
+                const int right = (q + 1 >= L) ? none : (u < CH - 1 ? sv[u + 1] : sn[0]);
                 // value of this class's function at q: |s| on voxels of the class that looks for the other one,
-                // 0 on voxels that ARE the sought class
-                const int val = cls == 0 ? (s > 0 ? s : 0) : (s < 0 ? -s : 0);
-                if (val < kInf32) {             // else: no site of the sought class in this voxel's row / plane
+                // 0 on voxels that ARE the sought class (kept only at the ends of their runs)
+                int val;
+                if (cls == 0) val = s > 0 ? s : ((left > 0 || right > 0) ? 0 : kInf32);
+                else val = s < 0 ? -s : ((left < 0 || right < 0) ? 0 : kInf32);
+                if (val < kInf32) {             // else: no (useful) site of the sought class at this position
                     const int Aq = val + q * q;
                     while (k >= 1 && (int64_t)(Aq - At) * (vt - vs) <= (int64_t)(At - As) * (q - vt)) {
                         --k; vt = vs; At = As;
@@ -114,6 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
                     vs = vt; As = At; vt = q; At = Aq;
                 }
             }
+            sprev = sv[CH - 1];
         }
         // ---- backward: evaluate on the voxels that need this class --------------------------------------
         int j = 0, v0 = 0, A0 = 0, v1 = 0, A1 = 0;
