@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Differential fuzzing on a GPU box: random shapes / densities / borders / scene types through the C ABI,
+every voxel compared bit for bit with the oracle's exact EDT (oracle/ is the checker here, as in tests/).
+
+  python tools/fuzz_parity.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402
+from sdf_tools_amd import capi, synth  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+ctx = capi.SdfGpu(0)
+sizes = [1, 2, 3, 5, 8, 13, 16, 21, 32, 33, 40, 64, 96, 128]
+t0 = time.time()
+n = 0
+while time.time() - t0 < budget:
+    shape = tuple(int(rng.choice(sizes)) for _ in range(3))
+    if rng.random() < 0.5:
+        shape = shape[:2] + (int(rng.choice([32, 64, 128, 256])),)        # dense-path eligible z extents
+    if np.prod(shape) > 1 << 21:
+        continue
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        m = synth.bernoulli_mask(shape, float(rng.choice([0.5, 0.3, 0.1, 0.01, 0.001, 0.9, 0.99, 0.999])), int(rng.integers(1 << 30)))
+    elif kind == 1:
+        m = synth.spheres_mask(shape, int(rng.integers(1, 5)), (1, 9), int(rng.integers(1 << 30)))
+    elif kind == 2:
+        m = np.zeros(shape, np.uint8)
+        for _ in range(int(rng.integers(0, 4))):
+            m[tuple(int(rng.integers(0, s)) for s in shape)] = 1
+        if rng.random() < 0.3:
+            m = 1 - m
+    else:
+        m = (rng.random(shape) < rng.random() ** 3).astype(np.uint8)
+        lo = [int(rng.integers(0, s)) for s in shape]
+        hi = [int(rng.integers(l, s)) + 1 for l, s in zip(lo, shape)]
+        m[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = rng.integers(0, 2)
+    res = float(rng.choice([1.0, 0.5, 0.01, 0.037]))
+    vb = bool(rng.integers(0, 2))
+    for k, v in (("dense", int(rng.integers(0, 2))), ("envelope", int(rng.integers(0, 2))), ("plane16", int(rng.integers(0, 2)))):
+        ctx.set_option(k, v)
+    got, ext = ctx.build(m, res, vb)
+    want, want_ext, _ = O.exact_sdf(m, res, vb)
+    if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
+        bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        np.save("gpurun_out/fuzz_fail_mask.npy", m)
+        print("MISMATCH shape", shape, "kind", kind, "res", res, "vb", vb, "bad", len(bad), bad[:3].tolist(), ext, want_ext)
+        sys.exit(1)
+    n += 1
+print("fuzz OK: %d scenes in %.0f s (seed %d)" % (n, time.time() - t0, seed))
