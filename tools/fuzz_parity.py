@@ -51,6 +51,7 @@ while time.time() - t0 < budget:
     want, want_ext, _ = O.exact_sdf(m, res, vb)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
         bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        os.makedirs("gpurun_out", exist_ok=True)
         np.save("gpurun_out/fuzz_fail_mask.npy", m)
         print("MISMATCH shape", shape, "kind", kind, "res", res, "vb", vb, "bad", len(bad), bad[:3].tolist(), ext, want_ext)
         sys.exit(1)
