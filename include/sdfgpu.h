@@ -251,7 +251,9 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * "x16_window" (2 or 3), "dense" (1 = try the bit-parallel dense kernel first, default; 0 = general
  * pipeline only), "envelope" (1 = bound the outward scans of K2 / K3 and redo far-field sweeps with the
  * lower-envelope kernels, default; 0 = unbounded scans), "envelope_mode" (force / clear the per-axis
- * "envelope kernel alone" policy state), "policy_reset" (forget what was learned from earlier builds). */
+ * "envelope kernel alone" policy state), "policy_reset" (forget what was learned from earlier builds),
+ * "dense_retry" (after an uncertified dense attempt, try the dense kernels again only every N-th build;
+ * default 16, 0 = always try). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),

@@ -115,3 +115,22 @@ def test_virtual_border_skips_the_dense_path(gpu):
     assert not gpu.last_build_info()["dense"]
     ex, ex_ext, _ = O.exact_sdf(m, 1.0, True)
     assert np.array_equal(sdf, ex) and ext == ex_ext
+
+
+def test_dense_retry_policy_skips_and_retries(gpu):
+    """After an uncertified dense attempt the dense kernels are left out of the next builds and tried again every
+    dense_retry-th build; results stay exact either way."""
+    gpu.set_option("dense_retry", 4)
+    sparse = synth.bernoulli_mask((16, 16, 64), 0.002, 9)
+    dense = synth.bernoulli_mask((16, 16, 64), 0.5, 9)
+    ex_d, ext_d, _ = O.exact_sdf(dense, 0.1)
+    sdf, _ = gpu.build(sparse, 0.1)
+    assert gpu.last_build_info()["dense"] and not gpu.last_dense_certified()
+    used = []
+    for _ in range(8):                                   # the scene turns dense: skipped 3 times, retried, then kept
+        sdf, ext = gpu.build(dense, 0.1)
+        assert np.array_equal(sdf, ex_d) and ext == ext_d
+        used.append(gpu.last_build_info()["dense"])
+    assert used == [False, False, False, True, True, True, True, True]
+    assert gpu.last_dense_certified()
+    gpu.set_option("dense_retry", 0)
