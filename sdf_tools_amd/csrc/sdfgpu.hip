@@ -47,6 +47,9 @@ struct sdfgpu_context {
     DeviceBuffer plane16;    // int16 [N]   plane field of the 16-bit pipeline
     DeviceBuffer bits;       // uint32 [N/32] packed occupancy of the dense path
     DeviceBuffer env;        // int2 [N] per-line stacks of the envelope kernels (far-field scenes)
+    DeviceBuffer unc;        // uint32 [N/32] undecided bits handed from the dense ball kernel to its fix-up kernel
+    DeviceBuffer tileflag;   // uint32 [tiles] which waves of a tile wrote unc words (kept zero between builds)
+    DeviceBuffer fix_order;  // uint32 [kFixRows] (dx, dy) rows of the fix-up kernel sorted by dx^2 + dy^2
     DeviceBuffer tagmask;    // uint8 [N] mask produced by the tagged-object classify kernel
     DeviceBuffer tagids;     // uint32 object id filter
     DeviceBuffer stage_in;   // host-API staging: mask / cells
@@ -62,6 +65,9 @@ struct sdfgpu_context {
     bool dense_on = true;            // try the bit-parallel dense kernel first when the shape allows
     int pack_variant = 0;
     int ball_block = 0;
+    int fixup_on = 1;             // fix-up kernel behind the dense ball kernel (almost-dense scenes)
+    bool fix_mode = false;        // policy: launch the fix-up kernel with the next dense build
+    bool prev_fix_mode = false;
     int dense_retry = 16;         // after an uncertified dense attempt, try the dense kernels again every N-th build (0 = always)
     int dense_skip = 0;           // builds left that skip the dense kernels
     int defer_fold = 0;           // stage entry points leave their maxima in the slot array until sdfgpu_fold_extrema_device
@@ -375,7 +381,8 @@ int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s) {
 }
 
 int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int64_t rows_x, int64_t out_lo, int64_t out_hi,
-                      int64_t ny, int64_t nz, double resolution, uint32_t* d_maxdsq, uint32_t* d_uncert, hipStream_t s) {
+                      int64_t ny, int64_t nz, double resolution, uint32_t* d_maxdsq, uint32_t* d_uncert, hipStream_t s,
+                      uint32_t* d_fix_needed = nullptr) {
     DenseArgs a{};
     a.bits = d_bits; a.out = d_out;
     a.nzw = (int)(nz / 32);
@@ -407,12 +414,44 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     const size_t tile_words = ((size_t)(a.tx + 2 * kBallR) * (a.ty + 2 * kBallR) * pitch + 3) & ~(size_t)3;
     const size_t lds = tile_words * 4 + (size_t)bd * 16 + 256 * 8 + 64;
     const dim3 grid((unsigned)gx, (unsigned)gy);
+    if (d_fix_needed) {                                              // fix-up mode: hand the undecided voxels to KF
+        const size_t tiles = (size_t)gx * gy;
+        if (int rc = ensure(h, h->unc, (size_t)(out_hi - out_lo) * ny * a.nzw * 4)) return rc;
+        if (h->tileflag.bytes < tiles * 4 || !h->tileflag.ptr) {
+            if (int rc = ensure(h, h->tileflag, tiles * 4)) return rc;
+            HIP_TRY(h, hipMemsetAsync(h->tileflag.ptr, 0, h->tileflag.bytes, s));     // afterwards KF keeps it zero
+        }
+        a.unc = (uint32_t*)h->unc.ptr; a.tileflag = (uint32_t*)h->tileflag.ptr; a.fix_needed = d_fix_needed;
+    }
     const bool zinv = nz <= (int64_t)bd * 4 && !(h->ball_variant & 2);   // an expansion pass covers whole z-rows
-    a.checked = h->ball_variant & ~2;
+    a.checked = h->ball_variant & 1;
     if (bd == 1024) hipLaunchKernelGGL((k_ball_dense<1024, true>), grid, dim3(1024), lds, s, a);
     else if (bd == 512) hipLaunchKernelGGL((k_ball_dense<512, true>), grid, dim3(512), lds, s, a);
     else if (zinv) hipLaunchKernelGGL((k_ball_dense<256, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((k_ball_dense<256, false>), grid, dim3(256), lds, s, a);
+    if (d_fix_needed) {
+        HIP_TRY(h, hipGetLastError());
+        if (!h->fix_order.ptr) {                                     // (dx, dy) rows by increasing dx^2 + dy^2, built once
+            std::vector<uint32_t> order;
+            for (int dx = -kFixR; dx <= kFixR; ++dx)
+                for (int dy = -kFixR; dy <= kFixR; ++dy)
+                    order.push_back((uint32_t)(dx + kFixR) | ((uint32_t)(dy + kFixR) << 8) | ((uint32_t)(dx * dx + dy * dy) << 16));
+            std::stable_sort(order.begin(), order.end(), [](uint32_t x, uint32_t y) { return (x >> 16) < (y >> 16); });
+            if (int rc = ensure(h, h->fix_order, order.size() * 4)) return rc;
+            HIP_TRY(h, hipMemcpy(h->fix_order.ptr, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        }
+        FixArgs f{};
+        f.bits = d_bits; f.out = d_out; f.unc = a.unc; f.tileflag = a.tileflag; f.fix_needed = d_fix_needed;
+        f.order = (const uint32_t*)h->fix_order.ptr;
+        f.nzw = a.nzw; f.log2_nzw = a.log2_nzw; f.ny = a.ny; f.rows_x = a.rows_x; f.out_lo = a.out_lo; f.out_hi = a.out_hi;
+        f.tx = a.tx; f.ty = a.ty; f.log2_ty = a.log2_ty; f.resolution = resolution;
+        f.slots = h->d_slots; f.uncertified = d_uncert;
+        const size_t flds = (size_t)(176 + kFixCap + 4) * 4 +
+                            (size_t)(a.tx + 2 * kFixR) * (a.ty + 2 * kFixR) * (a.nzw + 2) * 4;
+        if (bd == 1024) hipLaunchKernelGGL(k_ball_fixup<1024>, grid, dim3(1024), flds, s, f);
+        else if (bd == 512) hipLaunchKernelGGL(k_ball_fixup<512>, grid, dim3(512), flds, s, f);
+        else hipLaunchKernelGGL(k_ball_fixup<256>, grid, dim3(256), flds, s, f);
+    }
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -447,7 +486,14 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->expect_dense = !general_ran;
         //   dense attempted but not certified -> pack + ball were wasted (0.13 ms at 512^3): leave them out of the
         //                       next dense_retry - 1 builds, then try once more
-        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0) h->dense_skip = h->dense_retry - 1;
+        //   almost dense (the ball kernel left voxels undecided): first try the fix-up kernel behind it; only if that
+        //   cannot certify the scene either are the dense kernels left out of the next builds
+        if (h->prev_dense && h->fixup_on) {
+            if (!h->prev_fix_mode) h->fix_mode = h->h_flags[3] != 0;               // uncertified without KF: try KF next
+            else h->fix_mode = h->h_flags[6] != 0 && h->h_flags[3] == 0;           // keep KF while it is needed and works
+        }
+        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on))
+            h->dense_skip = h->dense_retry - 1;
         if (general_ran) {
             const uint32_t max_d = std::max(h->h_flags[0], h->h_flags[1]);
             const bool near = max_d <= (uint32_t)(kScanExpectNear * kScanExpectNear);
@@ -467,7 +513,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));        // [0..7]: maxima, status, uncertified, far flags, fix_needed
     // profiling marks: an event is recorded only behind a stage that launched something; a stage that
     // was not launched shares the previous mark (elapsed 0), so profiling adds as few packets as possible
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -504,10 +550,14 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         if (int rc = launch_pack_bits(h, d_filled, d_cells, stride, off, unknown, n, (uint32_t*)h->bits.ptr, s)) return rc;
         launched_since_mark = true;
         HIP_TRY(h, mark(1));
+        // fix-up mode (policy): undecided voxels go to the fix-up kernel, which raises `uncertified` only for what it
+        // cannot decide either; otherwise the ball kernel raises it directly and nothing extra is launched
+        const bool fix = h->fixup_on && h->fix_mode;
         if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
-                                       h->d_small + 3, s)) return rc;
+                                       h->d_small + 3, s, fix ? h->d_small + 6 : nullptr)) return rc;
         launched_since_mark = true;
         h->guard = h->d_small + 3;
+        h->prev_fix_mode = fix;
     } else {
         HIP_TRY(h, mark(1));
     }
@@ -701,7 +751,7 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
 int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
-    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->env, &h->tagmask, &h->tagids, &h->stage_in,
+    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->env, &h->unc, &h->tileflag, &h->fix_order, &h->tagmask, &h->tagids, &h->stage_in,
                             &h->stage_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
@@ -1020,7 +1070,9 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
     else if (n == "ball_variant") h->ball_variant = value;
-    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; }
+    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; h->fix_mode = false; }
+    else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; }
+    else if (n == "fixup_mode") h->fix_mode = value != 0;
     else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; }
     else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; }
     else if (n == "x16_voxels_per_lane") h->x16_v = value;

@@ -99,6 +99,11 @@ struct DenseArgs {
     float mag[8];           // float(sqrt(double(level d^2)) * resolution) per level; [7] = 0 (not found)
     uint32_t* slots;        // [kSlots][kSlotWords]: per-slot {max d^2 free, max d^2 filled}, see slot_max2 / k_fold_slots
     uint32_t* uncertified;  // set to 1 if some voxel has no opposite-class voxel within d^2 <= 8
+    // fix-up mode (k_ball_fixup runs behind this launch): instead of raising `uncertified`, a wave that holds
+    // undecided voxels writes its 64 "undecided" words, sets its bit in the tile's flag word and raises fix_needed
+    uint32_t* unc;          // [out rows][ny][nzw] undecided bits (only written by waves that have some)
+    uint32_t* tileflag;     // [tiles] bit w = wave w of the tile wrote its unc words (cleared again by k_ball_fixup)
+    uint32_t* fix_needed;
     int checked;            // debugging: take the bounds-checked expansion even for interior tiles
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
 };
@@ -343,9 +348,150 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
         mxQ = max(mxQ, __shfl_xor(mxQ, off));
     }
     const bool any_uncert = __any(uncert);
+    if (any_uncert && a.unc) {
+        if (row_in_grid)
+            a.unc[((int64_t)(x0 + tx_ - a.out_lo) * a.ny + (y0 + ty_)) * nzw + w] = ~acc[6];
+    }
     if ((t & 63) == 0) {
-        slot_max2(a.slots, ((uint32_t)blockIdx.y * gridDim.x + blockIdx.x) * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
-        if (any_uncert) raise_flag(a.uncertified);
+        const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
+        slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
+        if (any_uncert) {
+            if (a.unc) {
+                atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up
+                raise_flag(a.fix_needed);
+            } else {
+                raise_flag(a.uncertified);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KF: fix-up behind KD for "almost dense" scenes.
+//
+// At Bernoulli p = 0.1 the ball of d^2 <= 8 leaves 0.9^92 = 6e-5 of the free voxels undecided -- 7 000 of 134 M
+// -- and recomputing the whole grid with the general sweeps for them costs 5x the dense kernels.  KF visits only
+// those voxels: the tiles whose flag word KD set stage their bit rows again with a halo of kFixR planes / rows, the
+// undecided voxels of the tile are compacted into an LDS list, and one lane per voxel scans the (dx, dy) rows in
+// order of increasing dx^2 + dy^2 (stopping as soon as that alone reaches the best candidate), taking the nearest
+// opposite bit within |dz| <= kFixR of each row with two bit scans.  A candidate <= kFixR^2 is the exact squared
+// distance (every offset that could beat it lies inside the scanned cube; rows / bits beyond the grid replicate
+// the nearest in-grid voxel exactly as in KD); anything else -- or a tile with more than kFixCap undecided
+// voxels -- raises `uncertified` and the guarded general sweeps redo the grid, so results are exact for any input.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFixR = 6;
+constexpr int kFixCap = 2048;                                 // undecided voxels a tile may hand to KF
+constexpr int kFixRows = (2 * kFixR + 1) * (2 * kFixR + 1);   // 169 (dx, dy) rows
+
+struct FixArgs {
+    const uint32_t* bits;   // [rows_x][ny][nzw]
+    float* out;
+    const uint32_t* unc;
+    uint32_t* tileflag;
+    const uint32_t* fix_needed;   // guard
+    const uint32_t* order;  // [kFixRows] (dx + R) | (dy + R) << 8 | (dx^2 + dy^2) << 16, sorted by the last
+    int nzw, log2_nzw, ny, rows_x, out_lo, out_hi, tx, ty, log2_ty;
+    double resolution;
+    uint32_t* slots;
+    uint32_t* uncertified;
+};
+
+template <int BD>
+__global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fix_smem[];
+    if (*a.fix_needed == 0u) return;
+    const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t flags = a.tileflag[tile_id];               // wave-uniform
+    if (flags == 0u) return;
+    const int t = threadIdx.x;
+    const int nzw = a.nzw, lg = a.log2_nzw;
+    const int rw = nzw + 2;                                   // one replicated edge word on each side
+    const int hx = a.tx + 2 * kFixR, hy = a.ty + 2 * kFixR;
+    uint32_t* order = reinterpret_cast<uint32_t*>(fix_smem);  // [kFixRows] (+ pad)
+    uint32_t* list = order + 176;                             // [kFixCap] (tile row << 16) | z
+    uint32_t* count = list + kFixCap;                         // [1] (+ pad to 4 words)
+    uint32_t* tile = count + 4;                               // [hx][hy][rw]
+    if (t == 0) { *count = 0u; a.tileflag[tile_id] = 0u; }
+    for (int i = t; i < kFixRows; i += BD) order[i] = a.order[i];
+    const int x0 = a.out_lo + (int)blockIdx.y * a.tx, y0 = (int)blockIdx.x * a.ty;
+    for (int i = t; i < hx * hy * rw; i += BD) {              // rows / edge words replicate the nearest in-grid voxel
+        const int row = i / rw, ws = i - row * rw;
+        const int jx = row / hy, jy = row - jx * hy;
+        const int gx = min(max(x0 + jx - kFixR, 0), a.rows_x - 1);
+        const int gy = min(max(y0 + jy - kFixR, 0), a.ny - 1);
+        const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
+        uint32_t v;
+        if (ws == 0) v = (src[0] & 1u) ? ~0u : 0u;
+        else if (ws == rw - 1) v = (src[nzw - 1] >> 31) ? ~0u : 0u;
+        else v = src[ws - 1];
+        tile[i] = v;
+    }
+    __syncthreads();
+    // this lane's word (same mapping as KD) -> list of its undecided voxels
+    {
+        const int r = t >> lg, w = t & (nzw - 1);
+        const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
+        const bool row_in_grid = (x0 + tx_ < a.out_hi) && (y0 + ty_ < a.ny);
+        uint32_t u = 0;
+        if (row_in_grid && ((flags >> (t >> 6)) & 1u))
+            u = a.unc[((int64_t)(x0 + tx_ - a.out_lo) * a.ny + (y0 + ty_)) * nzw + w];
+        while (u) {
+            const int b = __builtin_ctz(u);
+            u &= u - 1;
+            const uint32_t slot = atomicAdd(count, 1u);
+            if (slot < (uint32_t)kFixCap) list[slot] = ((uint32_t)r << 16) | (uint32_t)(w * 32 + b);
+        }
+    }
+    __syncthreads();
+    const uint32_t n = *count;
+    if (n > (uint32_t)kFixCap) {                              // too many: let the general sweeps do the whole grid
+        if (t == 0) raise_flag(a.uncertified);
+        return;
+    }
+    int mxF = 0, mxQ = 0;
+    bool failed = false;
+    const int nz = nzw << 5;
+    for (uint32_t i = t; i < n; i += BD) {
+        const uint32_t e = list[i];
+        const int r = (int)(e >> 16), z = (int)(e & 0xffffu);
+        const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
+        const int w = z >> 5, b = z & 31;
+        const uint32_t* c0 = tile + ((tx_ + kFixR) * hy + (ty_ + kFixR)) * rw + (w + 1);
+        const uint32_t cls = (c0[0] >> b) & 1u;
+        const uint32_t flip = cls ? ~0u : 0u;                 // after the XOR a set bit = voxel of the OTHER class
+        int best = 1 << 20;
+        for (int k = 0; k < kFixRows; ++k) {
+            const uint32_t o = order[k];
+            const int d2 = (int)(o >> 16);
+            if (d2 >= best) break;                            // no row from here on can improve the candidate
+            const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
+            const uint32_t* p = c0 + (dx * hy + dy) * rw;
+            const uint32_t prev = p[-1] ^ flip, cur = p[0] ^ flip, next = p[1] ^ flip;
+            // dz >= 0: bit dz of `up` = voxel z + dz
+            const uint32_t up = (uint32_t)((((uint64_t)next << 32) | cur) >> b) & ((2u << kFixR) - 1u);
+            if (up) { const int dz = __builtin_ctz(up); best = min(best, d2 + dz * dz); }
+            // dz < 0: bit i of `dn` = voxel z - kFixR + i
+            const uint32_t dn = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32 + b - kFixR)) & ((1u << kFixR) - 1u);
+            if (dn) { const int dz = kFixR - (31 - __builtin_clz(dn)); best = min(best, d2 + dz * dz); }
+        }
+        if (best <= kFixR * kFixR) {
+            const float f = (float)(sqrt((double)best) * a.resolution);
+            const int gx = x0 + tx_, gy = y0 + ty_;
+            a.out[((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z] = cls ? -f : f;
+            if (cls) mxQ = max(mxQ, best); else mxF = max(mxF, best);
+        } else {
+            failed = true;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mxF = max(mxF, __shfl_xor(mxF, off));
+        mxQ = max(mxQ, __shfl_xor(mxQ, off));
+    }
+    const bool any_failed = __any(failed);
+    if ((t & 63) == 0) {
+        slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
+        if (any_failed) raise_flag(a.uncertified);
     }
 }
 

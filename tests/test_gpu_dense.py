@@ -118,14 +118,18 @@ def test_virtual_border_skips_the_dense_path(gpu):
 
 
 def test_dense_retry_policy_skips_and_retries(gpu):
-    """After an uncertified dense attempt the dense kernels are left out of the next builds and tried again every
-    dense_retry-th build; results stay exact either way."""
+    """An uncertified dense attempt is first retried with the fix-up kernel; if that cannot certify the scene
+    either, the dense kernels are left out of the next builds and tried again every dense_retry-th build.
+    Results stay exact all along."""
     gpu.set_option("dense_retry", 4)
     sparse = synth.bernoulli_mask((16, 16, 64), 0.002, 9)
     dense = synth.bernoulli_mask((16, 16, 64), 0.5, 9)
+    ex_s, ext_s, _ = O.exact_sdf(sparse, 0.1)
     ex_d, ext_d, _ = O.exact_sdf(dense, 0.1)
-    sdf, _ = gpu.build(sparse, 0.1)
-    assert gpu.last_build_info()["dense"] and not gpu.last_dense_certified()
+    for _ in range(2):                                   # plain attempt, then the attempt with the fix-up kernel
+        sdf, ext = gpu.build(sparse, 0.1)
+        assert np.array_equal(sdf, ex_s) and ext == ext_s
+        assert gpu.last_build_info()["dense"] and not gpu.last_dense_certified()
     used = []
     for _ in range(8):                                   # the scene turns dense: skipped 3 times, retried, then kept
         sdf, ext = gpu.build(dense, 0.1)
@@ -134,3 +138,42 @@ def test_dense_retry_policy_skips_and_retries(gpu):
     assert used == [False, False, False, True, True, True, True, True]
     assert gpu.last_dense_certified()
     gpu.set_option("dense_retry", 0)
+
+
+@pytest.mark.parametrize("p", [0.1, 0.07, 0.9, 0.93])
+def test_almost_dense_scenes_are_finished_by_the_fixup_kernel(gpu, p):
+    """A handful of voxels beyond the d^2 <= 8 ball: the first build falls back to the general sweeps, the policy
+    then puts the fix-up kernel behind the ball kernel and the scene is certified without them -- exact both ways."""
+    shape = (48, 40, 64)
+    m = synth.bernoulli_mask(shape, p, 21)
+    ex, ex_ext, dsq = O.exact_sdf(m, 0.05)
+    assert np.abs(dsq).max() > 8                           # the ball alone cannot decide this scene
+    certified = []
+    for _ in range(3):
+        sdf, ext = gpu.build(m, 0.05)
+        assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)) and ext == ex_ext
+        certified.append(gpu.last_dense_certified())
+    assert certified == [False, True, True]
+    # forced fix-up mode on a scene that needs distances beyond its cube: it must hand over, not guess
+    gpu.set_option("policy_reset", 1)
+    gpu.set_option("fixup_mode", 1)
+    far = np.zeros(shape, np.uint8)
+    far[3, 4, 5] = 1
+    far[40, 30, 60] = 1
+    sdf, ext = gpu.build(far, 1.0)
+    want, want_ext, _ = O.exact_sdf(far, 1.0)
+    assert np.array_equal(sdf, want) and ext == want_ext and not gpu.last_dense_certified()
+
+
+def test_fixup_kernel_edges_and_every_shape(gpu):
+    """Grid faces / word boundaries / odd tile shapes with the fix-up kernel forced on."""
+    for shape in ((5, 7, 32), (9, 4, 128), (3, 5, 1024), (33, 21, 96), (1, 40, 64), (2, 3, 2048)):
+        for p in (0.12, 0.9):
+            m = synth.bernoulli_mask(shape, p, 5)
+            m[0, 0, 0] = 1 - m[0, 0, 0]
+            gpu.set_option("policy_reset", 1)
+            gpu.set_option("fixup_mode", 1)
+            sdf, ext = gpu.build(m, 0.3)
+            ex, ex_ext, _ = O.exact_sdf(m, 0.3)
+            assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)), shape
+            assert ext == ex_ext

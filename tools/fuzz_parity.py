@@ -47,6 +47,8 @@ while time.time() - t0 < budget:
     vb = bool(rng.integers(0, 2))
     for k, v in (("dense", int(rng.integers(0, 2))), ("envelope", int(rng.integers(0, 2))), ("plane16", int(rng.integers(0, 2)))):
         ctx.set_option(k, v)
+    if rng.random() < 0.3:
+        ctx.set_option("fixup_mode", 1)                 # force the fix-up kernel behind the dense ball kernel
     got, ext = ctx.build(m, res, vb)
     want, want_ext, _ = O.exact_sdf(m, res, vb)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
