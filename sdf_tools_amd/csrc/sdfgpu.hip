@@ -68,6 +68,7 @@ struct sdfgpu_context {
     int fixup_on = 1;             // fix-up kernel behind the dense ball kernel (almost-dense scenes)
     bool fix_mode = false;        // policy: launch the fix-up kernel with the next dense build
     bool prev_fix_mode = false;
+    int fix_clean = 0;            // consecutive fix-mode builds that needed no fix (the mode is left after 8)
     int dense_retry = 16;         // after an uncertified dense attempt, try the dense kernels again every N-th build (0 = always)
     int dense_skip = 0;           // builds left that skip the dense kernels
     int defer_fold = 0;           // stage entry points leave their maxima in the slot array until sdfgpu_fold_extrema_device
@@ -489,8 +490,12 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         //   almost dense (the ball kernel left voxels undecided): first try the fix-up kernel behind it; only if that
         //   cannot certify the scene either are the dense kernels left out of the next builds
         if (h->prev_dense && h->fixup_on) {
-            if (!h->prev_fix_mode) h->fix_mode = h->h_flags[3] != 0;               // uncertified without KF: try KF next
-            else h->fix_mode = h->h_flags[6] != 0 && h->h_flags[3] == 0;           // keep KF while it is needed and works
+            if (!h->prev_fix_mode) { h->fix_mode = h->h_flags[3] != 0; h->fix_clean = 0; }   // uncertified without KF: try KF next
+            else if (h->h_flags[3] != 0) h->fix_mode = false;                      // KF could not certify it either
+            else {                                                                 // keep KF while it is needed (left after
+                h->fix_clean = h->h_flags[6] != 0 ? 0 : h->fix_clean + 1;          // 8 clean builds in a row: a scene at the
+                if (h->fix_clean >= 8) { h->fix_mode = false; h->fix_clean = 0; }  // edge of the ball must not flap)
+            }
         }
         if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on))
             h->dense_skip = h->dense_retry - 1;

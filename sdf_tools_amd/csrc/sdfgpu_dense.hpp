@@ -372,9 +372,9 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
 // At Bernoulli p = 0.1 the ball of d^2 <= 8 leaves 0.9^92 = 6e-5 of the free voxels undecided -- 7 000 of 134 M
 // -- and recomputing the whole grid with the general sweeps for them costs 5x the dense kernels.  KF visits only
 // those voxels: the tiles whose flag word KD set stage their bit rows again with a halo of kFixR planes / rows, the
-// undecided voxels of the tile are compacted into an LDS list, and one lane per voxel scans the (dx, dy) rows in
-// order of increasing dx^2 + dy^2 (stopping as soon as that alone reaches the best candidate), taking the nearest
-// opposite bit within |dz| <= kFixR of each row with two bit scans.  A candidate <= kFixR^2 is the exact squared
+// undecided voxels of the tile are compacted into an LDS list, and one wave per voxel scans the 169 (dx, dy) rows
+// (3 per lane), taking the nearest opposite bit within |dz| <= kFixR of each row with two bit scans, and
+// min-reduces the candidates.  A candidate <= kFixR^2 is the exact squared
 // distance (every offset that could beat it lies inside the scanned cube; rows / bits beyond the grid replicate
 // the nearest in-grid voxel exactly as in KD); anything else -- or a tile with more than kFixCap undecided
 // voxels -- raises `uncertified` and the guarded general sweeps redo the grid, so results are exact for any input.
@@ -414,17 +414,35 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     if (t == 0) { *count = 0u; a.tileflag[tile_id] = 0u; }
     for (int i = t; i < kFixRows; i += BD) order[i] = a.order[i];
     const int x0 = a.out_lo + (int)blockIdx.y * a.tx, y0 = (int)blockIdx.x * a.ty;
-    for (int i = t; i < hx * hy * rw; i += BD) {              // rows / edge words replicate the nearest in-grid voxel
-        const int row = i / rw, ws = i - row * rw;
-        const int jx = row / hy, jy = row - jx * hy;
-        const int gx = min(max(x0 + jx - kFixR, 0), a.rows_x - 1);
-        const int gy = min(max(y0 + jy - kFixR, 0), a.ny - 1);
-        const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
-        uint32_t v;
-        if (ws == 0) v = (src[0] & 1u) ? ~0u : 0u;
-        else if (ws == rw - 1) v = (src[nzw - 1] >> 31) ? ~0u : 0u;
-        else v = src[ws - 1];
-        tile[i] = v;
+    {
+        // rows / edge words replicate the nearest in-grid voxel.  Lanes = (row in pass, word slot): 2^lgp >= rw slots
+        const int lgp = lg + 1 > 2 ? lg + 1 : 2;
+        const int ws = t & ((1 << lgp) - 1), r0 = t >> lgp, rpp = BD >> lgp;
+        if (ws < rw) {
+            const int nrows = hx * hy;
+            for (int row0 = r0; row0 < nrows; row0 += 4 * rpp) {          // 4 independent loads in flight per lane
+                uint32_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = min(row0 + k * rpp, nrows - 1);
+                    const int jx = row / hy, jy = row - jx * hy;
+                    const int gx = min(max(x0 + jx - kFixR, 0), a.rows_x - 1);
+                    const int gy = min(max(y0 + jy - kFixR, 0), a.ny - 1);
+                    const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
+                    v[k] = src[min(max(ws - 1, 0), nzw - 1)];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = row0 + k * rpp;
+                    if (row < nrows) {
+                        uint32_t x = v[k];
+                        if (ws == 0) x = (x & 1u) ? ~0u : 0u;
+                        else if (ws == rw - 1) x = (x >> 31) ? ~0u : 0u;
+                        tile[row * rw + ws] = x;
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
     // this lane's word (same mapping as KD) -> list of its undecided voxels
@@ -451,8 +469,12 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     int mxF = 0, mxQ = 0;
     bool failed = false;
     const int nz = nzw << 5;
-    for (uint32_t i = t; i < n; i += BD) {
-        const uint32_t e = list[i];
+    // one WAVE per voxel: the 169 rows are spread over the 64 lanes (3 each, no dependence between them) and the
+    // candidates are min-reduced across the wave -- a lane-per-voxel scan with early exit was 4x slower here
+    // because a tile rarely holds more than a handful of undecided voxels
+    const int lane = t & 63;
+    for (uint32_t i = (uint32_t)t >> 6; i < n; i += BD / 64) {
+        const uint32_t e = list[i];                           // wave-uniform
         const int r = (int)(e >> 16), z = (int)(e & 0xffffu);
         const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
         const int w = z >> 5, b = z & 31;
@@ -460,24 +482,31 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         const uint32_t cls = (c0[0] >> b) & 1u;
         const uint32_t flip = cls ? ~0u : 0u;                 // after the XOR a set bit = voxel of the OTHER class
         int best = 1 << 20;
-        for (int k = 0; k < kFixRows; ++k) {
-            const uint32_t o = order[k];
-            const int d2 = (int)(o >> 16);
-            if (d2 >= best) break;                            // no row from here on can improve the candidate
-            const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
-            const uint32_t* p = c0 + (dx * hy + dy) * rw;
-            const uint32_t prev = p[-1] ^ flip, cur = p[0] ^ flip, next = p[1] ^ flip;
-            // dz >= 0: bit dz of `up` = voxel z + dz
-            const uint32_t up = (uint32_t)((((uint64_t)next << 32) | cur) >> b) & ((2u << kFixR) - 1u);
-            if (up) { const int dz = __builtin_ctz(up); best = min(best, d2 + dz * dz); }
-            // dz < 0: bit i of `dn` = voxel z - kFixR + i
-            const uint32_t dn = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32 + b - kFixR)) & ((1u << kFixR) - 1u);
-            if (dn) { const int dz = kFixR - (31 - __builtin_clz(dn)); best = min(best, d2 + dz * dz); }
+#pragma unroll
+        for (int k0 = 0; k0 < kFixRows; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < kFixRows) {
+                const uint32_t o = order[k];
+                const int d2 = (int)(o >> 16);
+                const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
+                const uint32_t* p = c0 + (dx * hy + dy) * rw;
+                const uint32_t prev = p[-1] ^ flip, cur = p[0] ^ flip, next = p[1] ^ flip;
+                // dz >= 0: bit dz of `up` = voxel z + dz
+                const uint32_t up = (uint32_t)((((uint64_t)next << 32) | cur) >> b) & ((2u << kFixR) - 1u);
+                if (up) { const int dz = __builtin_ctz(up); best = min(best, d2 + dz * dz); }
+                // dz < 0: bit i of `dn` = voxel z - kFixR + i
+                const uint32_t dn = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32 + b - kFixR)) & ((1u << kFixR) - 1u);
+                if (dn) { const int dz = kFixR - (31 - __builtin_clz(dn)); best = min(best, d2 + dz * dz); }
+            }
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off));
         if (best <= kFixR * kFixR) {
-            const float f = (float)(sqrt((double)best) * a.resolution);
-            const int gx = x0 + tx_, gy = y0 + ty_;
-            a.out[((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z] = cls ? -f : f;
+            if (lane == 0) {
+                const float f = (float)(sqrt((double)best) * a.resolution);
+                const int gx = x0 + tx_, gy = y0 + ty_;
+                a.out[((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z] = cls ? -f : f;
+            }
             if (cls) mxQ = max(mxQ, best); else mxF = max(mxF, best);
         } else {
             failed = true;
