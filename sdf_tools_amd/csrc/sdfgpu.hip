@@ -81,7 +81,6 @@ struct sdfgpu_context {
     bool prev_env_y = false, prev_env_x = false;
     bool fused_always = false;
     uint32_t* d_slots = nullptr;     // [kSlots][kSlotWords] extrema / flag slots of the dense kernel (kept zero between launches)
-    uint32_t* h_flags_dev = nullptr; // device-side address of h_flags
     uint32_t* h_flags = nullptr;     // pinned host copy of d_small, filled asynchronously after every build
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
@@ -376,8 +375,8 @@ int launch_pack_bits(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells
 }
 
 // Folds the per-slot maxima of the final-stage kernels launched so far into d_maxdsq[0..1] and clears the slots.
-int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s, uint32_t* report = nullptr) {
-    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_maxdsq, report);
+int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_maxdsq);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -613,14 +612,13 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                      nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s)) return rc;
         launched_since_mark = true;
     }
-    // fold the maxima; the same kernel stores the status block into pinned host memory for the next build's policy
-    const bool report = p16 && h->envelope_on && h->h_flags_dev;
-    if (int rc = fold_slots(h, h->d_small, s, report ? h->h_flags_dev : nullptr)) return rc;
+    if (int rc = fold_slots(h, h->d_small, s)) return rc;
     h->prev_env_y = env_y && !fused;
     h->prev_env_x = env_x;
     h->guard = nullptr;
     h->far_y = nullptr;
-    if (report) {
+    if (p16 && h->envelope_on && h->h_flags) {      // asynchronous read-back of the flags for the next build's policy
+        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_small, 32, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipEventRecord(h->flags_ev, s));
         h->flags_pending = true;
         h->prev_dense = dense;
@@ -746,8 +744,7 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
         delete ctx;
         return fail(nullptr, SDFGPU_ERR_HIP, "hipMalloc failed for context scratch");
     }
-    if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocMapped) != hipSuccess) ctx->h_flags = nullptr;
-    if (ctx->h_flags && hipHostGetDevicePointer((void**)&ctx->h_flags_dev, ctx->h_flags, 0) != hipSuccess) ctx->h_flags_dev = nullptr;
+    if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault) != hipSuccess) ctx->h_flags = nullptr;
     if (ctx->h_flags && hipEventCreateWithFlags(&ctx->flags_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipHostFree(ctx->h_flags);
         ctx->h_flags = nullptr;

@@ -72,12 +72,7 @@ __device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mx
     if (mxQ) atomic_max_if_larger(p + 1, (uint32_t)mxQ);
 }
 
-// `report` (optional, pinned host memory mapped into the device): the 8 status words {maxima, status, uncertified,
-// far flags, fix_needed, -} are stored there once the maxima are final, so the context's asynchronous "what did this
-// build need" read-back costs no copy operation on the stream.
-__global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
-                                                       uint32_t* __restrict__ report) {
-    __shared__ uint32_t part[2 * (kSlots / 64)];
+__global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq) {
     uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
     uint32_t f = p[0], q = p[1];
     if (f) p[0] = 0;
@@ -87,20 +82,9 @@ __global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ sl
         f = max(f, (uint32_t)__shfl_xor((int)f, off));
         q = max(q, (uint32_t)__shfl_xor((int)q, off));
     }
-    if ((threadIdx.x & 63) == 0) { part[2 * (threadIdx.x >> 6)] = f; part[2 * (threadIdx.x >> 6) + 1] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < kSlots / 64; ++w) { f = max(f, part[2 * w]); q = max(q, part[2 * w + 1]); }
+    if ((threadIdx.x & 63) == 0) {
         if (f) atomic_max_if_larger(maxdsq + 0, f);
         if (q) atomic_max_if_larger(maxdsq + 1, q);
-        if (report) {                                          // (maxdsq is then the context's 8-word status block)
-            __threadfence();
-            for (int i = 0; i < 8; ++i)
-                __hip_atomic_store(report + i, __hip_atomic_load(maxdsq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __threadfence_system();
-        }
     }
 }
 
