@@ -81,7 +81,10 @@ struct sdfgpu_context {
     bool prev_env_y = false, prev_env_x = false;
     bool fused_always = false;
     uint32_t* d_slots = nullptr;     // [kSlots][kSlotWords] extrema / flag slots of the dense kernel (kept zero between launches)
-    uint32_t* h_flags = nullptr;     // pinned host copy of d_small, filled asynchronously after every build
+    uint32_t* d_result = nullptr;    // [8] the status block of the last finished build (d_small is cleared by its fold)
+    bool small_clean = false;        // d_small is all zero (left so by the previous build's fold kernel)
+    uint32_t* h_flags_dev = nullptr; // device-side address of h_flags
+    uint32_t* h_flags = nullptr;     // pinned host copy of the status block, written by the fold kernel of every build
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
     bool prev_dense = false;
@@ -375,8 +378,8 @@ int launch_pack_bits(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells
 }
 
 // Folds the per-slot maxima of the final-stage kernels launched so far into d_maxdsq[0..1] and clears the slots.
-int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s) {
-    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_maxdsq);
+int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s, uint32_t* result = nullptr, uint32_t* report = nullptr) {
+    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_maxdsq, result, report);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -518,7 +521,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));        // [0..7]: maxima, status, uncertified, far flags, fix_needed
+    // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
+    // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
+    if (!h->small_clean || (h->have_result && s != h->last_stream)) HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
+    h->small_clean = false;
     // profiling marks: an event is recorded only behind a stage that launched something; a stage that
     // was not launched shares the previous mark (elapsed 0), so profiling adds as few packets as possible
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -612,13 +618,16 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                      nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s)) return rc;
         launched_since_mark = true;
     }
-    if (int rc = fold_slots(h, h->d_small, s)) return rc;
+    // one kernel folds the maxima, publishes the status block (device copy for get_extrema, pinned host copy for the
+    // next build's policy) and clears it for the next build
+    const bool report = p16 && h->envelope_on && h->h_flags_dev;
+    if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : nullptr)) return rc;
+    h->small_clean = true;
     h->prev_env_y = env_y && !fused;
     h->prev_env_x = env_x;
     h->guard = nullptr;
     h->far_y = nullptr;
-    if (p16 && h->envelope_on && h->h_flags) {      // asynchronous read-back of the flags for the next build's policy
-        HIP_TRY(h, hipMemcpyAsync(h->h_flags, h->d_small, 32, hipMemcpyDeviceToHost, s));
+    if (report) {
         HIP_TRY(h, hipEventRecord(h->flags_ev, s));
         h->flags_pending = true;
         h->prev_dense = dense;
@@ -740,11 +749,13 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
         delete ctx;
         return SDFGPU_ERR_HIP;
     }
-    if (hipMalloc((void**)&ctx->d_small, 256) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->d_small, 512) != hipSuccess) {
         delete ctx;
         return fail(nullptr, SDFGPU_ERR_HIP, "hipMalloc failed for context scratch");
     }
-    if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault) != hipSuccess) ctx->h_flags = nullptr;
+    ctx->d_result = ctx->d_small + 64;                       // second half of the same allocation
+    if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocMapped) != hipSuccess) ctx->h_flags = nullptr;
+    if (ctx->h_flags && hipHostGetDevicePointer((void**)&ctx->h_flags_dev, ctx->h_flags, 0) != hipSuccess) ctx->h_flags_dev = nullptr;
     if (ctx->h_flags && hipEventCreateWithFlags(&ctx->flags_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipHostFree(ctx->h_flags);
         ctx->h_flags = nullptr;
@@ -825,7 +836,7 @@ int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min) {
     if (!h->have_result) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no build has been issued on this handle");
     HIP_TRY(h, hipSetDevice(h->device));
     uint32_t v[4];
-    HIP_TRY(h, hipMemcpyAsync(v, h->d_small, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
+    HIP_TRY(h, hipMemcpyAsync(v, h->d_result, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     return sdfgpu_extrema_from_dsq(v[0], v[1], h->last_resolution, out_max, out_min);
 }
@@ -1097,7 +1108,7 @@ int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified) {
     if (!h->have_result) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no build has been issued on this handle");
     HIP_TRY(h, hipSetDevice(h->device));
     uint32_t v[8];
-    HIP_TRY(h, hipMemcpyAsync(v, h->d_small, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
+    HIP_TRY(h, hipMemcpyAsync(v, h->d_result, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     // bit 0: dense kernel decided everything; bit 1 / 2: the y / x sweep was redone by the envelope kernel
     *out_certified = ((h->last_dense && v[3] == 0) ? 1 : 0) | (v[4] ? 2 : 0) | (v[5] ? 4 : 0);

@@ -72,9 +72,17 @@ __device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mx
     if (mxQ) atomic_max_if_larger(p + 1, (uint32_t)mxQ);
 }
 
-__global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq) {
+// End-of-build form (result != nullptr; `maxdsq` is then the context's 8-word status block {maxima, status,
+// uncertified, far flags, fix_needed, -}): the final block is written to `result` (device; what get_extrema reads)
+// and to `report` (pinned host memory mapped into the device; the policy's asynchronous "what did this build need"),
+// and the status block is cleared for the next build -- one kernel instead of fold + copy kernel + fill kernel.
+__global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
+                                                       uint32_t* __restrict__ result, uint32_t* __restrict__ report) {
+    __shared__ uint32_t part[2 * (kSlots / 64)];
     uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
     uint32_t f = p[0], q = p[1];
+    uint32_t st = 0;
+    if (result && threadIdx.x < 8) st = __hip_atomic_load(maxdsq + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f) p[0] = 0;
     if (q) p[1] = 0;
 #pragma unroll
@@ -82,9 +90,21 @@ __global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ sl
         f = max(f, (uint32_t)__shfl_xor((int)f, off));
         q = max(q, (uint32_t)__shfl_xor((int)q, off));
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (f) atomic_max_if_larger(maxdsq + 0, f);
-        if (q) atomic_max_if_larger(maxdsq + 1, q);
+    if ((threadIdx.x & 63) == 0) { part[2 * (threadIdx.x >> 6)] = f; part[2 * (threadIdx.x >> 6) + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x < 8) {                                     // lanes 0..7 of wave 0: one status word each
+#pragma unroll
+        for (int w = 0; w < kSlots / 64; ++w) { f = max(f, part[2 * w]); q = max(q, part[2 * w + 1]); }
+        if (!result) {
+            if (threadIdx.x == 0 && f) atomic_max_if_larger(maxdsq + 0, f);
+            if (threadIdx.x == 1 && q) atomic_max_if_larger(maxdsq + 1, q);
+        } else {
+            if (threadIdx.x == 0) st = max(st, f);
+            if (threadIdx.x == 1) st = max(st, q);
+            result[threadIdx.x] = st;
+            if (report) __hip_atomic_store(report + threadIdx.x, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            maxdsq[threadIdx.x] = 0;
+        }
     }
 }
 
