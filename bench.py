@@ -171,12 +171,12 @@ def main():
     if not use_slab:
         ctx.get_stage_times()           # drop anything recorded so far
         # HIP events on the launch stream inside the timed region: around the dominant kernel only when the
-        # warm-up builds were dense-certified (2 events per build), around every stage otherwise
+        # warm-up builds were dense-certified (2 events on every 4th build), around every stage otherwise
         try:
             dominant_only = bool(ctx.last_path().get("dense_certified")) and not args.no_profile
         except Exception:               # no warm-up build yet
             dominant_only = False
-        ctx.set_profiling(0 if args.no_profile else (2 if dominant_only else 1))
+        ctx.set_profiling(0 if args.no_profile else (3 if dominant_only else 1))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

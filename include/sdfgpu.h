@@ -239,7 +239,8 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
  * synchronises, adds the elapsed times since the last call into out_ms_sum[7] (milliseconds),
  * returns the number of builds they cover in *out_builds and resets the accumulators.
  * enable = 2 brackets only the dominant kernel of the dense path (stage [1]; the other stages then read 0):
- * two events per build instead of five, for timed benchmark loops. */
+ * two events per build instead of five, for timed benchmark loops; enable = 3 does that on every 4th build
+ * only (out_builds then counts the sampled builds). */
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
 

@@ -271,7 +271,8 @@ class SdfGpu:
         return self.last_build_info()["fused_zy"]
 
     def set_profiling(self, enable=True):
-        """False/0 off, True/1 every stage, 2 only the dense ball kernel (two events per build)."""
+        """False/0 off, True/1 every stage, 2 only the dense ball kernel (two events per build), 3 = 2 on every
+        4th build."""
         self._check(self._lib.sdfgpu_set_profiling(self._h, int(enable)))
 
     def get_stage_times(self):

@@ -94,7 +94,9 @@ struct sdfgpu_context {
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     bool last_plane16 = false;
-    int profiling = 0;            // 0 off, 1 an event behind every stage, 2 events around the dense ball kernel only
+    int profiling = 0;            // 0 off, 1 an event behind every stage, 2 events around the dense ball kernel only,
+                                  // 3 like 2 but only on every 4th build
+    uint32_t profiled_builds = 0; // builds seen while profiling (level 3 samples every 4th)
     std::vector<hipEvent_t> event_pool;   // recycled profiling events
     std::vector<hipEvent_t> events;   // 8 per profiled build: start, after pack, ball, K1, K2/K12, KE2, K3, KE3
 };
@@ -529,9 +531,12 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // was not launched shares the previous mark (elapsed 0), so profiling adds as few packets as possible
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool launched_since_mark = true;
+    // level 3 = level 2 on every 4th build (a sampled timing costs the loop a quarter of the event overhead)
+    int prof = h->profiling;
+    if (prof == 3) prof = ((h->profiled_builds++ & 3u) == 0 && dense) ? 2 : 0;
     auto mark = [&](int k) -> hipError_t {
-        if (!h->profiling) return hipSuccess;
-        if (h->profiling == 2 && dense) {
+        if (!prof) return hipSuccess;
+        if (prof == 2 && dense) {
             // only the dominant kernel of the dense path is bracketed: stage 1 = [ev1, ev2], every other stage
             // shares a mark with its neighbour (elapsed 0)
             if (k == 0) return hipSuccess;
@@ -632,7 +637,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->flags_pending = true;
         h->prev_dense = dense;
     }
-    if (h->profiling) {
+    if (prof) {
         HIP_TRY(h, mark(7));
         for (auto e : ev) h->events.push_back(e);
     }
@@ -1045,7 +1050,8 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n) {
 
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
-    h->profiling = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+    h->profiling = enable < 0 ? 0 : (enable > 3 ? 1 : enable);
+    h->profiled_builds = 0;
     return SDFGPU_OK;
 }
 
