@@ -232,13 +232,13 @@ class SlabSdfBuilder:
         self._builds += 1
         slot.reduce_deferred = True
 
-    def _flush_deferred(self, exclude=None):
+    def _flush_deferred(self, exclude=None, only=None):
         """Issue the status all-reduce (+ copy to pinned host memory) of every build that still owes one.
         It is deferred until the NEXT build has posted its halo exchange, so that on the communicator's
         stream the latency-critical exchange is never queued behind the previous build's all-reduce; every
         rank defers identically, so the collective order stays the same everywhere."""
         for slot in self.slots:
-            if slot is exclude or not slot.reduce_deferred:
+            if slot is exclude or (only is not None and slot is not only) or not slot.reduce_deferred:
                 continue
             slot.reduce_deferred = False
             work = self._allreduce_small(slot.small, async_op=True)
@@ -349,7 +349,7 @@ class SlabSdfBuilder:
         assert slot.pending
         need_general = True
         if slot.dense:
-            self._flush_deferred()               # no later build posted it for us (e.g. build(), last step)
+            self._flush_deferred(only=slot)      # no later build posted it for us (e.g. build(), last step)
             if slot.event is not None:
                 slot.event.synchronize()
             max_f, max_q, _, uncert = (int(v) for v in slot.host.tolist())
