@@ -291,6 +291,18 @@ def main():
         result["config"]["whole_line_fallbacks"] = builder.fallbacks
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_slab:
+        # what a caller of the reference's C++ API sees: host mask -> host SDF through sdfgpu_build (PCIe both ways,
+        # fresh output buffer).  Reported for context only -- never `value`.
+        host_mask = mask.cpu().numpy()
+        ctx.build(host_mask, res)
+        t_host = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            ctx.build(host_mask, res)
+            t_host.append(time.perf_counter() - t1)
+        result["host_api"] = {"call": "sdfgpu_build (host -> host, PCIe inclusive)", "ms": round(min(t_host) * 1e3, 2),
+                              "Mvoxels_per_s": round(n_total / min(t_host) / 1e6, 1),
+                              "note": "includes numpy output allocation; not the benchmark metric"}
         result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.p, res)
     if rank == 0:
         print(json.dumps(result))
