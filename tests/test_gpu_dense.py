@@ -177,3 +177,40 @@ def test_fixup_kernel_edges_and_every_shape(gpu):
             ex, ex_ext, _ = O.exact_sdf(m, 0.3)
             assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)), shape
             assert ext == ex_ext
+
+
+def test_profiling_levels_and_stage_entry_points_fold(gpu):
+    """Profiling levels 1 / 2 / 3 (every stage / ball kernel only / ball kernel on every 4th build) and the deferred
+    fold of the stage entry points."""
+    import torch
+    shape = (32, 32, 64)
+    m = torch.from_numpy(synth.bernoulli_mask(shape, 0.5, 2)).cuda()
+    out = torch.empty(shape, dtype=torch.float32, device="cuda")
+
+    def run(n):
+        for _ in range(n):
+            gpu.build_device(m.data_ptr(), shape, out.data_ptr(), 0.1, False, torch.cuda.current_stream().cuda_stream)
+    run(2)
+    gpu.get_stage_times()
+    for level, builds in ((1, 8), (2, 8), (3, 2)):
+        gpu.set_profiling(level)
+        run(8)
+        ms, n = gpu.get_stage_times()
+        assert n == builds and ms[1] > 0.0                  # the ball kernel is timed at every level
+        assert (ms[0] > 0.0) == (level == 1)                # the pack kernel only at level 1
+    gpu.set_profiling(0)
+    # stage entry points: with "defer_fold" the maxima stay in the slot array until sdfgpu_fold_extrema_device
+    bits = torch.zeros((shape[0], shape[1], shape[2] // 32), dtype=torch.int32, device="cuda")
+    small = torch.zeros(4, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    gpu.pack_bits_device(m.data_ptr(), shape[0] * shape[1], shape[2], bits.data_ptr(), s)
+    gpu.set_option("defer_fold", 1)
+    gpu.dense_ball_device(bits.data_ptr(), shape[0], 0, shape[0], shape[1], shape[2], 0.1, out.data_ptr(), small.data_ptr(),
+                          small.data_ptr() + 12, s)
+    assert small.tolist()[:2] == [0, 0]
+    gpu.fold_extrema_device(small.data_ptr(), s)
+    gpu.set_option("defer_fold", 0)
+    mf, mq, _, unc = small.tolist()
+    want, want_ext, dsq = O.exact_sdf(m.cpu().numpy(), 0.1)
+    assert unc == 0 and mf == int(dsq.max()) and mq == int(-dsq.min())
+    assert np.array_equal(out.cpu().numpy(), want)
