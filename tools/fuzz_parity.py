@@ -25,6 +25,8 @@ while time.time() - t0 < budget:
     shape = tuple(int(rng.choice(sizes)) for _ in range(3))
     if rng.random() < 0.5:
         shape = shape[:2] + (int(rng.choice([32, 64, 128, 256])),)        # dense-path eligible z extents
+    if rng.random() < 0.08:                                              # wide rows: other tile shapes / expansion paths
+        shape = (int(rng.choice([1, 2, 5, 9, 17])), int(rng.choice([1, 3, 8, 20])), int(rng.choice([512, 1024, 2048])))
     if np.prod(shape) > 1 << 21:
         continue
     kind = rng.integers(0, 4)
