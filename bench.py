@@ -265,6 +265,10 @@ def main():
                 "alg_bytes_per_voxel": B_ALG[dom], "design_bytes_per_voxel": B_DESIGN[dom],
                 "avg_ms": round(stage_ms[dom], 4),
                 "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                "note": ("achieved = SURVEY 8(d) algorithmic bytes of the separable formulation attributed to this kernel "
+                         "x voxels / its HIP-event duration; a bit-parallel kernel moves far fewer bytes than that "
+                         "(design_bytes_per_voxel), so frac can exceed 1 -- hbm_frac_traffic = measured PMC bytes "
+                         "(traffic, from profiles/) / duration / peak is the hardware utilisation"),
                 "pipeline": {"alg_bytes_per_voxel": B_ALG_TOTAL, "kernel_ms": round(kernel_ms, 4),
                              "achieved": round(n_total * B_ALG_TOTAL / (kernel_ms * 1e-3) / 1e9, 1),
                              "frac": round(n_total * B_ALG_TOTAL / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
