@@ -180,6 +180,19 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
  * "defer_fold" = 1 and fold once itself: */
 int sdfgpu_fold_extrema_device(sdfgpu_handle h, uint32_t* d_maxdsq, void* stream);
 
+/* One x slab of the dense path in three calls (the same kernels as the stage entry points above, fewer host
+ * round trips per build).  d_bits_ext: [halo_lo + nxs + halo_hi][ny][nz/32] with halo_lo / halo_hi = 0 or 2 planes
+ * the caller fills by exchanging boundary planes; d_small: 4 words {max d^2 free, max d^2 filled, -, uncertified}.
+ *   phase 0   clear d_small, pack the boundary planes (everything if the slab has no neighbour or is too thin)
+ *             -> the caller posts the halo exchange of the 2 + 2 boundary bit-planes
+ *   phase 1   pack the interior, ball kernel on the planes that need no neighbour data (10 / 11: only the first /
+ *             second of the two)
+ *   phase 2   (after the exchange has completed) ball kernel on the border planes, fold of the maxima */
+int sdfgpu_slab_dense_phase(sdfgpu_handle h, int phase, const uint8_t* d_mask_slab,
+                            int64_t nxs, int64_t ny, int64_t nz,
+                            uint32_t* d_bits_ext, int64_t halo_lo, int64_t halo_hi,
+                            double resolution, float* d_out_sdf, uint32_t* d_small, void* stream);
+
 /* (max, min) from the two integer maxima (0 = class absent, >= SDFGPU_DSQ_INF =
  * infinite), reproducing sdf_generation.hpp:246-269 / :416-418. */
 int sdfgpu_extrema_from_dsq(uint32_t max_dsq_free, uint32_t max_dsq_filled,

@@ -22,7 +22,7 @@ EXPORTS = [
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
-    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device",
+    "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
 ]
 
 
@@ -65,6 +65,7 @@ def load_library():
     L.sdfgpu_build_tagged_cells.argtypes = [vp, vp, sz, sz, sz, ci, vp, i64, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_query_points_device.argtypes = [vp, vp, i64, i64, i64, dbl, vp, vp, ctypes.c_float, vp, i64, ci, vp, vp, vp, vp]
     L.sdfgpu_fold_extrema_device.argtypes = [vp, vp, vp]
+    L.sdfgpu_slab_dense_phase.argtypes = [vp, ci, vp, i64, i64, i64, vp, i64, i64, dbl, vp, vp, vp]
     L.sdfgpu_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
@@ -184,6 +185,12 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_query_points_device(
             self._h, d_sdf, nx, ny, nz, float(resolution), w, r, float(oob_value), d_points, int(n_points),
             int(bool(enable_edge_gradients)), d_distance or None, d_gradient or None, d_flags or None, stream or None))
+
+    def slab_dense_phase(self, phase, d_mask_slab, nxs, ny, nz, d_bits_ext, halo_lo, halo_hi, resolution, d_out, d_small,
+                         stream=0):
+        self._check(self._lib.sdfgpu_slab_dense_phase(self._h, int(phase), d_mask_slab, int(nxs), int(ny), int(nz), d_bits_ext,
+                                                      int(halo_lo), int(halo_hi), float(resolution), d_out, d_small,
+                                                      stream or None))
 
     def fold_extrema_device(self, d_maxdsq, stream=0):
         self._check(self._lib.sdfgpu_fold_extrema_device(self._h, d_maxdsq, stream or None))

@@ -905,6 +905,63 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
     return h->defer_fold ? SDFGPU_OK : fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
 
+// One x slab of the dense path in three host calls instead of ten (the per-call cost of the Python binding is what
+// limits a rank at ~0.15 ms per build): phase 0 = clear the status words + pack the boundary planes (the caller then
+// posts the halo exchange), phase 1 = pack the interior + ball kernel on every plane that needs no neighbour data
+// (10 / 11 = only the first / second half of that), phase 2 = ball kernel on the border planes + fold of the maxima
+// (after the exchange has been waited for).  Without neighbours, or for slabs too thin to split, phase 0 packs
+// everything, phase 1 does nothing and phase 2 runs the ball kernel on the whole slab.
+int sdfgpu_slab_dense_phase(sdfgpu_handle h, int phase, const uint8_t* d_mask_slab, int64_t nxs, int64_t ny, int64_t nz,
+                            uint32_t* d_bits_ext, int64_t halo_lo, int64_t halo_hi, double resolution, float* d_out,
+                            uint32_t* d_small, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_mask_slab || !d_bits_ext || !d_out || !d_small) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    const int64_t hb = kBallR;
+    if (nxs <= 0 || (halo_lo != 0 && halo_lo != hb) || (halo_hi != 0 && halo_hi != hb))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "inconsistent slab geometry");
+    if (int rc = check_dims(h, halo_lo + nxs + halo_hi, ny, nz)) return rc;
+    if (!dense_eligible(h, nz, 0)) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense kernel needs nz = 32 * 2^k <= 2048");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t plane = ny * nz, wplane = ny * (nz / 32), rows_x = halo_lo + nxs + halo_hi;
+    uint32_t* own = d_bits_ext + halo_lo * wplane;
+    const bool split = (halo_lo || halo_hi) && 4 * hb < nxs;
+    const int64_t i_lo = (split && halo_lo) ? hb : 0, i_hi = (split && halo_hi) ? nxs - hb : nxs;
+    auto pack = [&](int64_t p0, int64_t p1) -> int {
+        if (p1 <= p0) return SDFGPU_OK;
+        return launch_pack_bits(h, d_mask_slab + p0 * plane, nullptr, 0, 0, 0, (p1 - p0) * plane, own + p0 * wplane, s);
+    };
+    auto ball = [&](int64_t p0, int64_t p1) -> int {
+        if (p1 <= p0) return SDFGPU_OK;
+        return launch_ball_dense(h, d_bits_ext, d_out + p0 * plane, rows_x, halo_lo + p0, halo_lo + p1, ny, nz, resolution,
+                                 d_small, d_small + 3, s);
+    };
+    switch (phase) {
+    case 0:
+        HIP_TRY(h, hipMemsetAsync(d_small, 0, 16, s));
+        if (!split) return pack(0, nxs);
+        if (int rc = pack(0, hb)) return rc;
+        return pack(nxs - hb, nxs);
+    case 1:
+    case 10:
+    case 11:
+        if (!split) return SDFGPU_OK;
+        if (phase != 11) if (int rc = pack(hb, nxs - hb)) return rc;
+        if (phase != 10) if (int rc = ball(i_lo, i_hi)) return rc;
+        return SDFGPU_OK;
+    case 2:
+        if (!split) {
+            if (int rc = ball(0, nxs)) return rc;
+        } else {
+            if (int rc = ball(0, i_lo)) return rc;
+            if (int rc = ball(i_hi, nxs)) return rc;
+        }
+        return fold_slots(h, d_small, s);
+    default:
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown phase %d", phase);
+    }
+}
+
 int sdfgpu_fold_extrema_device(sdfgpu_handle h, uint32_t* d_maxdsq, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!d_maxdsq) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");

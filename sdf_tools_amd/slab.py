@@ -71,6 +71,12 @@ class HipStages:
         self.ctx.sweep_x_device(ext.data_ptr(), halo_lo, nxs, halo_hi, ny, nz, lo_trunc, hi_trunc, x_global,
                                 nx_global, resolution, vb, out.data_ptr(), base, base + 8, self.stream())
 
+    def dense_phase(self, phase, mask_slab, bits_ext, halo_lo, halo_hi, resolution, out, small, stream=None):
+        """One of the three native phases of a dense slab build (see sdfgpu_slab_dense_phase in include/sdfgpu.h)."""
+        nxs, ny, nz = mask_slab.shape
+        self.ctx.slab_dense_phase(phase, mask_slab.data_ptr(), nxs, ny, nz, bits_ext.data_ptr(), halo_lo, halo_hi,
+                                  resolution, out.data_ptr(), small.data_ptr(), self.stream() if stream is None else stream)
+
     def fold(self, small):
         """Fold the maxima the stage kernels left in the context's slot array into small[0:2]."""
         self.ctx.fold_extrema_device(small.data_ptr(), self.stream())
@@ -184,6 +190,8 @@ class SlabSdfBuilder:
 
     # -- dense path --------------------------------------------------------------------------------
     def _enqueue_dense(self, mask_slab, slot):
+        if hasattr(self.stages, "dense_phase"):
+            return self._enqueue_dense_native(mask_slab, slot)
         n, lo, h = self.nxs, self.bh_lo, BALL_HALO
         own = self.bits[lo:lo + n]
         slot.small.zero_()
@@ -198,15 +206,8 @@ class SlabSdfBuilder:
             self.stages.pack_bits(mask_slab[h:n - h], own[h:n - h])
             i_lo = h if self.bh_lo else 0
             i_hi = n - h if self.bh_hi else n
-            timed = self._timing_every > 0 and self._builds % self._timing_every == 0
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             self.stages.dense_ball(self.bits, lo + i_lo, lo + i_hi, self.nz, self.resolution, slot.out[i_lo:i_hi],
                                    slot.small)
-            if timed:
-                e1.record()
-                self._timings.append((e0, e1, (i_hi - i_lo) * self.ny * self.nz))
             for w in works:
                 w.wait()
             if i_lo:
@@ -219,16 +220,45 @@ class SlabSdfBuilder:
             self._flush_deferred(exclude=slot)
             for w in works:
                 w.wait()
-            timed = self._timing_every > 0 and self._builds % self._timing_every == 0
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             self.stages.dense_ball(self.bits, lo, lo + n, self.nz, self.resolution, slot.out, slot.small)
-            if timed:
-                e1.record()
-                self._timings.append((e0, e1, n * self.ny * self.nz))
         if hasattr(self.stages, "fold"):
             self.stages.fold(slot.small)
+        self._builds += 1
+        slot.reduce_deferred = True
+
+    def _enqueue_dense_native(self, mask_slab, slot):
+        """The same schedule through the three native phases (3 host calls per build instead of ~10: at 0.15 ms of
+        GPU work per build the binding's per-call cost decides whether a rank stays GPU-bound)."""
+        st = self.stages
+        stream = st.stream()
+        args = (mask_slab, self.bits, self.bh_lo, self.bh_hi, self.resolution, slot.out, slot.small, stream)
+        st.dense_phase(0, *args)                    # clear the status words, pack the boundary planes
+        works = self._exchange(self.bits, self.bh_lo, self.nxs, BALL_HALO)
+        self._flush_deferred(exclude=slot)          # previous build's all-reduce goes behind this exchange
+        timed = self._timing_every > 0 and self._builds % self._timing_every == 0
+        if timed:                                   # events around the ball kernel of the interior planes only
+            st.dense_phase(10, *args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st.dense_phase(11, *args)
+            e1.record()
+            split = (self.bh_lo or self.bh_hi) and 4 * BALL_HALO < self.nxs
+            i_lo = BALL_HALO if (split and self.bh_lo) else 0
+            i_hi = self.nxs - BALL_HALO if (split and self.bh_hi) else self.nxs
+            if split:
+                self._timings.append((e0, e1, (i_hi - i_lo) * self.ny * self.nz))
+        else:
+            st.dense_phase(1, *args)                # pack the interior, ball kernel where no neighbour data is needed
+        for w in works:
+            w.wait()
+        if timed and not ((self.bh_lo or self.bh_hi) and 4 * BALL_HALO < self.nxs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st.dense_phase(2, *args)                # unsplit slab: the whole ball kernel (+ fold) is in this phase
+            e1.record()
+            self._timings.append((e0, e1, self.nxs * self.ny * self.nz))
+        else:
+            st.dense_phase(2, *args)                # border planes + fold of the maxima
         self._builds += 1
         slot.reduce_deferred = True
 

@@ -212,3 +212,50 @@ def test_gradient_matches_reference_definition(gpu):
     g2 = torch.empty((20, 40, 1, 3), dtype=torch.float64, device="cuda")
     gpu.gradient_device(f2.data_ptr(), (20, 40, 1), g2.data_ptr(), 0.05, True, True)
     np.testing.assert_allclose(g2[4, 1, 0].cpu().numpy(), [1.5, 0.0, 0.0], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_native_dense_phases_on_slabs(gpu, world):
+    """sdfgpu_slab_dense_phase: the three-call schedule of a dense slab build, one GPU playing every rank (the halo
+    planes are copied between the ranks' buffers where the bit-plane exchange would run)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    stages = slab.HipStages(0)
+    shape = (36, 24, 64)
+    nx, ny, nz = shape
+    h = slab.BALL_HALO
+    m = synth.bernoulli_mask(shape, 0.5, 8)
+    want, want_ext = O.reference_sdf(m, 0.5)
+    ranks = []
+    for r in range(world):
+        a, b = slab.slab_range(nx, r, world)
+        lo = h if r > 0 else 0
+        hi = h if r < world - 1 else 0
+        ranks.append(dict(a=a, b=b, lo=lo, hi=hi, mask=torch.from_numpy(m[a:b]).to(dev),
+                          bits=torch.zeros((lo + b - a + hi, ny, nz // 32), dtype=torch.int32, device=dev),
+                          out=torch.empty((b - a, ny, nz), dtype=torch.float32, device=dev),
+                          small=torch.full((4,), 7, dtype=torch.int32, device=dev)))
+    for k in ranks:                                             # phase 0 everywhere, then "exchange"
+        stages.dense_phase(0, k["mask"], k["bits"], k["lo"], k["hi"], 0.5, k["out"], k["small"])
+    for r, k in enumerate(ranks):
+        n = k["b"] - k["a"]
+        if k["lo"]:
+            p = ranks[r - 1]
+            k["bits"][:h] = p["bits"][p["lo"] + (p["b"] - p["a"]) - h:p["lo"] + (p["b"] - p["a"])]
+        if k["hi"]:
+            q = ranks[r + 1]
+            k["bits"][k["lo"] + n:] = q["bits"][q["lo"]:q["lo"] + h]
+    out = np.empty(shape, np.float32)
+    small_all = np.zeros(4, np.int64)
+    for r, k in enumerate(ranks):
+        if r % 2:                                               # both forms of phase 1
+            stages.dense_phase(10, k["mask"], k["bits"], k["lo"], k["hi"], 0.5, k["out"], k["small"])
+            stages.dense_phase(11, k["mask"], k["bits"], k["lo"], k["hi"], 0.5, k["out"], k["small"])
+        else:
+            stages.dense_phase(1, k["mask"], k["bits"], k["lo"], k["hi"], 0.5, k["out"], k["small"])
+        stages.dense_phase(2, k["mask"], k["bits"], k["lo"], k["hi"], 0.5, k["out"], k["small"])
+        out[k["a"]:k["b"]] = k["out"].cpu().numpy()
+        small_all = np.maximum(small_all, k["small"].cpu().numpy())
+    assert small_all[3] == 0 and small_all[2] == 0
+    assert np.array_equal(out, want)
+    assert capi.extrema_from_dsq(int(small_all[0]), int(small_all[1]), 0.5) == want_ext
