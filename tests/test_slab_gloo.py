@@ -102,6 +102,45 @@ class OracleStages:
         small[2] = max(int(small[2]), status)
 
 
+class OraclePhaseStages(OracleStages):
+    """Adds the contract of sdfgpu_slab_dense_phase (three calls per dense slab build), so the builder takes the
+    same code path it takes with HipStages on the GPUs."""
+
+    def stream(self):
+        return None
+
+    def dense_phase(self, phase, mask_slab, bits_ext, halo_lo, halo_hi, res, out, small, stream=None):
+        h = slab.BALL_HALO
+        n, ny, nz = mask_slab.shape
+        own = bits_ext[halo_lo:halo_lo + n]
+        split = (halo_lo or halo_hi) and 4 * h < n
+        i_lo = h if (split and halo_lo) else 0
+        i_hi = n - h if (split and halo_hi) else n
+        if phase == 0:
+            small.zero_()
+            if not split:
+                self.pack_bits(mask_slab, own)
+            else:
+                self.pack_bits(mask_slab[:h], own[:h])
+                self.pack_bits(mask_slab[n - h:], own[n - h:])
+        elif phase in (1, 10, 11):
+            if split:
+                if phase != 11:
+                    self.pack_bits(mask_slab[h:n - h], own[h:n - h])
+                if phase != 10:
+                    self.dense_ball(bits_ext, halo_lo + i_lo, halo_lo + i_hi, nz, res, out[i_lo:i_hi], small)
+        elif phase == 2:
+            if not split:
+                self.dense_ball(bits_ext, halo_lo, halo_lo + n, nz, res, out, small)
+            else:
+                if i_lo:
+                    self.dense_ball(bits_ext, halo_lo, halo_lo + i_lo, nz, res, out[:i_lo], small)
+                if i_hi < n:
+                    self.dense_ball(bits_ext, halo_lo + i_hi, halo_lo + n, nz, res, out[i_hi:], small)
+        else:
+            raise ValueError(phase)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -110,14 +149,15 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, p, seed, res, vb, halo, q, dense=False, steps=1):
+def _worker(rank, world, port, shape, p, seed, res, vb, halo, q, dense=False, steps=1, phases=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         x0, x1 = slab.slab_range(shape[0], rank, world)
         mask = torch.from_numpy(synth.bernoulli_mask(shape, p, seed, x_range=(x0, x1)))
-        b = slab.SlabSdfBuilder(OracleStages(), shape, res, vb, halo=halo, rank=rank, world=world, dense=dense)
+        b = slab.SlabSdfBuilder(OraclePhaseStages() if phases else OracleStages(), shape, res, vb, halo=halo, rank=rank,
+                                world=world, dense=dense)
         if steps == 1:
             sdf, ext = b.build(mask)
         else:                                   # pipelined use: validate one build behind
@@ -133,11 +173,11 @@ def _worker(rank, world, port, shape, p, seed, res, vb, halo, q, dense=False, st
         dist.destroy_process_group()
 
 
-def _run(world, shape, p, seed, res=1.0, vb=False, halo=4, dense=False, steps=1):
+def _run(world, shape, p, seed, res=1.0, vb=False, halo=4, dense=False, steps=1, phases=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, p, seed, res, vb, halo, q, dense, steps))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, p, seed, res, vb, halo, q, dense, steps, phases))
              for r in range(world)]
     for pr in procs:
         pr.start()
@@ -216,3 +256,19 @@ def test_slab_range_covers_grid():
             r = [slab.slab_range(nx, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == nx
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+
+
+def test_dense_path_through_the_native_phase_schedule():
+    """The code path the GPUs take: three dense_phase calls per build around the exchange and its wait, pipelined
+    builds, split and unsplit slabs, and the collective fall-back when a rank stays uncertified."""
+    for world, shape in ((2, (24, 9, 32)), (3, (36, 6, 64)), (3, (20, 6, 64))):
+        m = synth.bernoulli_mask(shape, 0.5, 4)
+        got, ext, (fallbacks, general, dense) = _run(world, shape, 0.5, 4, res=0.25, dense=True, steps=3, phases=True)
+        assert dense and general == 0 and fallbacks == 0
+        want, want_ext = O.reference_sdf(m, 0.25)
+        assert np.array_equal(got, want) and ext == want_ext
+    shape = (24, 8, 32)
+    got, ext, (fallbacks, general, dense) = _run(2, shape, 0.004, 5, halo=2, dense=True, steps=2, phases=True)
+    want, want_ext, _ = O.exact_sdf(synth.bernoulli_mask(shape, 0.004, 5), 1.0)
+    assert dense and general == 2
+    assert np.array_equal(got, want) and ext == want_ext
