@@ -32,8 +32,11 @@ def _hipcc():
 
 
 def build_libsdfgpu(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, "sdfgpu.hip"), os.path.join(CSRC, "sdfgpu_kernels.hpp"),
-            os.path.join(INCLUDE, "sdfgpu.h")]
+    # the translation unit first, then EVERY header it includes (a stale library after a header-only edit is the
+    # kind of bug that invalidates measurements without failing anything)
+    srcs = [os.path.join(CSRC, "sdfgpu.hip")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("sdfgpu") and f.endswith(".hpp")) + [
+        os.path.join(INCLUDE, "sdfgpu.h")]
     if not force and not _newer(LIB, srcs):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",

@@ -93,6 +93,8 @@ struct sdfgpu_context {
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
+    int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
+    bool wide_y = false, wide_x = false;   // policy: radius-8 windows for the next build's y / x marching sweep
     bool last_plane16 = false;
     int profiling = 0;            // 0 off, 1 an event behind every stage, 2 events around the dense ball kernel only,
                                   // 3 like 2 but only on every 4th build
@@ -181,7 +183,7 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
 
 int pick_T(int user, int span) {
     int T = user > 0 ? user : 64;
-    T = std::max(T, 2 * kH + 1);
+    T = std::max(T, 2 * 8 + 1);
     return std::min(T, std::max(span, 1));
 }
 
@@ -192,7 +194,15 @@ int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s) {
     const int64_t nbx = (a.ncols + kBlock - 1) / kBlock;
     if (nbx > 0x7fffffffLL || nchunks > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "sweep grid too large");
     dim3 grid((unsigned)nbx, (unsigned)nchunks), block(kBlock);
-    if (vec4) hipLaunchKernelGGL((k_sweep_march<STAGE, 4, kH, VB>), grid, block, 0, s, a);
+    bool wide = false;
+    if constexpr (STAGE == 2 && !VB) {                       // radius-8 window: y sweep only
+        if (vec4 && (h->march_h == 8 || h->wide_y)) {
+            hipLaunchKernelGGL((k_sweep_march<2, 4, 8, false>), grid, block, 0, s, a);
+            wide = true;
+        }
+    }
+    if (wide) {}
+    else if (vec4) hipLaunchKernelGGL((k_sweep_march<STAGE, 4, kH, VB>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_march<STAGE, 1, kH, VB>), grid, block, 0, s, a);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
@@ -295,6 +305,8 @@ int launch_sweep_x16(sdfgpu_handle h, const int16_t* d_in16, const int32_t* d_si
     const bool slab = lo_trunc || hi_trunc || side_lo > 0 || side_hi < a.L;
     if (V == 8) launch_x16_variant<8, 3>(a, grid, block, vb != 0, slab, s);
     else if (h->x16_h == 2) launch_x16_variant<4, 2>(a, grid, block, vb != 0, slab, s);
+    else if ((h->x16_h == 8 || (h->x16_h == 3 && h->wide_x)) && !vb && !slab)      // wide window: plain grids only
+        hipLaunchKernelGGL((k_sweep_x16<4, 8, false, false>), grid, block, 0, s, a);
     else launch_x16_variant<4, 3>(a, grid, block, vb != 0, slab, s);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
@@ -504,6 +516,16 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         }
         if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on))
             h->dense_skip = h->dense_retry - 1;
+        //   mid-sparse scenes (largest squared distance beyond the radius-3 window's 16): radius-8 register windows
+        //   decide most voxels without the outward scan (measured at 512^3: y sweep 0.96 -> 0.53 ms at p = 0.02,
+        //   x sweep 1.22 -> 0.60 ms at p = 0.01; the wider x window only pays from ~128 upward)
+        if (general_ran) {
+            const uint32_t md = std::max(h->h_flags[0], h->h_flags[1]);
+            h->wide_y = md > 16u && md < (uint32_t)kInf32;
+            h->wide_x = md >= 128u && md < (uint32_t)kInf32;
+        } else {
+            h->wide_y = h->wide_x = false;
+        }
         if (general_ran) {
             const uint32_t max_d = std::max(h->h_flags[0], h->h_flags[1]);
             const bool near = max_d <= (uint32_t)(kScanExpectNear * kScanExpectNear);
@@ -1149,13 +1171,14 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
     else if (n == "ball_variant") h->ball_variant = value;
-    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; h->fix_mode = false; }
+    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; h->fix_mode = false; h->wide_y = h->wide_x = false; }
     else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; }
     else if (n == "fixup_mode") h->fix_mode = value != 0;
     else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; }
     else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; }
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
+    else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return SDFGPU_OK;
 }
