@@ -45,8 +45,35 @@ struct EnvArgs {
     const uint32_t* guard;    // run only if *guard != 0
 };
 
+// vmcnt counts loads and stores alike and the compiler cannot count the stores of a data-dependent loop, so ANY
+// global load whose result is used inside the push / pop loop costs an s_waitcnt vmcnt(0) there -- which also
+// waits for the scratch store of the site pushed just before: one full memory round trip per site, strictly
+// serial.  Therefore the hot loops below never consume a global load:
+//   forward   the top kEnvRing entries of a lane's stack are mirrored in an LDS ring (slot = depth mod kEnvRing)
+//             and pops read only LDS; if a pop sequence runs below the ring, a refill copies the next
+//             kEnvRing / 2 older entries from the scratch into the ring;
+//   backward  the next kEnvWin parabolas are fetched with independent loads once per batch of positions into a
+//             register window that is shifted on every advance; running out of it mid-batch is the rare case.
+// The rare paths load through inline assembly that carries its own wait, so the compiler does not see a pending
+// load and puts no conservative wait into the hot loops.
+constexpr int kEnvRing = 16;
+constexpr int kEnvWin = 8;
+
+__device__ __forceinline__ int2 env_load_waited(const int2* p) {
+    int2 e;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(e) : "v"(p) : "memory");
+    return e;
+}
+__device__ __forceinline__ void env_ring_refill(int2* ring_lane, const int2* scratch_lane, int64_t nl, int i) {
+    for (int c = 0; c < kEnvRing / 2; ++c) {
+        const int d = i - c;
+        if (d >= 0) ring_lane[(d & (kEnvRing - 1)) * kBlock] = env_load_waited(scratch_lane + (int64_t)d * nl);
+    }
+}
+
 template <int STAGE>
 __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
+    __shared__ int2 ring[kEnvRing * kBlock];
     if (a.guard && *a.guard == 0u) return;
     int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool valid = t < a.nlines;
@@ -83,8 +110,10 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
         // objects in free space) skips it entirely
         if (cls == 1 && !has_filled) break;
         // ---- forward: build the envelope -------------------------------------------------------------
-        int k = -1;
+        int k = -1, lo = 0;                     // stack top; lowest depth whose ring slot is current
         int vt = 0, At = 0, vs = 0, As = 0;     // top and second entry (copies of scratch[k], scratch[k-1])
+        int2* const ring_lane = ring + threadIdx.x;
+        const int2* const scratch_lane = a.scratch + t;
         int sv[CH], sn[CH];                     // current batch and the one in flight behind it
         // Site pruning.  The voxels that ARE the sought class have value 0, and along a line only the two ends
         // of a run of them can ever be nearest to a voxel outside the run: (p - end)^2 < (p - interior)^2.
@@ -118,36 +147,65 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
                     const int Aq = val + q * q;
                     while (k >= 1 && (int64_t)(Aq - At) * (vt - vs) <= (int64_t)(At - As) * (q - vt)) {
                         --k; vt = vs; At = As;
-                        if (k >= 1) { const int2 e = a.scratch[(int64_t)(k - 1) * nl + t]; vs = e.x; As = e.y; }
+                        if (k >= 1) {
+                            const int i = k - 1;
+                            if (i < lo) {                       // rare: popped below the ring
+                                env_ring_refill(ring_lane, scratch_lane, nl, i);
+                                lo = max(0, i - kEnvRing / 2 + 1);
+                            }
+                            const int2 e = ring_lane[(i & (kEnvRing - 1)) * kBlock];
+                            vs = e.x; As = e.y;
+                        }
                     }
                     ++k;
                     a.scratch[(int64_t)k * nl + t] = make_int2(q, Aq);
+                    ring_lane[(k & (kEnvRing - 1)) * kBlock] = make_int2(q, Aq);
+                    lo = max(lo, k - kEnvRing + 1);
                     vs = vt; As = At; vt = q; At = Aq;
                 }
             }
             sprev = sv[CH - 1];
         }
         // ---- backward: evaluate on the voxels that need this class --------------------------------------
-        int j = 0, v0 = 0, A0 = 0, v1 = 0, A1 = 0;
+        int j = 0, v0 = 0, A0 = 0;               // current parabola = entry j
+        int wv[kEnvWin], wA[kEnvWin];            // entries j+1 .. j+kEnvWin; navail of them are loaded
+        int navail = 0;
         if (k >= 0) { const int2 e = a.scratch[t]; v0 = e.x; A0 = e.y; }
-        if (k >= 1) { const int2 e = a.scratch[nl + t]; v1 = e.x; A1 = e.y; }
+#pragma unroll
+        for (int i = 0; i < kEnvWin; ++i) { wv[i] = 0; wA[i] = 0; }
         int16_t rawv[CH], rawn[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) rawn[u] = (u < L) ? a.in16[base + (int64_t)u * ls] : (int16_t)0;
+        for (int u = 0; u < CH; ++u) rawn[u] = a.in16[base + (int64_t)min(u, L - 1) * ls];
         for (int p0 = 0; p0 < L; p0 += CH) {
 #pragma unroll
             for (int u = 0; u < CH; ++u) rawv[u] = rawn[u];
-            if (p0 + CH < L) {
 #pragma unroll
-                for (int u = 0; u < CH; ++u) rawn[u] = (p0 + CH + u < L) ? a.in16[base + (int64_t)(p0 + CH + u) * ls] : (int16_t)0;
+            for (int u = 0; u < CH; ++u) rawn[u] = a.in16[base + (int64_t)min(p0 + CH + u, L - 1) * ls];
+            // top the window up: independent, unconditional loads (clamped depth), waited for once per batch
+            {
+                int2 e[kEnvWin];
+#pragma unroll
+                for (int i = 0; i < kEnvWin; ++i) e[i] = a.scratch[(int64_t)max(0, min(j + 1 + i, k)) * nl + t];
+#pragma unroll
+                for (int i = 0; i < kEnvWin; ++i) {
+                    if (i >= navail) { wv[i] = e[i].x; wA[i] = e[i].y; }
+                }
             }
+            navail = max(0, min(kEnvWin, k - j));
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int p = p0 + u;
                 if (p >= L) break;
-                while (j < k && (int64_t)(A1 - A0) <= (int64_t)2 * p * (v1 - v0)) {
-                    ++j; v0 = v1; A0 = A1;
-                    if (j < k) { const int2 e = a.scratch[(int64_t)(j + 1) * nl + t]; v1 = e.x; A1 = e.y; }
+                while (j < k && (int64_t)(wA[0] - A0) <= (int64_t)2 * p * (wv[0] - v0)) {
+                    ++j; v0 = wv[0]; A0 = wA[0];
+#pragma unroll
+                    for (int i = 0; i + 1 < kEnvWin; ++i) { wv[i] = wv[i + 1]; wA[i] = wA[i + 1]; }
+                    --navail;
+                    if (navail == 0 && j < k) {               // rare: window exhausted inside a batch
+                        const int2 e = env_load_waited(scratch_lane + (int64_t)(j + 1) * nl);
+                        wv[0] = e.x; wA[0] = e.y;
+                        navail = 1;
+                    }
                 }
                 const bool filled = rawv[u] < 0;
                 if ((cls == 0) == filled) continue;                  // this voxel belongs to the other pass
