@@ -57,7 +57,13 @@ struct EnvArgs {
 // The rare paths load through inline assembly that carries its own wait, so the compiler does not see a pending
 // load and puts no conservative wait into the hot loops.
 constexpr int kEnvRing = 16;
-constexpr int kEnvWin = 8;
+#ifndef SDFGPU_ENV_WIN
+#define SDFGPU_ENV_WIN 4
+#endif
+#ifndef SDFGPU_ENV_CH
+#define SDFGPU_ENV_CH 8
+#endif
+constexpr int kEnvWin = SDFGPU_ENV_WIN;
 
 __device__ __forceinline__ int2 env_load_waited(const int2* p) {
     int2 e;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
     int vy = 0, vz = 0;
     if constexpr (STAGE == 3) { vy = (int)(t / a.nz); vz = (int)(t - (int64_t)vy * a.nz); }
 
-    constexpr int CH = 8;                      // rows fetched per batch: 8 independent loads in flight per lane
+    constexpr int CH = SDFGPU_ENV_CH;          // rows fetched per batch: CH independent loads in flight per lane
     bool has_filled = false;                   // learned during pass 0: does this line hold any filled voxel?
     if (valid) {                               // (lanes past the last line must not touch another line's stack)
 #pragma unroll 1
@@ -192,28 +198,41 @@ __global__ __launch_bounds__(kBlock) void k_envelope(const EnvArgs a) {
                 }
             }
             navail = max(0, min(kEnvWin, k - j));
+            // step 1: every advance and distance of the batch, kept in registers; step 2: all stores together
+            int Dv[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int p = p0 + u;
-                if (p >= L) break;
+                Dv[u] = -1;
+                if (p < L) {
                 while (j < k && (int64_t)(wA[0] - A0) <= (int64_t)2 * p * (wv[0] - v0)) {
-                    ++j; v0 = wv[0]; A0 = wA[0];
+                        ++j; v0 = wv[0]; A0 = wA[0];
 #pragma unroll
-                    for (int i = 0; i + 1 < kEnvWin; ++i) { wv[i] = wv[i + 1]; wA[i] = wA[i + 1]; }
-                    --navail;
-                    if (navail == 0 && j < k) {               // rare: window exhausted inside a batch
-                        const int2 e = env_load_waited(scratch_lane + (int64_t)(j + 1) * nl);
-                        wv[0] = e.x; wA[0] = e.y;
-                        navail = 1;
+                        for (int i = 0; i + 1 < kEnvWin; ++i) { wv[i] = wv[i + 1]; wA[i] = wA[i + 1]; }
+                        --navail;
+                        if (navail == 0 && j < k) {               // rare: window exhausted inside a batch
+                            const int2 e = env_load_waited(scratch_lane + (int64_t)(j + 1) * nl);
+                            wv[0] = e.x; wA[0] = e.y;
+                            navail = 1;
+                        }
+                    }
+                    const bool filled = rawv[u] < 0;
+                    if ((cls == 0) != filled) {
+                        int D = kInf32;
+                        if (k >= 0) {
+                            const int64_t d = (int64_t)A0 + (int64_t)p * p - (int64_t)2 * p * v0;
+                            D = (int)min(d, (int64_t)kInf32);
+                        }
+                        Dv[u] = D;
                     }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int p = p0 + u;
+                int D = Dv[u];
+                if (D < 0) continue;
                 const bool filled = rawv[u] < 0;
-                if ((cls == 0) == filled) continue;                  // this voxel belongs to the other pass
-                int D = kInf32;
-                if (k >= 0) {
-                    const int64_t d = (int64_t)A0 + (int64_t)p * p - (int64_t)2 * p * v0;
-                    D = (int)min(d, (int64_t)kInf32);
-                }
                 const int64_t oi = base + (int64_t)p * ls;
                 if constexpr (STAGE == 2) {
                     a.side_out[oi] = filled ? -D : D;
