@@ -165,6 +165,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+        torch.cuda.synchronize(dev)     # untimed: lets the handle's policy see each warm-up build before the next one
     fence()
     if use_slab and not args.no_profile:
         builder.time_ball_kernel(4)     # events around the dominant kernel of every 4th build, on its launch stream

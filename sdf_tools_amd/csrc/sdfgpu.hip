@@ -581,6 +581,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     HIP_TRY(h, mark(0));
     // Dense path first: exact wherever the nearest opposite voxel is within d^2 <= 8; raises
     // d_small[3] otherwise, in which case (and only then) the general pipeline below does any work.
+    bool cur_fix_mode = false;
     h->last_dense = dense;
     h->guard = nullptr;
     if (dense) {
@@ -595,7 +596,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                        h->d_small + 3, s, fix ? h->d_small + 6 : nullptr)) return rc;
         launched_since_mark = true;
         h->guard = h->d_small + 3;
-        h->prev_fix_mode = fix;
+        cur_fix_mode = fix;
     } else {
         HIP_TRY(h, mark(1));
     }
@@ -647,17 +648,23 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     }
     // one kernel folds the maxima, publishes the status block (device copy for get_extrema, pinned host copy for the
     // next build's policy) and clears it for the next build
-    const bool report = p16 && h->envelope_on && h->h_flags_dev;
+    // The report (status block -> pinned host memory + an event) is only taken when the previous report has been
+    // consumed: the event is then never re-recorded while the host still waits for it, so even a caller that
+    // enqueues builds back to back without ever synchronising keeps feeding the policy (a few builds late), and the
+    // builds in between skip the host write.  What the reported build was (dense? fix-up? envelope mode?) is
+    // remembered with the report -- not with whatever build happens to be the latest when it is read.
+    const bool report = p16 && h->envelope_on && h->h_flags_dev && !h->flags_pending;
     if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : nullptr)) return rc;
     h->small_clean = true;
-    h->prev_env_y = env_y && !fused;
-    h->prev_env_x = env_x;
     h->guard = nullptr;
     h->far_y = nullptr;
     if (report) {
         HIP_TRY(h, hipEventRecord(h->flags_ev, s));
         h->flags_pending = true;
         h->prev_dense = dense;
+        h->prev_fix_mode = cur_fix_mode;
+        h->prev_env_y = env_y && !fused;
+        h->prev_env_x = env_x;
     }
     if (prof) {
         HIP_TRY(h, mark(7));
