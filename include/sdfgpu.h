@@ -268,7 +268,9 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * "envelope kernel alone" policy state), "policy_reset" (forget what was learned from earlier builds),
  * "dense_retry" (after an uncertified dense attempt, try the dense kernels again only every N-th build;
  * default 16, 0 = always try), "fixup" (the fix-up kernel behind the dense ball kernel for almost-dense
- * scenes, default 1), "fixup_mode" (force the policy state that launches it with the next build). */
+ * scenes, default 1), "fixup_mode" (force the policy state that launches it with the next build),
+ * "march_window" / "x16_window" = 8 (force the radius-8 register windows of the y / x marching sweeps,
+ * which the policy otherwise selects for mid-sparse scenes). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),

@@ -518,17 +518,22 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
             h->dense_skip = h->dense_retry - 1;
         //   mid-sparse scenes (largest squared distance beyond the radius-3 window's 16): radius-8 register windows
         //   decide most voxels without the outward scan (measured at 512^3: y sweep 0.96 -> 0.53 ms at p = 0.02,
-        //   x sweep 1.22 -> 0.60 ms at p = 0.01; the wider x window only pays from ~128 upward)
+        //   x sweep 1.22 -> 0.60 ms at p = 0.01; the wider x window only pays from a largest squared distance of ~32 upward:
+        //   p = 0.03 has 28 and gets slower, p = 0.02 has 37 and gets faster)
         if (general_ran) {
             const uint32_t md = std::max(h->h_flags[0], h->h_flags[1]);
-            h->wide_y = md > 16u && md < (uint32_t)kInf32;
-            h->wide_x = md >= 128u && md < (uint32_t)kInf32;
+            h->wide_y = md > 16u && md <= 100u;           // (beyond ~100 the scans past a radius-8 window dominate again:
+            h->wide_x = md >= 32u && md <= 160u;          //  p = 0.003 has 130: x sweep 1.7 -> 1.2 ms; p = 0.001 has 270 and
+                                                          //  its x sweep took 5.0 instead of 2.4 ms)
         } else {
             h->wide_y = h->wide_x = false;
         }
         if (general_ran) {
             const uint32_t max_d = std::max(h->h_flags[0], h->h_flags[1]);
-            const bool near = max_d <= (uint32_t)(kScanExpectNear * kScanExpectNear);
+            // (hysteresis: an axis enters envelope mode on its far flag -- an IN-PLANE distance beyond the scan bound --
+            //  and leaves it only when the 3-D maximum is far below that bound; p = 0.003 has in-plane distances of 44
+            //  with a 3-D maximum of 11 and used to alternate between the two modes)
+            const bool near = max_d <= (uint32_t)((kScanExpectNear / 4) * (kScanExpectNear / 4));
             h->env_mode_y = h->prev_env_y ? !near : (h->h_flags[4] != 0);
             h->env_mode_x = h->prev_env_x ? !near : (h->h_flags[5] != 0);
         } else {
