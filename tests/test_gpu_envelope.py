@@ -100,3 +100,46 @@ def test_policy_transitions_stay_exact(gpu, shape):
         torch.cuda.synchronize()
         assert np.array_equal(sdf.view(np.uint32), want[name][0].view(np.uint32)), name
         assert ext == want[name][1], name
+
+
+def test_envelope_rare_paths_deep_pops_and_dense_advances(gpu):
+    """The hot loops of the envelope kernels read only LDS / registers; these scenes force their out-of-line paths:
+    a site that pops far more stack entries than the 16-entry LDS ring holds, and runs of positions that each
+    advance to a new parabola (more than the register window holds per batch)."""
+    gpu.set_option("policy_reset", 1)
+    gpu.set_option("dense", 0)
+    gpu.set_option("envelope_mode", 1)                      # the envelope kernel is the only sweep of each axis
+    try:
+        scenes_ = []
+        # (a) 40 rows whose only filled voxel is far away in z, then a row with a filled voxel at z = 0: on the lines
+        #     near z = 0 the last site dominates (pops) all 40 earlier parabolas at once; mirrored along x as well
+        m = np.zeros((48, 64, 64), np.uint8)
+        m[:, :40, 63] = 1
+        m[:, 40, 0] = 1
+        scenes_.append(m)
+        m = np.zeros((64, 12, 64), np.uint8)
+        m[:40, :, 63] = 1
+        m[40, :, 0] = 1
+        scenes_.append(m)
+        # (b) a staircase: every position along the line gets its own parabola (advance at every step)
+        m = np.zeros((40, 40, 64), np.uint8)
+        for i in range(40):
+            m[i, :, min(63, 8 + i)] = 1
+            m[:, i, min(63, 20 + (i * 7) % 40)] = 1
+        scenes_.append(m)
+        # (c) random smooth height field + its complement
+        rng = np.random.default_rng(12)
+        hgt = (rng.random((36, 44)) * 30 + 10).astype(int)
+        m = (np.arange(64)[None, None, :] >= hgt[:, :, None]).astype(np.uint8)
+        scenes_.append(m)
+        scenes_.append(1 - m)
+        for k, m in enumerate(scenes_):
+            for vb in (False, True):
+                sdf, ext = gpu.build(m, 0.05, vb)
+                ex, ex_ext, _ = O.exact_sdf(m, 0.05, vb)
+                bad = np.argwhere(sdf.view(np.uint32) != ex.view(np.uint32))
+                assert len(bad) == 0, "scene %d vb=%s: %d voxels differ, first %s" % (k, vb, len(bad), bad[0].tolist())
+                assert ext == ex_ext
+    finally:
+        gpu.set_option("envelope_mode", 0)
+        gpu.set_option("dense", 1)
