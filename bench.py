@@ -4,18 +4,28 @@
 A "step" is one pass of the hot path over one synthetic occupancy grid: device-resident uint8
 mask -> device-resident fp32 signed distance field + extrema, through the C ABI
 (libsdfgpu.so).  Inputs are i.i.d. Bernoulli(p = 0.5) occupancy,
-generated directly in HBM before the timed region.
+generated directly in HBM before the timed region; the steps rotate over three different grids
+(seeds 1, 2, 3) so that no step finds its input in the 256 MiB Infinity Cache.
 
   N = 1 : 512^3 (the configuration the metric is quoted on)
-  N > 1 : one process per GPU (torchrun), the grid cut into x slabs with an RCCL halo exchange
+  N > 1 : one process per GPU, the grid cut into x slabs with an RCCL halo exchange
           (sdf_tools_amd/slab.py); weak scaling at 134 Mvoxel per GPU:
-          N=2 1024x512x512, N=4 1024x1024x512, N=8 1024^3 (the metric's 8-GPU configuration)
+          N=2 1024x512x512, N=4 1024x1024x512, N=8 1024^3 (the metric's 8-GPU configuration).
+          `python bench.py --gpus N` launches its own N ranks (re-exec through
+          torch.distributed.run on 127.0.0.1); under an existing torchrun it uses the ranks it is given.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries (N = 1 only, all untimed
+with respect to `value`):
+  roofline      dominant kernel of the timed steps: HIP-event duration, compulsory bytes, PMC traffic
+  legs          the other tiers at the same 512^3 size: general (separable sweeps) tier on the headline
+                input, a sparse Bernoulli grid, the streaming two-box point cloud
+  parity        voxels that differ from the reference algorithm (oracle) on 128^3 samples
+  cpu_baseline  the oracle timed on this host
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -24,21 +34,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-# Algorithmic bytes per voxel: uint8 mask in, int16 / int32 intermediates, fp32 out
-# (K1 1+2, K2 2+4, K3 4+4 = 17).  The fused z+y kernel does K1's and K2's work in one launch, so it is
-# priced at their sum (9); the bytes it actually has to move are fewer (1 in + 4 out) and are reported
-# next to it as design_bytes_per_voxel.
-# The dense path does the whole mask -> fp32 job in K0 (pack) + KD (ball): K0 is priced at the 1 B/voxel
-# mask read, KD at the remaining 16 B of the separable formulation it replaces.
-B_ALG = {"pack_bits": 1, "dense_ball": 16, "sweep_z": 1 + 2, "sweep_y": 2 + 4, "sweep_zy": 9, "sweep_x": 4 + 4,
-         "envelope_y": 2 + 4, "envelope_x": 4 + 4}
-B_DESIGN32 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8,
-              "envelope_y": 8, "envelope_x": 10}
-B_DESIGN16 = {"pack_bits": 1.125, "dense_ball": 4.625, "sweep_z": 3, "sweep_y": 4, "sweep_zy": 3, "sweep_x": 6,
-              "envelope_y": 8, "envelope_x": 10}
+# Compulsory bytes per voxel of each kernel (what it must read + write once):
+#   pack 1 B mask in + 1/8 B bits out; ball 1/8 in + 4 out; z sweep 1 + 2; y sweep 2 + 2 (16-bit plane field) or
+#   2 + 4 (int32); fused z+y 1 + 2 (or 1 + 4); x sweep 2 + 4 (or 4 + 4); envelope sweeps like the marching ones.
+B_KERNEL16 = {"pack_bits": 1.125, "dense_ball": 4.125, "sweep_z": 3, "sweep_y": 4, "sweep_zy": 3, "sweep_x": 6,
+              "envelope_y": 4, "envelope_x": 6}
+B_KERNEL32 = {"pack_bits": 1.125, "dense_ball": 4.125, "sweep_z": 3, "sweep_y": 6, "sweep_zy": 5, "sweep_x": 8,
+              "envelope_y": 6, "envelope_x": 8}
+# SURVEY.md 8(d)'s algorithmic figure for the separable formulation (K1 1+2, K2 2+4, K3 4+4 = 17 B/voxel),
+# attributed to the kernel that does that part of the work; reported as roofline.alg_equiv, never as frac.
+B_ALG = {"pack_bits": 1, "dense_ball": 16, "sweep_z": 3, "sweep_y": 6, "sweep_zy": 9, "sweep_x": 8,
+         "envelope_y": 6, "envelope_x": 8}
 B_ALG_TOTAL = 17
-KERNEL_NAMES = {"envelope_y": "k_envelope<2>", "envelope_x": "k_envelope<3>", "pack_bits": "k_pack_bits_mask", "dense_ball": "k_ball_dense", "sweep_z": "k_sweep_z_vec16", "sweep_y": "k_sweep_march<2,...>",
-                "sweep_zy": "k_sweep_zy_fused", "sweep_x": "k_sweep_march<3,...> / k_sweep_x16"}
+B_COMPULSORY_TOTAL = 5          # mask in + fp32 out
+KERNEL_NAMES = {"envelope_y": "k_envelope_dc<2> / k_envelope<2>", "envelope_x": "k_envelope_dc<3> / k_envelope<3>",
+                "pack_bits": "k_pack_bits_mask", "dense_ball": "k_ball_dense", "sweep_z": "k_sweep_z_vec16",
+                "sweep_y": "k_sweep_march<2,...>", "sweep_zy": "k_sweep_zy_fused",
+                "sweep_x": "k_sweep_march<3,...> / k_sweep_x16"}
+STAGES = ["pack_bits", "dense_ball", "sweep_z", "sweep_y", "envelope_y", "sweep_x", "envelope_x"]
 
 GRIDS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024, 1024, 1024)}
 
@@ -46,14 +59,17 @@ GRIDS = {1: (512, 512, 512), 2: (1024, 512, 512), 4: (1024, 1024, 512), 8: (1024
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, nargs=3, default=None, help="override grid nx ny nz")
     ap.add_argument("--p", type=float, default=0.5, help="Bernoulli occupancy probability")
     ap.add_argument("--resolution", type=float, default=0.01)
     ap.add_argument("--halo", type=int, default=3)
+    ap.add_argument("--masks", type=int, default=3, help="distinct input grids the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=320, help="edge of the cube timed on the CPU oracle")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra (untimed) tier legs and the parity counts")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="edge of the cube timed on the CPU oracle (0 = 512 if the host has the memory, else 320)")
     ap.add_argument("--tune", type=int, nargs=2, default=None, help="rows per chunk: y x")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-GPU slab builder even at N = 1")
@@ -61,26 +77,49 @@ def parse_args():
     return ap.parse_args()
 
 
+def relaunch_as_ranks(n):
+    """`python bench.py --gpus N` without a launcher: become N ranks (one per GPU) through torch.distributed.run."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
+
+
+def host_mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1048576.0
+    except Exception:
+        pass
+    return 0.0
+
+
 def cpu_baseline(sample_n, p, resolution):
     """Times the CPU oracle (kind = "port": the C restatement of the reference's single-threaded
-    bucket-queue BuildDistanceField path) on a bounded sample of the same workload."""
-    import numpy as np  # noqa: F401
-
+    bucket-queue BuildDistanceField path) on the same generator as the GPU workload."""
     from oracle import oracle as O
     from sdf_tools_amd import synth
 
+    if sample_n <= 0:       # the full 512^3 workload needs ~23 GB and ~35 s; fall back to a 320^3 sample on small hosts
+        sample_n = 512 if host_mem_available_gb() >= 96.0 else 320
     m = synth.bernoulli_mask((sample_n,) * 3, p, 1)
     t0 = time.perf_counter()
     O.reference_sdf(m, resolution)
     dt = time.perf_counter() - t0
     return {"value": round(m.size / dt / 1e6, 4), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
             "host_cores": os.cpu_count(), "seconds": round(dt, 2),
-            "sample": "%d^3 Bernoulli(p=%g) occupancy grid, same generator and resolution as the GPU workload; "
-                      "single-threaded like the reference" % (sample_n, p)}
+            "sample": "%d^3 Bernoulli(p=%g) occupancy grid (seed 1), same generator and resolution as the GPU workload%s; "
+                      "single-threaded like the reference" % (sample_n, p, " = the full workload" if sample_n == 512 else "")}
 
 
 def load_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/*_traffic.json), if any."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if any."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         try:
@@ -90,9 +129,169 @@ def load_traffic():
     return None
 
 
+def stage_table(ctx, ms_sum, builds, n_total):
+    """Per-stage average ms of the profiled builds -> {stage: ms}, kernels used, dominant stage."""
+    info = ctx.last_build_info()
+    info.update(ctx.last_path())
+    avg = [v / max(builds, 1) for v in ms_sum]
+    stage_ms = {}
+    if info["dense"]:
+        stage_ms["pack_bits"], stage_ms["dense_ball"] = avg[0], avg[1]
+    if not info["dense_certified"]:
+        if info["fused_zy"]:
+            stage_ms["sweep_zy"] = avg[3]
+        else:
+            stage_ms["sweep_z"], stage_ms["sweep_y"] = avg[2], avg[3]
+        stage_ms["sweep_x"] = avg[5]
+        if info["far_y"] or avg[4] > 0.02:
+            stage_ms["envelope_y"] = avg[4]
+        if info["far_x"] or avg[6] > 0.02:
+            stage_ms["envelope_x"] = avg[6]
+    stage_ms = {k: v for k, v in stage_ms.items() if v > 0.0005}
+    return info, avg, stage_ms
+
+
+def roofline_of(stage, ms, n_total, plane16, traffic_table=None):
+    bk = (B_KERNEL16 if plane16 else B_KERNEL32)[stage]
+    achieved = n_total * bk / (ms * 1e-3) / 1e9
+    tr = (traffic_table or {}).get(stage) if n_total == 512 ** 3 else None
+    r = {"bound": "hbm", "kernel": KERNEL_NAMES[stage], "stage": stage,
+         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": tr,
+         "bytes_per_voxel": bk, "avg_ms": round(ms, 4)}
+    if tr:
+        r["traffic_frac"] = round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        r["traffic_over_compulsory"] = round(tr / (n_total * bk), 3)
+    alg = n_total * B_ALG[stage] / (ms * 1e-3) / 1e9
+    r["alg_equiv"] = {"bytes_per_voxel": B_ALG[stage], "achieved": round(alg, 1), "ratio_to_peak": round(alg / HBM_PEAK_GBPS, 4),
+                      "note": "SURVEY 8(d) bytes of the three materialised sweeps attributed to this kernel; a fused / "
+                              "bit-parallel kernel moves fewer bytes, so this is an equivalence figure, not a hardware fraction"}
+    return r
+
+
+def timed_loop(step, steps, fence):
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    fence()
+    return time.perf_counter() - t0
+
+
+def run_leg(torch, capi, dev, shape, res, masks, opts, steps, warmup, label):
+    """One extra (untimed w.r.t. `value`) leg: its own context, its own loop, per-stage HIP events."""
+    ctx = capi.SdfGpu(dev.index)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n_total = shape[0] * shape[1] * shape[2]
+
+    def step(i):
+        ctx.build_device(masks[i % len(masks)].data_ptr(), shape, out.data_ptr(), res, False, stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+
+    t_first0 = time.perf_counter()
+    step(0)
+    fence()
+    first_ms = (time.perf_counter() - t_first0) * 1e3        # a fresh context on this scene (one-shot callers)
+    for i in range(warmup):
+        step(i)
+        fence()
+    dt = timed_loop(step, steps, fence)
+    ctx.get_stage_times()
+    ctx.set_profiling(1)
+    timed_loop(step, min(steps, 20), fence)
+    ms_sum, builds = ctx.get_stage_times()
+    ctx.set_profiling(0)
+    info, avg, stage_ms = stage_table(ctx, ms_sum, builds, n_total)
+    leg = {"workload": label, "ms_per_step": round(dt / steps * 1e3, 4),
+           "Mvoxels_per_s": round(n_total / (dt / steps) / 1e6, 1),
+           "first_build_ms_fresh_context": round(first_ms, 3),
+           "pipeline_frac_compulsory": round(n_total * B_COMPULSORY_TOTAL / (dt / steps) / 1e9 / HBM_PEAK_GBPS, 4),
+           "kernels": info, "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "extrema": list(ctx.get_extrema())}
+    if stage_ms:
+        dom = max(stage_ms, key=stage_ms.get)
+        leg["roofline"] = roofline_of(dom, stage_ms[dom], n_total, info["plane16"], load_traffic())
+    ctx.close()
+    return leg
+
+
+def streaming_leg(torch, dev, n, res, frames):
+    """BASELINE configs[4]: 200 k points / frame -> occupancy -> SDF + gradient at n^3, everything in HBM."""
+    from sdf_tools_amd import synth
+    from sdf_tools_amd.streaming import StreamingSdf
+
+    st = StreamingSdf((n, n, n), res, (0.0, 0.0, 0.0), dev.index, gradient=True)
+    clouds = [torch.from_numpy(synth.two_box_points(200000, seed=f, scale=n * res)).to(dev) for f in range(4)]
+    t0 = time.perf_counter()
+    st.frame(clouds[0])
+    torch.cuda.synchronize(dev)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    for f in range(3):
+        st.frame(clouds[f % 4])
+        torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for f in range(frames):
+        st.frame(clouds[f % 4])
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    st.ctx.get_stage_times()
+    st.ctx.set_profiling(1)
+    for f in range(8):
+        st.frame(clouds[f % 4])
+    torch.cuda.synchronize(dev)
+    ms_sum, builds = st.ctx.get_stage_times()
+    st.ctx.set_profiling(0)
+    info, avg, stage_ms = stage_table(st.ctx, ms_sum, builds, n ** 3)
+    leg = {"workload": "200 k points in two boxes (scripts/3d_sdf_demo_rviz.py pattern) -> %d^3 occupancy @ %g m -> SDF + "
+                       "full-grid gradient, per frame" % (n, res),
+           "frames_per_s": round(frames / dt, 1), "ms_per_frame": round(dt / frames * 1e3, 3), "target_hz": 30,
+           "first_frame_ms_fresh_context": round(first_ms, 3),
+           "kernels": info, "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "extrema": list(st.extrema())}
+    if stage_ms:
+        dom = max(stage_ms, key=stage_ms.get)
+        leg["roofline"] = roofline_of(dom, stage_ms[dom], n ** 3, info["plane16"], load_traffic())
+    st.ctx.close()
+    return leg
+
+
+def parity_counts(ctx, res):
+    """Voxels whose GPU value differs from the reference algorithm (the oracle's restatement of the bucket-queue
+    propagation) on 128^3 samples of the benchmark generators.  The reference is exact wherever the true squared
+    distance is < 8 and over-estimates a few voxels beyond; every mismatch is checked to be such an over-estimate
+    (GPU == exact EDT, |reference| > |GPU|)."""
+    import numpy as np
+
+    from oracle import oracle as O
+    from sdf_tools_amd import synth
+
+    out = {"tolerance": 1e-5, "sample": "128^3, resolution %g" % res, "cases": {}}
+    for name, p, seed in (("bernoulli_p0.5", 0.5, 1), ("bernoulli_p0.01", 0.01, 2)):
+        m = synth.bernoulli_mask((128, 128, 128), p, seed)
+        got, ext = ctx.build(m, res)
+        ref, ref_ext = O.reference_sdf(m, res)
+        ex, ex_ext, _ = O.exact_sdf(m, res)
+        diff = np.abs(got.astype(np.float64) - ref.astype(np.float64)) > 1e-5
+        n_diff = int(diff.sum())
+        bit_equal_exact = bool(np.array_equal(got.view(np.uint32), ex.view(np.uint32)))
+        over = int((np.abs(ref[diff]) > np.abs(got[diff])).sum()) if n_diff else 0
+        out["cases"][name] = {"voxels": int(m.size), "differ_from_reference_gt_tol": n_diff,
+                              "of_which_reference_overestimates": over,
+                              "gpu_bit_equal_to_exact_edt": bit_equal_exact,
+                              "sign_mismatches": int(((got < 0) != (m != 0)).sum()),
+                              "extrema_equal_reference": bool(ext == ref_ext)}
+    return out
+
+
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL between processes here
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_as_ranks(args.gpus)                                # does not return
     import torch
     import torch.distributed as dist
 
@@ -102,9 +301,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match the launcher's WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the SDF build path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -118,6 +315,7 @@ def main():
     n_total = nx * ny * nz
     res = args.resolution
     stream = torch.cuda.current_stream(dev)
+    n_masks = max(1, args.masks)
 
     use_slab = world > 1 or args.force_slab
     if not use_slab:
@@ -126,11 +324,11 @@ def main():
             ctx.set_tuning(*args.tune)
         for kv in args.opt:
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-        mask = synth.bernoulli_mask_torch(shape, args.p, 1, device=dev)
+        masks = [synth.bernoulli_mask_torch(shape, args.p, 1 + k, device=dev) for k in range(n_masks)]
         out = torch.empty(shape, dtype=torch.float32, device=dev)
 
-        def step():
-            ctx.build_device(mask.data_ptr(), shape, out.data_ptr(), res, False, stream.cuda_stream)
+        def step(i):
+            ctx.build_device(masks[i % n_masks].data_ptr(), shape, out.data_ptr(), res, False, stream.cuda_stream)
     else:
         stages = slab.HipStages(local_rank)
         ctx = stages.ctx
@@ -139,15 +337,15 @@ def main():
         for kv in args.opt:
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         x0, x1 = slab.slab_range(nx, rank, world)
-        mask = synth.bernoulli_mask_torch(shape, args.p, 1, x_range=(x0, x1), device=dev)
+        masks = [synth.bernoulli_mask_torch(shape, args.p, 1 + k, x_range=(x0, x1), device=dev) for k in range(n_masks)]
         builder = slab.SlabSdfBuilder(stages, shape, res, False, halo=args.halo, rank=rank, world=world)
         pending = []
 
-        def step():
+        def step(i):
             # enqueue this build, then validate the previous one (its all-reduced status has already
             # landed in pinned host memory): every build is validated inside the timed region, but the
             # GPUs never wait for the host between builds
-            pending.append(builder.build_async(mask))
+            pending.append(builder.build_async(masks[i % n_masks]))
             if len(pending) > 1:
                 builder.finish(pending.pop(0))
 
@@ -163,12 +361,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
         torch.cuda.synchronize(dev)     # untimed: lets the handle's policy see each warm-up build before the next one
     fence()
     if use_slab and not args.no_profile:
         builder.time_ball_kernel(4)     # events around the dominant kernel of every 4th build, on its launch stream
+    dominant_only = False
     if not use_slab:
         ctx.get_stage_times()           # drop anything recorded so far
         # HIP events on the launch stream inside the timed region: around the dominant kernel only when the
@@ -178,11 +377,7 @@ def main():
         except Exception:               # no warm-up build yet
             dominant_only = False
         ctx.set_profiling(0 if args.no_profile else (3 if dominant_only else 1))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = timed_loop(step, args.steps, fence)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -195,110 +390,98 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "%dx%dx%d uint8 occupancy grid, Bernoulli(p=%g) seed 1, resolution %g, "
-                               "no virtual border; device-resident mask -> device-resident fp32 SDF + extrema"
-                               % (nx, ny, nz, args.p, res),
+        "config": {"workload": "%dx%dx%d uint8 occupancy grid, Bernoulli(p=%g), %d grids (seeds 1..%d) in rotation, "
+                               "resolution %g, no virtual border; device-resident mask -> device-resident fp32 SDF + extrema"
+                               % (nx, ny, nz, args.p, n_masks, n_masks, res),
                    "grid": list(shape), "voxels": n_total,
                    "partition": "single GPU" if world == 1 else
                    "x-slab x%d; RCCL halo exchange: 2 bit-planes (dense path) / %d int32 planes (general path)"
                    % (world, args.halo)},
+    }
+    # whole step against the compulsory 5 B/voxel (mask in, fp32 out) and against SURVEY 8(d)'s 17 B/voxel
+    result["pipeline"] = {
+        "compulsory_bytes_per_voxel": B_COMPULSORY_TOTAL,
+        "frac_of_hbm_peak": round(n_total * B_COMPULSORY_TOTAL / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS / world, 4),
+        "alg_equiv": {"bytes_per_voxel": B_ALG_TOTAL,
+                      "ratio_to_peak": round(n_total * B_ALG_TOTAL / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS / world, 4)},
     }
 
     if not use_slab:
         ms_sum, builds = ctx.get_stage_times()
         ctx.set_profiling(False)
         if not args.no_profile and dominant_only:
-            # per-stage breakdown from a second, untimed pass of K steps with an event behind every stage
+            # per-stage breakdown from a second, untimed pass with an event behind every stage
             dominant_ms = ms_sum[1] / max(builds, 1)
-            fence()
             ctx.set_profiling(1)
-            for _ in range(args.steps):
-                step()
-            fence()
+            timed_loop(step, min(args.steps, 50), fence)
             ms_sum, builds = ctx.get_stage_times()
             ctx.set_profiling(False)
             ms_sum = list(ms_sum)
-            result["config"]["stage_breakdown"] = "untimed second pass with an event behind every stage; dense_ball from the timed pass"
+            result["config"]["stage_breakdown"] = ("untimed second pass with an event behind every stage; dense_ball from "
+                                                   "the timed pass (events around it on every 4th build)")
             ms_sum[1] = dominant_ms * builds
         if not args.no_profile:
-            # the same K steps again without the per-stage HIP events (they cost a few us per build):
-            # reported next to `value`, never instead of it
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            fence()
-            result["value_without_stage_events"] = round(n_total / ((time.perf_counter() - t1) / args.steps) / 1e6, 2)
+            # the same steps again without any HIP events: reported next to `value`, never instead of it
+            dt2 = timed_loop(step, args.steps, fence)
+            result["value_without_stage_events"] = round(n_total / (dt2 / args.steps) / 1e6, 2)
         mx, mn = ctx.get_extrema()
         result["extrema"] = [mx, mn]
         if builds:
-            info = ctx.last_build_info()
-            B_DESIGN = B_DESIGN16 if info["plane16"] else B_DESIGN32
-            info.update(ctx.last_path())
+            info, avg, stage_ms = stage_table(ctx, ms_sum, builds, n_total)
             result["config"]["kernels"] = info
-            avg = [v / builds for v in ms_sum]
-            stage_ms = {}
-            if info["dense"]:
-                stage_ms["pack_bits"], stage_ms["dense_ball"] = avg[0], avg[1]
-            if not info["dense_certified"]:
-                if info["fused_zy"]:
-                    stage_ms["sweep_zy"] = avg[3]
-                else:
-                    stage_ms["sweep_z"], stage_ms["sweep_y"] = avg[2], avg[3]
-                stage_ms["sweep_x"] = avg[5]
-                if info["far_y"] or avg[4] > 0.05:
-                    stage_ms["envelope_y"] = avg[4]
-                if info["far_x"] or avg[6] > 0.05:
-                    stage_ms["envelope_x"] = avg[6]
-            else:
+            if info["dense_certified"]:
                 result["config"]["guarded_general_pipeline_ms"] = round(sum(avg[2:]), 4)
             dom = max(stage_ms, key=stage_ms.get)
-            achieved = n_total * B_ALG[dom] / (stage_ms[dom] * 1e-3) / 1e9
-            traffic = load_traffic()
-            kernel_ms = sum(avg)
-            result["roofline"] = {
-                "bound": "hbm", "kernel": KERNEL_NAMES[dom], "stage": dom,
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": (traffic or {}).get(dom),
-                "hbm_frac_traffic": (round((traffic or {}).get(dom) / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                                     if (traffic or {}).get(dom) and n_total == 512 ** 3 else None),
-                "alg_bytes_per_voxel": B_ALG[dom], "design_bytes_per_voxel": B_DESIGN[dom],
-                "avg_ms": round(stage_ms[dom], 4),
-                "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-                "note": ("achieved = SURVEY 8(d) algorithmic bytes of the separable formulation attributed to this kernel "
-                         "x voxels / its HIP-event duration; a bit-parallel kernel moves far fewer bytes than that "
-                         "(design_bytes_per_voxel), so frac can exceed 1 -- hbm_frac_traffic = measured PMC bytes "
-                         "(traffic, from profiles/) / duration / peak is the hardware utilisation"),
-                "pipeline": {"alg_bytes_per_voxel": B_ALG_TOTAL, "kernel_ms": round(kernel_ms, 4),
-                             "achieved": round(n_total * B_ALG_TOTAL / (kernel_ms * 1e-3) / 1e9, 1),
-                             "frac": round(n_total * B_ALG_TOTAL / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-            }
+            r = roofline_of(dom, stage_ms[dom], n_total, info["plane16"], load_traffic())
+            r["stages_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+            r["note"] = ("frac = compulsory bytes of this kernel (bytes_per_voxel x voxels) / HIP-event duration / peak; "
+                         "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json)")
+            result["roofline"] = r
     else:
         launches, ms_total, vox = builder.pop_ball_timings()
         if launches and rank == 0:
             avg_ms = ms_total / launches
-            achieved = vox * B_ALG["dense_ball"] / (avg_ms * 1e-3) / 1e9
             traffic = load_traffic()
             per_voxel = ((traffic or {}).get("dense_ball") or 0) / float(512 ** 3)
-            result["roofline"] = {
-                "bound": "hbm", "kernel": KERNEL_NAMES["dense_ball"], "stage": "dense_ball",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": int(per_voxel * vox) if per_voxel else None,
-                "hbm_frac_traffic": round(per_voxel * vox / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if per_voxel else None,
-                "alg_bytes_per_voxel": B_ALG["dense_ball"], "avg_ms": round(avg_ms, 4),
-                "launches_timed": launches, "voxels_per_launch": vox,
-                "note": "rank 0, interior planes of its slab, every 4th build; traffic scaled from the 512^3 PMC pass",
-            }
+            r = roofline_of("dense_ball", avg_ms, vox, True, None)
+            r["traffic"] = int(per_voxel * vox) if per_voxel else None
+            if per_voxel:
+                r["traffic_frac"] = round(per_voxel * vox / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            r["launches_timed"] = launches
+            r["voxels_per_launch"] = vox
+            r["note"] = "rank 0, interior planes of its slab, every 4th build; traffic scaled from the 512^3 PMC pass"
+            result["roofline"] = r
         result["config"]["dense_path"] = builder.dense
         result["config"]["builds_needing_general_path"] = builder.general_builds
         result["config"]["whole_line_fallbacks"] = builder.fallbacks
+        result["config"]["general_exchange"] = getattr(builder, "general_exchange", None)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_slab:
+    single = rank == 0 and world == 1 and not args.force_slab
+    if single and not args.no_legs:
+        legs = {}
+        leg_steps = max(10, min(50, args.steps))
+        try:
+            legs["general_tier_headline_input"] = run_leg(
+                torch, capi, dev, shape, res, masks, {"dense": 0}, leg_steps, 5,
+                "the headline grids through the separable-sweep tier only (option dense=0)")
+            sparse = [synth.bernoulli_mask_torch(shape, 0.01, 11 + k, device=dev) for k in range(2)]
+            legs["sparse_bernoulli_p0.01"] = run_leg(
+                torch, capi, dev, shape, res, sparse, {}, leg_steps, 20,
+                "%dx%dx%d Bernoulli(p=0.01), 2 grids in rotation, default policy" % shape)
+            del sparse
+            if shape == (512, 512, 512):
+                legs["streaming_two_box"] = streaming_leg(torch, dev, 512, 0.01, 30)
+        except Exception as e:                     # a leg must never take the contract line down with it
+            legs["error"] = repr(e)
+        result["legs"] = legs
+        try:
+            result["parity"] = parity_counts(ctx, res)
+        except Exception as e:
+            result["parity"] = {"error": repr(e)}
+    if single and not args.no_cpu_baseline:
         # what a caller of the reference's C++ API sees: host mask -> host SDF through sdfgpu_build (PCIe both ways,
         # fresh output buffer).  Reported for context only -- never `value`.
-        host_mask = mask.cpu().numpy()
+        host_mask = masks[0].cpu().numpy()
         ctx.build(host_mask, res)
         t_host = []
         for _ in range(2):
@@ -308,6 +491,7 @@ def main():
         result["host_api"] = {"call": "sdfgpu_build (host -> host, PCIe inclusive)", "ms": round(min(t_host) * 1e3, 2),
                               "Mvoxels_per_s": round(n_total / min(t_host) / 1e6, 1),
                               "note": "includes numpy output allocation; not the benchmark metric"}
+        del host_mask
         result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.p, res)
     if rank == 0:
         print(json.dumps(result))

@@ -60,6 +60,26 @@ int main(int argc, char** argv) {
     const auto vb = collision_map.ExtractSignedDistanceField(oob_value, false, true);
     const auto via_pred = collision_map.ExtractSignedDistanceFieldViaPredicate(oob_value, false, false);
     ok = ok && via_pred.first.GetImmutableRawData() == sdf.GetImmutableRawData() && vb.second.first <= max_d;
+    // the cell-predicate overload (reference sdf_generation.hpp:422-441), as client code calls it
+    const std::function<bool(const sdf_tools::COLLISION_CELL&)> cell_is_filled = [](const sdf_tools::COLLISION_CELL& cell) {
+        return cell.occupancy > 0.5f;
+    };
+    const auto via_cell_pred = sdf_generation::ExtractSignedDistanceField<sdf_tools::COLLISION_CELL>(collision_map, cell_is_filled, oob_value, frame);
+    ok = ok && via_cell_pred.first.GetImmutableRawData() == sdf.GetImmutableRawData() &&
+         via_cell_pred.second.first == max_d && via_cell_pred.second.second == min_d;
+    // full-grid gradient through the GPU fast path == the per-voxel host calls
+    {
+        const std::vector<double> flat = sdf.GetFullGradientFlat(true, 0.0);
+        bool same = flat.size() == (size_t)40 * 40 * 40 * 3;
+        for (int64_t x = 0; same && x < 40; x += 13)
+            for (int64_t y = 0; y < 40; y += 7)
+                for (int64_t z = 0; z < 40; z++) {
+                    const std::vector<double> gh = sdf.GetGradient(x, y, z, true);
+                    const size_t i = (size_t)((x * 40 + y) * 40 + z) * 3;
+                    same = same && gh.size() == 3 && gh[0] == flat[i] && gh[1] == flat[i + 1] && gh[2] == flat[i + 2];
+                }
+        ok = ok && same;
+    }
     // file round trip (SDFZ)
     sdf_tools::SignedDistanceField::SaveToFile(sdf, "/tmp/tutorial.sdf", true);
     const sdf_tools::SignedDistanceField back = sdf_tools::SignedDistanceField::LoadFromFile("/tmp/tutorial.sdf");

@@ -19,6 +19,7 @@
 #include "arc_utilities/voxel_grid.hpp"
 #include "arc_utilities/zlib_helpers.hpp"
 #include "sdf_tools/eigen_lite.hpp"
+#include "sdf_tools/gpu_context.hpp"
 
 namespace sdf_tools {
 using VoxelGrid::GRID_INDEX;
@@ -123,6 +124,30 @@ public:
     }
     std::vector<double> GetGradient(const double x, const double y, const double z, const bool e = false) const {
         return GetGradient4d(Eigen::Vector4d(x, y, z, 1.0), e);
+    }
+
+    // Every cell's world-frame gradient at once, [x][y][z][3] doubles, computed by ONE kernel on the MI355X
+    // (sdfgpu_gradient) instead of nx*ny*nz GetGradient calls: the values are those of GetGradient(x, y, z,
+    // enable_edge_gradients) bit for bit (same float-subtract / double-scale arithmetic, :447-512); cells for which
+    // the reference returns an empty vector hold `empty_fill` in all three components.  A rotated origin frame
+    // applies the reference's quaternion sandwich (:405-430) on the host to the grid-aligned values.
+    std::vector<double> GetFullGradientFlat(const bool enable_edge_gradients, const double empty_fill) const {
+        const int64_t nx = GetNumXCells(), ny = GetNumYCells(), nz = GetNumZCells();
+        std::vector<double> g((size_t)(nx * ny * nz) * 3);
+        if (g.empty()) return g;
+        sdfgpu_handle h = sdf_generation::GpuContext::Get();
+        sdf_generation::ThrowOnStatus(h, sdfgpu_gradient(h, data_.data(), nx, ny, nz, GetResolution(),
+                                                         enable_edge_gradients ? 1 : 0, g.data(), 1));
+        const Eigen::Quaterniond q(origin_transform_.rotation());
+        const bool identity = q.w() == 1.0 && q.x() == 0.0 && q.y() == 0.0 && q.z() == 0.0;
+        const Eigen::Quaterniond qi = q.inverse();
+        for (size_t i = 0; i < g.size(); i += 3) {
+            if (std::isnan(g[i])) { g[i] = g[i + 1] = g[i + 2] = empty_fill; continue; }
+            if (identity) continue;                           // q * (0, g) * q^-1 == g exactly
+            const Eigen::Quaterniond r = q * (Eigen::Quaterniond(0.0, g[i], g[i + 1], g[i + 2]) * qi);
+            g[i] = r.x(); g[i + 1] = r.y(); g[i + 2] = r.z();
+        }
+        return g;
     }
 
     using GradientFunction = std::function<std::vector<double>(int64_t, int64_t, int64_t, bool)>;

@@ -16,34 +16,11 @@
 #include <vector>
 
 #include "arc_utilities/voxel_grid.hpp"
+#include "sdf_tools/gpu_context.hpp"
 #include "sdf_tools/sdf.hpp"
 #include "sdfgpu.h"
 
 namespace sdf_generation {
-
-// One GPU context per host thread (the ABI is re-entrant per context; SURVEY.md 8(b) "Threading").
-class GpuContext {
-public:
-    static sdfgpu_handle Get() {
-        thread_local GpuContext ctx;
-        if (!ctx.handle_) {
-            const int rc = sdfgpu_create(DeviceIndex(), &ctx.handle_);
-            if (rc != SDFGPU_OK) throw std::runtime_error(std::string("sdfgpu: ") + sdfgpu_last_error(nullptr));
-        }
-        return ctx.handle_;
-    }
-    static int& DeviceIndex() { static int device = 0; return device; }
-    ~GpuContext() { if (handle_) sdfgpu_destroy(handle_); }
-private:
-    sdfgpu_handle handle_ = nullptr;
-};
-
-inline void ThrowOnStatus(sdfgpu_handle h, const int rc) {
-    if (rc == SDFGPU_OK) return;
-    const std::string msg = std::string("sdfgpu: ") + sdfgpu_last_error(h);
-    if (rc == SDFGPU_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
-    throw std::runtime_error(msg);
-}
 
 // Core overload: origin, resolution, cell counts, index predicate (reference :209-271).
 // The predicate may be stateful (MoveIt collision checks), so it is evaluated on the host exactly

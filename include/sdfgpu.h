@@ -20,6 +20,14 @@
  *   - every function returns SDFGPU_OK (0) or a negative sdfgpu_status;
  *     nothing throws; sdfgpu_last_error() gives the message for the handle
  *   - a handle is bound to one GPU; use one handle per host thread
+ *   - builds on one handle share its scratch fields and status block.  Builds issued on the same stream are
+ *     ordered by the stream; a build issued on a different stream than the previous one first waits (on the
+ *     device, hipStreamWaitEvent) for the previous build's last kernel.  The stage-level entry points
+ *     (sdfgpu_sweep_*_device, sdfgpu_dense_ball_device, sdfgpu_slab_dense_phase ...) write only caller-owned
+ *     buffers plus the handle's extrema slots: issue all stage calls of one build on one stream.
+ *   - host-buffer entry points use the caller's output buffer as scratch while they run (its pages are
+ *     faulted in while the input travels to the GPU): when such a call fails, the contents of out_sdf /
+ *     out_grad are undefined
  *   - there is NO CPU fallback: without a usable HIP device sdfgpu_create fails
  */
 #ifndef SDFGPU_H
@@ -92,6 +100,7 @@ int sdfgpu_build_cells(sdfgpu_handle h, const void* cells,
  *   object_mode 1: object_id > 0                 (object_filled_fn :757-775, "named objects")
  *   object_mode 2: object_id in object_ids[0..n) (ExtractSignedDistanceField(objects_to_use) :817-827;
  *                                                 n == 0 means any object, like :826)
+ * object_ids may hold any number of ids in any order (a sorted copy is searched on the device).
  * Classified on the device, then the same build as sdfgpu_build. */
 int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells,
                               size_t cell_stride, size_t occupancy_offset, size_t object_id_offset,
@@ -211,6 +220,14 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf,
                            int64_t nx, int64_t ny, int64_t nz,
                            double resolution, int enable_edge_gradients,
                            void* d_out_grad, int out_is_f64, void* stream);
+
+/* Host-buffer form (what SignedDistanceField::GetFullGradient's fast path and pysdf_tools call instead of
+ * nx*ny*nz host GetGradient calls, reference sdf.hpp:341-358 / utils_3d.py:77-90): sdf = N floats,
+ * out_grad = N x 3 doubles (out_is_f64) or floats; NaN where the reference returns an empty vector. */
+int sdfgpu_gradient(sdfgpu_handle h, const float* sdf,
+                    int64_t nx, int64_t ny, int64_t nz,
+                    double resolution, int enable_edge_gradients,
+                    void* out_grad, int out_is_f64);
 
 /* Next-row N1, query side: batched SignedDistanceField::EstimateDistance4d (sdf.hpp:947-961: trilinear
  * inter/extrapolation :836-902 of the 8 surrounding cell centres, each shrunk by half a cell toward the

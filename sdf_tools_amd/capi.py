@@ -23,6 +23,7 @@ EXPORTS = [
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
     "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
+    "sdfgpu_gradient",
 ]
 
 
@@ -76,6 +77,7 @@ def load_library():
     L.sdfgpu_voxelize_points_device.argtypes = [vp, vp, i64, vp, dbl, i64, i64, i64, vp, ci, vp]
     L.sdfgpu_extrema_from_dsq.argtypes = [u32, u32, dbl, vp, vp]
     L.sdfgpu_gradient_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci, vp]
+    L.sdfgpu_gradient.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci]
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_debug_copy_yzsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_set_tuning.argtypes = [vp, ci, ci]
@@ -246,6 +248,14 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_gradient_device(self._h, d_sdf, nx, ny, nz, float(resolution),
                                                      int(bool(enable_edge_gradients)), d_out, int(bool(f64)),
                                                      stream or None))
+
+    def gradient(self, sdf, resolution=1.0, enable_edge_gradients=True, f64=True):
+        """Host-buffer full-grid gradient: sdf float32 [nx,ny,nz] -> [nx,ny,nz,3] (NaN where the reference has none)."""
+        f = np.ascontiguousarray(sdf, dtype=np.float32)
+        out = np.empty(f.shape + (3,), dtype=np.float64 if f64 else np.float32)
+        self._check(self._lib.sdfgpu_gradient(self._h, f.ctypes.data, *f.shape, float(resolution),
+                                              int(bool(enable_edge_gradients)), out.ctypes.data, int(bool(f64))))
+        return out
 
     def debug_zsweep(self, shape):
         out = np.empty(shape, dtype=np.int16)

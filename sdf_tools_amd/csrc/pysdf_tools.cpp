@@ -100,6 +100,21 @@ PYBIND11_MODULE(pysdf_tools, m) {
         })
         .def("GetFullGradientNumpy", [](const SignedDistanceField& s, bool enable_edge_gradients) {
             const int64_t nx = s.GetNumXCells(), ny = s.GetNumYCells(), nz = s.GetNumZCells();
+            // one kernel on the GPU (sdfgpu_gradient) instead of nx*ny*nz GetGradient calls; same values bit for bit.
+            // Cells without a gradient (boundary shell when edge gradients are off) hold 3 x the OOB value here; the
+            // reference's GetFullGradient stores an empty vector there (sdf.hpp:341-358).
+            std::vector<double> g;
+            {
+                py::gil_scoped_release release;
+                g = s.GetFullGradientFlat(enable_edge_gradients, (double)s.GetOOBValue());
+            }
+            py::array_t<double> out({nx, ny, nz, (int64_t)3});
+            std::memcpy(out.mutable_data(), g.data(), g.size() * sizeof(double));
+            return out;
+        }, py::arg("enable_edge_gradients") = true)
+        .def("GetFullGradientNumpyHost", [](const SignedDistanceField& s, bool enable_edge_gradients) {
+            // the reference's per-voxel loop (sdf.hpp:341-358) on one host core: kept as the checker of the GPU path
+            const int64_t nx = s.GetNumXCells(), ny = s.GetNumYCells(), nz = s.GetNumZCells();
             py::array_t<double> out({nx, ny, nz, (int64_t)3});
             double* p = out.mutable_data();
             const double oob = (double)s.GetOOBValue();
@@ -125,6 +140,11 @@ PYBIND11_MODULE(pysdf_tools, m) {
         .def("ExtractSignedDistanceField", &CollisionMapGrid::ExtractSignedDistanceField, py::call_guard<py::gil_scoped_release>())
         .def("ExtractSignedDistanceFieldViaPredicate", &CollisionMapGrid::ExtractSignedDistanceFieldViaPredicate,
              py::call_guard<py::gil_scoped_release>())
+        // the reference's cell-predicate overload (sdf_generation.hpp:422-441) with a Python predicate on the cell
+        .def("ExtractSignedDistanceFieldCellPredicate",
+             [](const CollisionMapGrid& g, const std::function<bool(const COLLISION_CELL&)>& is_filled_fn, float oob_value) {
+                 return sdf_generation::ExtractSignedDistanceField<COLLISION_CELL>(g, is_filled_fn, oob_value, g.GetFrame());
+             }, py::arg("is_filled_fn"), py::arg("oob_value"))
         .def("SetOccupancyFromNumpy", [](CollisionMapGrid& g, const py::array_t<float, py::array::c_style | py::array::forcecast>& occ) {
             if (occ.ndim() != 3 || occ.shape(0) != g.GetNumXCells() || occ.shape(1) != g.GetNumYCells() || occ.shape(2) != g.GetNumZCells())
                 throw std::invalid_argument("occupancy array must be [nx, ny, nz]");

@@ -87,6 +87,7 @@ struct sdfgpu_context {
     uint32_t* h_flags = nullptr;     // pinned host copy of the status block, written by the fold kernel of every build
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
+    hipEvent_t build_done_ev = nullptr;   // recorded behind every build: a build on another stream waits for it first
     bool prev_dense = false;
     bool expect_dense = false;
     bool last_dense = false;
@@ -552,7 +553,13 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
-    if (!h->small_clean || (h->have_result && s != h->last_stream)) HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
+    // Builds on one handle share its status block, extrema slots and scratch fields.  On the same stream they are
+    // ordered by the stream; a build issued on ANOTHER stream first waits for the previous build's last kernel.
+    if (h->have_result && s != h->last_stream) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
+    if (!h->small_clean) {
+        HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
+        HIP_TRY(h, hipMemsetAsync(h->d_slots, 0, (size_t)kSlots * kSlotWords * 4, s));   // a failed build may have left maxima behind
+    }
     h->small_clean = false;
     // profiling marks: an event is recorded only behind a stage that launched something; a stage that
     // was not launched shares the previous mark (elapsed 0), so profiling adds as few packets as possible
@@ -675,6 +682,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         HIP_TRY(h, mark(7));
         for (auto e : ev) h->events.push_back(e);
     }
+    HIP_TRY(h, hipEventRecord(h->build_done_ev, s));
     h->last_stream = s;
     h->last_resolution = resolution;
     h->last_n = n;
@@ -734,6 +742,7 @@ int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, s
     const bool timing = getenv("SDFGPU_HOST_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
+    // (out_sdf is scratch from here on: include/sdfgpu.h documents that its contents are undefined when the call fails)
     toucher.start(out_sdf, (size_t)n * 4);
     const double t1 = now();
     HIP_TRY(h, hipMemcpy(h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes, hipMemcpyHostToDevice));
@@ -782,15 +791,18 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
     sdfgpu_context* ctx = new (std::nothrow) sdfgpu_context();
     if (!ctx) return fail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
     ctx->device = device;
-    if (hipMalloc((void**)&ctx->d_slots, (size_t)kSlots * kSlotWords * 4) != hipSuccess ||
-        hipMemset(ctx->d_slots, 0, (size_t)kSlots * kSlotWords * 4) != hipSuccess) {
+    hipError_t ce = hipMalloc((void**)&ctx->d_slots, (size_t)kSlots * kSlotWords * 4);
+    if (ce == hipSuccess) ce = hipMemset(ctx->d_slots, 0, (size_t)kSlots * kSlotWords * 4);
+    if (ce == hipSuccess) ce = hipMalloc((void**)&ctx->d_small, 512);
+    if (ce == hipSuccess) ce = hipMemset(ctx->d_small, 0, 512);
+    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ctx->build_done_ev, hipEventDisableTiming);
+    if (ce != hipSuccess) {
         if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+        if (ctx->d_small) (void)hipFree(ctx->d_small);
+        if (ctx->build_done_ev) (void)hipEventDestroy(ctx->build_done_ev);
         delete ctx;
-        return SDFGPU_ERR_HIP;
-    }
-    if (hipMalloc((void**)&ctx->d_small, 512) != hipSuccess) {
-        delete ctx;
-        return fail(nullptr, SDFGPU_ERR_HIP, "hipMalloc failed for context scratch");
+        return fail(nullptr, SDFGPU_ERR_HIP, "HIP error %d (%s) while allocating the context's status blocks",
+                    (int)ce, hipGetErrorString(ce));
     }
     ctx->d_result = ctx->d_small + 64;                       // second half of the same allocation
     if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocMapped) != hipSuccess) ctx->h_flags = nullptr;
@@ -812,6 +824,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
     if (h->d_small) (void)hipFree(h->d_small);
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->flags_ev); }
+    if (h->build_done_ev) (void)hipEventDestroy(h->build_done_ev);
     for (size_t i = 0; i < h->events.size(); ++i)
         if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
@@ -1012,7 +1025,8 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
     if (cell_stride < 8 || (cell_stride % 4) || (occupancy_offset % 4) || (object_id_offset % 4) ||
         occupancy_offset + 4 > cell_stride || object_id_offset + 4 > cell_stride)
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell layout must be 4-byte aligned and in range");
-    if (object_mode < 0 || object_mode > 2 || n_object_ids < 0 || n_object_ids > 4096 || (object_mode == 2 && n_object_ids > 0 && !object_ids))
+    if (object_mode < 0 || object_mode > 2 || n_object_ids < 0 || n_object_ids > 0x7fffffffLL ||
+        (object_mode == 2 && n_object_ids > 0 && !object_ids))
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad object filter");
     if (object_mode == 2 && n_object_ids == 0) object_mode = 0;       // "no objects supplied" = any object (:826)
     if (int rc = check_dims(h, nx, ny, nz)) return rc;
@@ -1025,7 +1039,11 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
     PageToucher toucher;
     toucher.start(out_sdf, (size_t)n * 4);
     HIP_TRY(h, hipMemcpy(h->stage_in.ptr, cells, (size_t)n * cell_stride, hipMemcpyHostToDevice));
-    if (n_object_ids > 0) HIP_TRY(h, hipMemcpy(h->tagids.ptr, object_ids, (size_t)n_object_ids * 4, hipMemcpyHostToDevice));
+    if (n_object_ids > 0) {                        // sorted copy: the classify kernel binary-searches it
+        std::vector<uint32_t> sorted_ids(object_ids, object_ids + n_object_ids);
+        std::sort(sorted_ids.begin(), sorted_ids.end());
+        HIP_TRY(h, hipMemcpy(h->tagids.ptr, sorted_ids.data(), (size_t)n_object_ids * 4, hipMemcpyHostToDevice));
+    }
     hipLaunchKernelGGL(k_classify_tagged, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
                        (const char*)h->stage_in.ptr, (int64_t)cell_stride, (int64_t)occupancy_offset, (int64_t)object_id_offset,
                        unknown_is_filled, object_mode, (const uint32_t*)h->tagids.ptr, (int)n_object_ids, n,
@@ -1082,6 +1100,41 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
         hipLaunchKernelGGL(k_gradient<float>, grid, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution,
                            enable_edge_gradients);
     HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
+// Host-buffer form of the full-grid gradient (what SignedDistanceField::GetFullGradient / pysdf_tools'
+// GetFullGradientNumpy call instead of N host GetGradient calls): upload the field, one kernel, download.
+int sdfgpu_gradient(sdfgpu_handle h, const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                    int enable_edge_gradients, void* out_grad, int out_is_f64) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!sdf || !out_grad) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = (size_t)(nx * ny * nz), esz = out_is_f64 ? 8 : 4;
+    // the x axis is cut into chunks (+1 plane of context each side) so that the staging stays <= ~1.5 GiB even
+    // for the 24 B/voxel double output of a 512^3 field
+    const int64_t plane = ny * nz;
+    const int64_t max_rows = std::max<int64_t>(1, ((int64_t)1 << 26) / std::max<int64_t>(plane, 1));   // <= 64 Mi voxels per chunk
+    const int64_t rows = std::min<int64_t>(nx, max_rows);
+    if (int rc = ensure(h, h->stage_in, (size_t)(rows + 2) * plane * 4)) return rc;
+    if (int rc = ensure(h, h->stage_out, (size_t)(rows + 2) * plane * 3 * esz)) return rc;
+    (void)n;
+    PageToucher toucher;
+    toucher.start(out_grad, (size_t)nx * plane * 3 * esz);
+    for (int64_t x0 = 0; x0 < nx; x0 += rows) {
+        const int64_t x1 = std::min(nx, x0 + rows);
+        const int64_t lo = std::max<int64_t>(0, x0 - 1), hi = std::min(nx, x1 + 1);     // context planes
+        HIP_TRY(h, hipMemcpy(h->stage_in.ptr, sdf + lo * plane, (size_t)(hi - lo) * plane * 4, hipMemcpyHostToDevice));
+        // the kernel treats the chunk as a grid of its own: its first / last plane would take the one-sided boundary
+        // formula, so those planes are computed only when they ARE grid faces and are otherwise context that is skipped
+        if (int rc = sdfgpu_gradient_device(h, (const float*)h->stage_in.ptr, hi - lo, ny, nz, resolution, enable_edge_gradients,
+                                            h->stage_out.ptr, out_is_f64, nullptr)) return rc;
+        if (x0 == 0) toucher.join();
+        HIP_TRY(h, hipMemcpy((char*)out_grad + (size_t)x0 * plane * 3 * esz,
+                             (const char*)h->stage_out.ptr + (size_t)(x0 - lo) * plane * 3 * esz,
+                             (size_t)(x1 - x0) * plane * 3 * esz, hipMemcpyDeviceToHost));
+    }
     return SDFGPU_OK;
 }
 

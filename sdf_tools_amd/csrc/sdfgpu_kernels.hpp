@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
 // (occ > 0.5, or == 0.5 when unknown_is_filled) AND its object id passes the filter:
 //   mode 0: any object                      (free_sdf_filled_fn :736-749, and objects_to_use empty :826)
 //   mode 1: object_id > 0                   (object_filled_fn :757-775, "named objects")
-//   mode 2: object_id in the given id list  (object_use_map :817-827)
+//   mode 2: object_id in the given id list  (object_use_map :817-827); the list arrives sorted, any length
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_classify_tagged(const char* __restrict__ cells, int64_t stride,
                                                            int64_t occ_off, int64_t obj_off, int unknown_is_filled,
@@ -574,8 +574,14 @@ __global__ __launch_bounds__(kBlock) void k_classify_tagged(const char* __restri
     const float occ = *reinterpret_cast<const float*>(cells + i * stride + occ_off);
     const uint32_t obj = *reinterpret_cast<const uint32_t*>(cells + i * stride + obj_off);
     bool pass = mode == 0 || (mode == 1 && obj > 0u);
-    if (mode == 2)
-        for (int k = 0; k < n_ids; ++k) pass |= ids[k] == obj;
+    if (mode == 2) {                                   // ids are sorted ascending by the host: binary search
+        int lo = 0, hi = n_ids;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ids[mid] < obj) lo = mid + 1; else hi = mid;
+        }
+        pass = lo < n_ids && ids[lo] == obj;
+    }
     const bool occupied = (occ > 0.5f) || (unknown_is_filled && (occ == 0.5f));
     mask[i] = (pass && occupied) ? 1 : 0;
 }

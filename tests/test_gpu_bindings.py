@@ -117,3 +117,76 @@ def test_tagged_object_cells_match_oracle_per_filter():
                 want, want_ext, _ = O.exact_sdf(mask.astype(np.uint8), 0.25, vb)
                 np.testing.assert_array_equal(got, want)
                 assert ext == tuple(float(v) for v in want_ext)
+
+
+def test_cell_predicate_overload_matches_oracle():
+    """A8: the cell-predicate overload (reference sdf_generation.hpp:422-441) instantiated with a caller's predicate --
+    here a Python lambda on COLLISION_CELL with its own threshold and a component filter."""
+    rng = np.random.default_rng(5)
+    shape = (14, 11, 16)
+    occ = rng.random(shape).astype(np.float32)
+    g = m.CollisionMapGrid(m.Isometry3d(IDENT), "world", 0.2, *shape, m.COLLISION_CELL(0.0))
+    g.SetOccupancyFromNumpy(occ)
+    calls = []
+
+    def is_filled(cell):
+        calls.append(1)
+        return cell.occupancy > 0.7 and cell.component == 0
+
+    sdf, ext = g.ExtractSignedDistanceFieldCellPredicate(is_filled, 0.0)
+    assert len(calls) == occ.size                                      # evaluated exactly once per voxel
+    want, want_ext = O.reference_sdf((occ > 0.7).astype(np.uint8), 0.2)
+    assert np.array_equal(sdf.GetRawDataNumpy(), want) and ext == want_ext
+
+
+@pytest.mark.parametrize("shape", [(9, 12, 10), (33, 40, 64), (1, 20, 40)])
+def test_full_gradient_gpu_fast_path_equals_host_loop(shape):
+    """N1 behind the reference API: GetFullGradientNumpy (one kernel through sdfgpu_gradient) == the per-voxel
+    GetGradient loop of sdf.hpp:341-358, bit for bit, with and without edge gradients, identity and rotated frames."""
+    mask = synth.bernoulli_mask(shape, 0.3, 7)
+    rot = [[0.0, -1.0, 0.0, 0.3], [1.0, 0.0, 0.0, -0.2], [0.0, 0.0, 1.0, 0.1], [0, 0, 0, 1]]
+    for frame in (IDENT, rot):
+        g = m.CollisionMapGrid(m.Isometry3d(frame), "world", 0.05, *shape, m.COLLISION_CELL(0.0))
+        g.SetOccupancyFromNumpy(mask.astype(np.float32))
+        sdf, _ = g.ExtractSignedDistanceField(123.0, False, False)
+        for edge in (True, False):
+            fast = sdf.GetFullGradientNumpy(edge)
+            slow = sdf.GetFullGradientNumpyHost(edge)
+            assert fast.shape == shape + (3,)
+            assert np.array_equal(fast, slow)
+
+
+def test_full_gradient_256_is_fast():
+    """utils_3d.compute_sdf_and_gradient at 256^3 end to end (< 100 ms for the gradient part)."""
+    import time
+    n = 256
+    env = synth.bernoulli_mask((n, n, n), 0.5, 1).astype(np.float32)
+    obj = utils_3d.compute_sdf(env, 0.01, [0.0, 0.0, 0.0])
+    obj.GetFullGradientNumpy(True)
+    t0 = time.perf_counter()
+    grad = obj.GetFullGradientNumpy(True)
+    dt = time.perf_counter() - t0
+    assert grad.shape == (n, n, n, 3)
+    print("GetFullGradientNumpy 256^3: %.1f ms" % (dt * 1e3))
+    assert dt < 1.0                                                    # the per-voxel host loop takes ~10 s
+    # spot-check against the per-voxel API
+    for (x, y, z) in [(0, 0, 0), (5, 7, 9), (255, 255, 255), (128, 0, 3)]:
+        assert list(grad[x, y, z]) == obj.GetGradient(x, y, z, True)
+
+
+def test_tagged_object_filter_takes_many_ids():
+    """More object ids than the old 4096 cap; ids unsorted."""
+    from sdf_tools_amd import capi
+    rng = np.random.default_rng(3)
+    shape = (16, 16, 32)
+    cells = np.zeros(shape, dtype=np.dtype([("occupancy", "<f4"), ("component", "<u4"), ("object_id", "<u4"),
+                                            ("convex_segment", "<u4")]))
+    cells["occupancy"] = (rng.random(shape) < 0.3).astype(np.float32)
+    cells["object_id"] = rng.integers(0, 20000, size=shape)
+    ids = rng.permutation(np.arange(0, 20000, 2, dtype=np.uint32))     # 10000 even ids, shuffled
+    g = capi.SdfGpu(0)
+    got, ext = g.build_tagged_cells(cells, shape, object_mode=2, object_ids=ids, resolution=0.5)
+    mask = (cells["occupancy"] > 0.5) & (cells["object_id"] % 2 == 0)
+    want, want_ext, _ = O.exact_sdf(mask.astype(np.uint8), 0.5)
+    np.testing.assert_array_equal(got, want)
+    assert ext == tuple(float(v) for v in want_ext)
