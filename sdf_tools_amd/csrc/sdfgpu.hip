@@ -6,6 +6,7 @@
 #include "sdfgpu_fused_zy.hpp"
 #include "sdfgpu_dense.hpp"
 #include "sdfgpu_envelope.hpp"
+#include "sdfgpu_envelope_dc.hpp"
 
 #include <sys/mman.h>
 
@@ -75,6 +76,8 @@ struct sdfgpu_context {
     int ball_variant = 0;         // debugging: bit0 = bounds-checked expansion, bit1 = generic (non-ZINV) expansion
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
+    bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
+    bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
     int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // outward-scan bounds of the marching kernels
     bool env_mode_y = false, env_mode_x = false;               // policy: run the envelope kernel alone on that axis
@@ -340,17 +343,61 @@ int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t h
     return vb ? launch_march<3, true>(h, a, vec4, s) : launch_march<3, false>(h, a, vec4, s);
 }
 
-// KE2 / KE3: exact lower-envelope sweeps, run only when the bounded K2 / K3 raised their far flag
+// Shapes the divide-and-conquer envelope kernel takes: tiles of 16 memory-adjacent lines, keys that fit 32 bits.
+struct DcGeometry { bool ok; int B; uint32_t finf; int pitch; int M, Kp; };
+DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz) {
+    DcGeometry g{};
+    const int64_t L = stage == 2 ? ny : nx;
+    const int64_t group = stage == 2 ? nz : ny * nz;          // lines that are contiguous in memory
+    if (!h->envelope_dc || L < 1 || L > 1024 || (group % kDcLines) != 0 || (nz % 4) != 0) return g;
+    int B = 1;
+    while ((1ll << B) < L) ++B;
+    const int64_t finf = (nx - 1) * (nx - 1) + (ny - 1) * (ny - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2
+    if (finf + L * L >= (1ll << (32 - B))) return g;
+    g.ok = true; g.B = B; g.finf = (uint32_t)finf;
+    g.pitch = (int)(((L + 2 + 31) / 32) * 32 + 1);
+    g.M = (int)((L + kDcChunk - 1) / kDcChunk);
+    g.Kp = 0;
+    while ((1 << g.Kp) <= g.M) ++g.Kp;
+    return g;
+}
+
+// KE2 / KE3: exact far-field sweeps.  guard: run iff (*guard != 0) != guard_invert (nullptr: always).
 int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int32_t* d_side_in, void* d_out,
                     int32_t* d_side_out, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
-                    uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s) {
+                    uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s, int guard_invert = 0) {
+    (void)d_maxdsq;
+    const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz);
+    if (g.ok) {
+        EnvDcArgs a{};
+        a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
+        int64_t ntiles;
+        if (stage == 2) { ntiles = nx * (nz / kDcLines); a.tiles_per_outer = nz / kDcLines; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
+        else { ntiles = ny * nz / kDcLines; a.tiles_per_outer = ntiles; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
+        a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = g.Kp;
+        a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
+        a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
+        if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
+        const size_t lds = envelope_dc_lds_bytes(a.L, a.pitch);
+        if (lds > 64 * 1024 && !h->dc_lds_attr[stage - 2]) {
+            const void* fn = stage == 2 ? (const void*)k_envelope_dc<2> : (const void*)k_envelope_dc<3>;
+            HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            h->dc_lds_attr[stage - 2] = true;
+        }
+        if (stage == 2) hipLaunchKernelGGL(k_envelope_dc<2>, dim3((unsigned)ntiles), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(k_envelope_dc<3>, dim3((unsigned)ntiles), dim3(256), lds, s, a);
+        HIP_TRY(h, hipGetLastError());
+        return SDFGPU_OK;
+    }
+    if (guard_invert) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "inverted guard needs the divide-and-conquer envelope kernel");
+    // first-generation kernel (one lane per line, stacks in a global scratch array of 8 B/voxel, allocated only here)
+    if (int rc = ensure(h, h->env, (size_t)(nx * ny * nz) * 8)) return rc;
     EnvArgs a{};
     a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
     a.scratch = (int2*)h->env.ptr;
     if (stage == 2) { a.nlines = nx * nz; a.cpl = nz; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
     else { a.nlines = ny * nz; a.cpl = a.nlines; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
     a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
-    (void)d_maxdsq;
     a.maxdsq = h->d_slots; a.guard = guard;
     dim3 grid((unsigned)((a.nlines + kBlock - 1) / kBlock)), block(kBlock);
     if (stage == 2) hipLaunchKernelGGL(k_envelope<2>, grid, block, 0, s, a);
@@ -550,7 +597,6 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
-    if (envelope) if (int rc = ensure(h, h->env, (size_t)n * 8)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
     // Builds on one handle share its status block, extrema slots and scratch fields.  On the same stream they are
@@ -1231,6 +1277,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "plane16") h->plane16_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;
+    else if (n == "envelope_dc") h->envelope_dc = value != 0;
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;

@@ -143,3 +143,47 @@ def test_envelope_rare_paths_deep_pops_and_dense_advances(gpu):
     finally:
         gpu.set_option("envelope_mode", 0)
         gpu.set_option("dense", 1)
+
+
+DC_SHAPES = [(40, 100, 48), (1024, 4, 16), (7, 1024, 16), (512, 8, 32), (13, 9, 16), (2, 3, 16), (1, 1, 64), (24, 520, 32),
+             (65, 63, 80), (16, 16, 20)]
+
+
+@pytest.mark.parametrize("shape", DC_SHAPES, ids=["x".join(map(str, s)) for s in DC_SHAPES])
+def test_divide_and_conquer_envelope_kernel_is_exact(gpu, shape):
+    """k_envelope_dc (sdfgpu_envelope_dc.hpp) as the ONLY sweep of the y and x axes: line lengths that are not multiples
+    of 8, of length 1, 512 and 1024 (keys at their 32-bit limit), lines without sites, both classes, virtual border;
+    and the same scenes through the first-generation kernel (option envelope_dc = 0; (16,16,20) always takes it:
+    nz % 16 != 0).  Everything must equal the exact oracle bit for bit."""
+    gpu.set_option("policy_reset", 1)
+    gpu.set_option("dense", 0)
+    gpu.set_option("envelope_mode", 1)
+    rng = np.random.default_rng(abs(hash(shape)) % (1 << 31))
+    nx, ny, nz = shape
+    scenes_ = {
+        "sparse": synth.bernoulli_mask(shape, 0.002, 3),
+        "boxes": _two_boxes(shape),
+        "single": scenes.single_voxel(shape),
+        "inverse single": 1 - scenes.single_voxel(shape, (nx - 1, 0, nz // 3)),
+        "all free": np.zeros(shape, np.uint8),
+        "all filled": np.ones(shape, np.uint8),
+        "half dense": np.concatenate([synth.bernoulli_mask((nx, ny, nz - nz // 2), 0.4, 9), np.zeros((nx, ny, nz // 2), np.uint8)], axis=2),
+    }
+    hgt = (rng.random((nx, ny)) * nz * 0.8).astype(int)
+    scenes_["height field"] = (np.arange(nz)[None, None, :] >= hgt[:, :, None]).astype(np.uint8)
+    try:
+        for name, m in scenes_.items():
+            for vb in (False, True):
+                ex, ex_ext, _ = O.exact_sdf(m, 0.05, vb)
+                for dc in (1, 0):
+                    gpu.set_option("envelope_dc", dc)
+                    gpu.set_option("envelope_mode", 1)
+                    sdf, ext = gpu.build(m, 0.05, vb)
+                    bad = np.argwhere(sdf.view(np.uint32) != ex.view(np.uint32))
+                    assert len(bad) == 0, "%s vb=%s dc=%d: %d voxels differ, first %s got %r want %r" % (
+                        name, vb, dc, len(bad), bad[0].tolist(), sdf[tuple(bad[0])], ex[tuple(bad[0])])
+                    assert ext == ex_ext, (name, vb, dc, ext, ex_ext)
+    finally:
+        gpu.set_option("envelope_dc", 1)
+        gpu.set_option("envelope_mode", 0)
+        gpu.set_option("dense", 1)
