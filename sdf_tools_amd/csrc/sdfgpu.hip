@@ -77,6 +77,7 @@ struct sdfgpu_context {
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
     bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
+    int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
     int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // outward-scan bounds of the marching kernels
@@ -376,7 +377,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         else { ntiles = ny * nz / kDcLines; a.tiles_per_outer = ntiles; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
         a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = g.Kp;
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
-        a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
+        a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert; a.dbg = h->dc_debug;
         if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
         const size_t lds = envelope_dc_lds_bytes(a.L, a.pitch);
         if (lds > 64 * 1024 && !h->dc_lds_attr[stage - 2]) {
@@ -1278,6 +1279,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense") h->dense_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;
     else if (n == "envelope_dc") h->envelope_dc = value != 0;
+    else if (n == "dc_debug") h->dc_debug = value;
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;

@@ -40,6 +40,10 @@ namespace sdfgpu {
 
 constexpr int kDcLines = 16;          // lines per tile
 constexpr int kDcChunk = 8;           // positions per lane in the chunk phase
+constexpr int kDcBatch = 8;           // staging: row loads in flight per lane
+constexpr int kDcBrute = 24;          // chunk phase: candidate ranges below this are searched exhaustively
+constexpr int kDcLocalMax = 64;       // pass 0 finishes filled voxels whose in-row squared distance is at most this ...
+constexpr int kDcLocalFilled = 96;    // ... when the tile holds at most this many filled voxels (of 16 x L)
 
 struct EnvDcArgs {
     const int16_t* in16;      // STAGE 2: z field (+-g, 32767 = none); STAGE 3: plane field p16
@@ -60,6 +64,8 @@ struct EnvDcArgs {
     uint32_t* maxdsq;         // slot array (STAGE 3)
     const uint32_t* guard;    // nullptr: always run; else run iff (*guard != 0) != guard_invert
     int guard_invert;
+    int dbg;                  // profiling aid (wrong results!): bit0 skip upper levels, bit1 skip chunk search, bit2 skip stores,
+                              // bit3 skip the second class, bit4 skip key conversion
 };
 
 inline size_t envelope_dc_lds_bytes(int L, int pitch) {
@@ -68,7 +74,7 @@ inline size_t envelope_dc_lds_bytes(int L, int pitch) {
 }
 
 template <int STAGE>
-__global__ __launch_bounds__(256) void k_envelope_dc(const EnvDcArgs a) {
+__global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dc_smem[];
     if (a.guard) {
         const uint32_t gv = *a.guard;
@@ -84,10 +90,15 @@ __global__ __launch_bounds__(256) void k_envelope_dc(const EnvDcArgs a) {
     uint16_t* args = reinterpret_cast<uint16_t*>(flg + 32);     // [16][AP]   argmin of coarse position i' (1-based)
     const int t = threadIdx.x;
 
-    // tile of this workgroup; consecutive tiles share cache lines (16 lines x 2 B = 32 B of a 128-B line), so the
-    // workgroups that an XCD receives round-robin are mapped to one contiguous range of tiles
+    // tile of this workgroup.  Four consecutive tiles share cache lines (16 lines x 2 B = 32 B of a 128-B line), so an XCD
+    // (workgroups are dealt to the 8 XCDs round-robin, each with its own L2) gets runs of 4 consecutive tiles; the runs
+    // themselves are dealt round-robin, so that every XCD sees every part of the grid (work is not uniform in space:
+    // a tile far from every object is trivial)
     int64_t tile = blockIdx.x;
-    if ((gridDim.x & 7u) == 0u) tile = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if ((gridDim.x & 31u) == 0u) {
+        const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+        tile = ((int64_t)(seq >> 2) * 8 + xcd) * 4 + (seq & 3u);
+    }
     const int64_t o = tile / a.tiles_per_outer;
     const int64_t c0 = (tile - o * a.tiles_per_outer) * kDcLines;
     const int64_t base = o * a.outer_stride + c0;               // element index of (line 0, position 0)
@@ -124,90 +135,179 @@ __global__ __launch_bounds__(256) void k_envelope_dc(const EnvDcArgs a) {
         }
     }
 
+    // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
+    auto raw_signed = [&](int line, int q) -> int {
+        const int64_t idx = base + line + (int64_t)q * ls;
+        int v = a.in16[idx];
+        if constexpr (STAGE == 2) {
+            const int g = abs(v);
+            const int sq = g >= kInf16 ? kInf32 : g * g;
+            return v < 0 ? -sq : sq;
+        } else {
+            if (abs(v) >= kSat16) v = a.side_in[idx];
+            return v;
+        }
+    };
+    // finish one voxel: STAGE 2 plane field (+ side table on request), STAGE 3 the reference's merge arithmetic
+    auto emit = [&](int line, int p, int D, bool filled, bool side) {
+        const int64_t oi = base + line + (int64_t)p * ls;
+        if constexpr (STAGE == 2) {
+            reinterpret_cast<int16_t*>(a.out)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
+            if (side) a.side_out[oi] = filled ? -D : D;
+        } else {
+            if (a.vb) {
+                int b = byz;
+                if (a.nx > 1) b = min(b, (int)min((int64_t)p + 1, a.nx - p));
+                if (b < 32768) D = min(D, b * b);
+            }
+            if (filled) mxQ = max(mxQ, D); else mxF = max(mxF, D);
+            const float f = (D >= kInf32) ? __builtin_inff() : (float)(sqrt((double)D) * a.resolution);
+            reinterpret_cast<float*>(a.out)[oi] = filled ? -f : f;
+        }
+    };
+
 #pragma unroll 1
     for (int cls = 0; cls < 2; ++cls) {         // 0: sites of "distance to filled" (for free voxels); 1: the reverse
-        // ---- stage the tile: rows -> keys ----------------------------------------------------------------------------
-        if (cls == 0) {
-            for (int i = t; i < kDcLines * SW; i += 256) sgn[i] = 0u;
-            if (t < 32) flg[t] = 0u;
-        }
-        if (t < 16) { span[2 * t] = 0xFFFFFFFFu; span[2 * t + 1] = 0u; }
-        __syncthreads();
-        if (cls == 1 && flg[16] == 0u) break;   // no filled voxel in the tile: nothing to produce (block-uniform)
+        if (cls == 0 && t == 0) { flg[16] = 0u; flg[17] = 0u; }   // (ordered before their users by the barriers of pass 0)
+        // ---- stage the tile ----------------------------------------------------------------------------------------------
+        // step 1: rows -> LDS, the exact signed value of every voxel parked in its key slot.  Nothing but loads and LDS
+        //         writes, a batch of independent row loads in flight per lane (a lane reads 4 lines x 1 position = 8 B; STAGE 3
+        //         adds the 16-B side-table group where the 16-bit value is saturated).
+        // step 2: slots -> keys in place, lane = (line, 16 consecutive positions per step): sign bits by ballot, first / last
+        //         site by a 16-lane reduction, no atomics.
+        if (cls == 1 && (a.dbg & 8)) break;
+        // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose
+        // in-row squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can
+        // only matter while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises flg[17] for the rest.
+        if (cls == 1 && flg[17] == 0u) break;   // (block-uniform)
         {
             const int sub = t & 3, r = t >> 2;
-            uint32_t mn[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[4] = {0u, 0u, 0u, 0u};
-            bool anyf[4] = {false, false, false, false};
-            for (int p = r; p < L; p += 64) {
-                const int64_t idx = base + (int64_t)p * ls + 4 * sub;
-                const uint2 raw = *reinterpret_cast<const uint2*>(a.in16 + idx);
-                int s[4] = {(int)(short)(raw.x & 0xffffu), (int)(short)(raw.x >> 16), (int)(short)(raw.y & 0xffffu),
-                            (int)(short)(raw.y >> 16)};
-                if constexpr (STAGE == 2) {
+            int32_t* slots = reinterpret_cast<int32_t*>(keys);
+            for (int pb = 0; pb < L; pb += 64 * kDcBatch) {
+                uint2 raw[kDcBatch];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int g = abs(s[k]);
-                        const int sq = g >= kInf16 ? kInf32 : g * g;
-                        s[k] = s[k] < 0 ? -sq : sq;
+                for (int it = 0; it < kDcBatch; ++it) {
+                    const int p = min(pb + 64 * it + r, L - 1);
+                    raw[it] = *reinterpret_cast<const uint2*>(a.in16 + base + (int64_t)p * ls + 4 * sub);
+                }
+                if constexpr (STAGE == 3) {
+                    int4 ex[kDcBatch];
+                    uint32_t satm = 0u;
+#pragma unroll
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        const int p = min(pb + 64 * it + r, L - 1);
+                        // |v| >= 32767 for a 16-bit lane: v == 32767 or v == -32767 (-32768 is never stored)
+                        const uint32_t x = raw[it].x, y = raw[it].y;
+                        const bool sat = ((x & 0xffffu) == 0x7fffu) | ((x & 0xffffu) == 0x8001u) | ((x >> 16) == 0x7fffu) | ((x >> 16) == 0x8001u) |
+                                         ((y & 0xffffu) == 0x7fffu) | ((y & 0xffffu) == 0x8001u) | ((y >> 16) == 0x7fffu) | ((y >> 16) == 0x8001u);
+                        if (sat) { ex[it] = *reinterpret_cast<const int4*>(a.side_in + base + (int64_t)p * ls + 4 * sub); satm |= 1u << it; }
+                    }
+#pragma unroll
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        const int p = pb + 64 * it + r;
+                        if (p < L) {
+                            const bool sat = (satm >> it) & 1u;
+                            int32_t* d = slots + (4 * sub) * pitch + p;
+                            d[0] = sat ? ex[it].x : (int)(short)(raw[it].x & 0xffffu);
+                            d[pitch] = sat ? ex[it].y : (int)(short)(raw[it].x >> 16);
+                            d[2 * pitch] = sat ? ex[it].z : (int)(short)(raw[it].y & 0xffffu);
+                            d[3 * pitch] = sat ? ex[it].w : (int)(short)(raw[it].y >> 16);
+                        }
                     }
                 } else {
-                    bool sat = false;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) sat |= abs(s[k]) >= kSat16;
-                    if (sat) {
-                        const int4 e = *reinterpret_cast<const int4*>(a.side_in + idx);
-                        s[0] = e.x; s[1] = e.y; s[2] = e.z; s[3] = e.w;
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        const int p = pb + 64 * it + r;
+                        if (p < L) {
+                            int32_t* d = slots + (4 * sub) * pitch + p;
+                            d[0] = (int)(short)(raw[it].x & 0xffffu);
+                            d[pitch] = (int)(short)(raw[it].x >> 16);
+                            d[2 * pitch] = (int)(short)(raw[it].y & 0xffffu);
+                            d[3 * pitch] = (int)(short)(raw[it].y >> 16);
+                        }
                     }
                 }
-                const uint32_t pp = (uint32_t)p * (uint32_t)p;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int line = 4 * sub + k;
-                    uint32_t F;
-                    bool none;
-                    if (cls == 0) {
-                        if (s[k] < 0) { atomicOr(&sgn[line * SW + (p >> 5)], 1u << (p & 31)); anyf[k] = true; }
-                        F = s[k] > 0 ? (uint32_t)s[k] : 0u;
-                        none = s[k] >= kInf32;
-                    } else if (s[k] < 0) {
-                        F = (uint32_t)(-s[k]);
-                        none = -s[k] >= kInf32;
-                    } else {                    // free voxel: a zero-valued site only next to a filled voxel of its line
-                        F = 0u;
-                        bool nb = false;
-                        if (p > 0) nb |= (sgn[line * SW + ((p - 1) >> 5)] >> ((p - 1) & 31)) & 1u;
-                        if (p + 1 < L) nb |= (sgn[line * SW + ((p + 1) >> 5)] >> ((p + 1) & 31)) & 1u;
-                        none = !nb;
-                    }
-                    keys[line * pitch + p] = (((none ? finf : F) + pp) << B) | (uint32_t)p;
-                    if (!none) { mn[k] = min(mn[k], (uint32_t)p); mx[k] = max(mx[k], (uint32_t)p); }
+            }
+        }
+        __syncthreads();
+        {
+            const int lineU = t >> 4, g = t & 15;
+            uint32_t* kl = keys + lineU * pitch;
+            uint16_t* sg = reinterpret_cast<uint16_t*>(sgn) + lineU * (2 * SW);      // 16 positions per half-word
+            uint32_t mn = 0xFFFFFFFFu, mx = 0u, nfilled = 0u;
+            bool anyf = false;
+            for (int p0 = 0; p0 < ((a.dbg & 16) ? 16 : L); p0 += 16) {
+                const int p = p0 + g;
+                const bool inl = p < L;
+                int sv = inl ? (int)kl[p] : 1;
+                if constexpr (STAGE == 2) {
+                    const int gz = abs(sv);
+                    const int sq = gz >= kInf16 ? kInf32 : gz * gz;
+                    sv = sv < 0 ? -sq : sq;
+                }
+                uint32_t F;
+                bool none;
+                if (cls == 0) {
+                    const uint64_t fb = __ballot(inl && sv < 0);
+                    const uint32_t bits = (uint32_t)(fb >> (16 * ((t >> 4) & 3))) & 0xFFFFu;
+                    if (g == 0) sg[p0 >> 4] = (uint16_t)bits;
+                    anyf |= bits != 0u;
+                    nfilled += __popc(bits);
+                    F = (uint32_t)max(sv, 0);
+                    none = sv >= kInf32;
+                } else if (sv < 0) {
+                    F = (uint32_t)(-sv);
+                    none = -sv >= kInf32;
+                } else {                        // free voxel: a zero-valued site only next to a filled voxel of its line
+                    F = 0u;
+                    bool nb = false;
+                    if (p > 0) nb |= (sg[(p - 1) >> 4] >> ((p - 1) & 15)) & 1u;
+                    if (p + 1 < L) nb |= (sg[(p + 1) >> 4] >> ((p + 1) & 15)) & 1u;
+                    none = !nb;
+                }
+                if (inl) {
+                    kl[p] = (((none ? finf : F) + (uint32_t)p * (uint32_t)p) << B) | (uint32_t)p;
+                    if (!none) { mn = min(mn, (uint32_t)p); mx = max(mx, (uint32_t)p); }
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int line = 4 * sub + k;
-                if (mn[k] != 0xFFFFFFFFu) { atomicMin(&span[2 * line], mn[k]); atomicMax(&span[2 * line + 1], mx[k]); }
-                if (anyf[k]) { flg[line] = 1u; flg[16] = 1u; }
+            for (int off = 1; off < 16; off <<= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
             }
-            if (t < 16) keys[t * pitch + L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);   // sentinel
+            if (g == 0) {
+                span[2 * lineU] = mn; span[2 * lineU + 1] = mx;
+                kl[L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);                  // sentinel
+                if (cls == 0 && anyf) atomicAdd(&flg[16], nfilled);
+            }
         }
         __syncthreads();
 
-        // ---- upper levels: coarse positions p = 8 (i' - 1), i' = 1 .. M, 16 lanes per line -------------------------------
+        // ---- upper levels: coarse positions p = 8 (i' - 1), i' = 1 .. M ---------------------------------------------------
+        // Levels with few positions split each position's candidate range over several lanes of the line's 16-lane row
+        // (min-reduced with shuffles); levels with many positions switch to lane = (line, slot): the 16 lanes of a row then
+        // work on the SAME position of 16 neighbouring lines, whose ranges are alike (the scene is coherent across
+        // lines), so the per-lane loops of a row have nearly the same trip count.
+        const bool many_filled = flg[16] > (uint32_t)kDcLocalFilled;
+        const int lineT = t & 15, slotT = t >> 4;
+        const uint32_t qmnT = span[2 * lineT], qmxT = span[2 * lineT + 1];
+        const bool actT = qmnT <= qmxT;
         {
             const int lineU = t >> 4, g = t & 15;
             const uint32_t* klU = keys + lineU * pitch;
             uint16_t* aU = args + lineU * AP;
             const uint32_t qmn = span[2 * lineU], qmx = span[2 * lineU + 1];
             const bool actU = qmn <= qmx;
-            for (int l = 0; l < Kp; ++l) {
+            const uint32_t* klT = keys + lineT * pitch;
+            uint16_t* aT = args + lineT * AP;
+            for (int l = 0; l < ((a.dbg & 1) ? 0 : Kp); ++l) {
                 const int h = 1 << (Kp - 1 - l);
-                const int sh = l < 4 ? 4 - l : 0;               // log2 of the lanes per position
-                const int G = 1 << sh;
-                const int npl = l > 4 ? 1 << (l - 4) : 1;       // positions per lane
-                for (int k = 0; k < npl; ++k) {
-                    const int j = (g >> sh) + 16 * k;
-                    const int u = g & (G - 1);
+                const int n = (M / h + 1) >> 1;                 // positions of this level: i' = h (2 j + 1) <= M
+                if (n <= 8) {
+                    int sh = 4;                                 // log2 of the lanes per position
+                    while ((16 >> sh) < n) --sh;
+                    const int G = 1 << sh;
+                    const int j = g >> sh, u = g & (G - 1);
                     const int ip = h * (2 * j + 1);
                     const bool valid = actU && ip <= M;
                     int lo = 1, hi = 0;
@@ -218,6 +318,16 @@ __global__ __launch_bounds__(256) void k_envelope_dc(const EnvDcArgs a) {
                     uint32_t best = scan(klU, 8u * (uint32_t)(ip - 1), lo, hi, u, G);
                     for (int off = 1; off < G; off <<= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off));
                     if (valid && u == 0) aU[ip] = (uint16_t)(best & mask);
+                } else {
+                    for (int j = slotT; j < n; j += 16) {
+                        const int ip = h * (2 * j + 1);
+                        if (actT) {
+                            const int lo = (ip - h == 0) ? (int)qmnT : (int)aT[ip - h];
+                            const int hi = (ip + h > M) ? (int)qmxT : (int)aT[ip + h];
+                            const uint32_t best = scan(klT, 8u * (uint32_t)(ip - 1), lo, hi, 0, 1);
+                            aT[ip] = (uint16_t)(best & mask);
+                        }
+                    }
                 }
                 __syncthreads();
             }
@@ -225,11 +335,11 @@ __global__ __launch_bounds__(256) void k_envelope_dc(const EnvDcArgs a) {
 
         // ---- chunk phase: lane = (line, chunk of 8 positions); finish and store -------------------------------------------
         {
-            const int line = t & 15, slot = t >> 4;
+            const int line = lineT, slot = slotT;
             const uint32_t* kl = keys + line * pitch;
             const uint16_t* al = args + line * AP;
-            const uint32_t qmn = span[2 * line], qmx = span[2 * line + 1];
-            const bool act = qmn <= qmx;
+            const uint32_t qmx = qmxT;
+            const bool act = actT;
             for (int i0 = 0; i0 < M; i0 += 16) {
                 const int i = i0 + slot;
                 const bool live = i < M;
@@ -237,9 +347,38 @@ __global__ __launch_bounds__(256) void k_envelope_dc(const EnvDcArgs a) {
                 int D[kDcChunk];
 #pragma unroll
                 for (int k = 0; k < kDcChunk; ++k) D[k] = kInf32;
-                if (live && act) {
-                    const int a0 = al[i + 1];
-                    const int a8 = (i + 2 <= M) ? (int)al[i + 2] : (int)qmx;
+                const int a0 = (live && act && !(a.dbg & 2)) ? (int)al[i + 1] : 0;
+                const int a8 = (live && act && !(a.dbg & 2)) ? ((i + 2 <= M) ? (int)al[i + 2] : (int)qmx) : -1;
+                if (live && act && a8 - a0 < kDcBrute) {
+                    // few candidates (the common case: the argmin moves ~ half a site per position): all 8 positions against
+                    // every candidate of [a0, a8], branch-free, two candidates per step; 2 VALU per evaluation, no per-position
+                    // set-up.  With p_k = p0 + k: R_k(q) = (p_k^2 << B) - ((2 p_k) << B) q, R_k(a0) - R_{k-1}(a0) =
+                    // ((2 (p0 - a0) + 2k - 1) << B).
+                    uint32_t R[kDcChunk], nc[kDcChunk], best[kDcChunk];
+                    const uint32_t W = (uint32_t)(2 * (p0 - a0)) << B;
+                    R[0] = (((uint32_t)p0 * (uint32_t)p0) << B) - (((uint32_t)(2 * p0)) << B) * (uint32_t)a0;
+                    nc[0] = 0u - ((uint32_t)(2 * p0) << B);
+                    best[0] = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = 1; k < kDcChunk; ++k) {
+                        R[k] = R[k - 1] + W + ((uint32_t)(2 * k - 1) << B);
+                        nc[k] = nc[k - 1] - (2u << B);
+                        best[k] = 0xFFFFFFFFu;
+                    }
+                    for (int q = a0; q <= a8; q += 2) {
+                        const uint32_t k0 = kl[q], k1 = kl[q + 1];
+#pragma unroll
+                        for (int k = 0; k < kDcChunk; ++k) {
+                            best[k] = min(best[k], min(k0 + R[k], k1 + R[k] + nc[k]));
+                            R[k] += 2u * nc[k];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < kDcChunk; ++k) {
+                        const uint32_t d = best[k] >> B;
+                        D[k] = d >= finf ? kInf32 : (int)d;
+                    }
+                } else if (live && act && !(a.dbg & 2)) {
                     // position p0 + k over [lo, hi]: distance to D[k], argmin returned (positions beyond the line end
                     // only pass the upper bound on)
                     auto pos = [&](auto kc, int lo, int hi) -> int {
@@ -266,32 +405,35 @@ __global__ __launch_bounds__(256) void k_envelope_dc(const EnvDcArgs a) {
                     const int p = p0 + k;
                     const bool inl = live && p < L;
                     const bool filled = (cm >> k) & 1u;
-                    const bool mine = inl && (filled == (cls == 1));
-                    const int64_t oi = base + line + (int64_t)p * ls;
+                    const bool mine = inl && (filled == (cls == 1)) && !(a.dbg & 4);
                     if constexpr (STAGE == 2) {
                         // side-table convention (sdfgpu_sweep_x16.hpp): if ANY voxel of a group of 4 is saturated, the
-                        // exact values of the whole group must be in the side table.  This pass only knows its own
-                        // class, so a voxel also writes its exact value when its group holds a voxel of the other class
-                        // (those write theirs in their own pass: always).
+                        // exact values of the whole group must be in the side table.  A pass only knows its own class, so a
+                        // voxel also writes its exact value when its group holds a voxel of the other class (filled voxels
+                        // always write theirs).
                         const int need = mine ? (D[k] >= kSat16 ? 1 : 0) : (inl ? 1 : 0);
                         int any = need | __shfl_xor(need, 1);
                         any |= __shfl_xor(any, 2);
-                        if (mine) {
-                            const int sD = filled ? -D[k] : D[k];
-                            reinterpret_cast<int16_t*>(a.out)[oi] = (int16_t)(filled ? -min(D[k], kSat16) : min(D[k], kSat16));
-                            if (cls == 1 || any) a.side_out[oi] = sD;
-                        }
+                        if (mine) emit(line, p, D[k], filled, cls == 1 || any);
                     } else {
-                        if (mine) {
-                            int Dk = D[k];
-                            if (a.vb) {
-                                int b = byz;
-                                if (a.nx > 1) b = min(b, (int)min((int64_t)p + 1, a.nx - p));
-                                if (b < 32768) Dk = min(Dk, b * b);
+                        if (mine) emit(line, p, D[k], filled, false);
+                    }
+                }
+                // pass 0 finishes the tile's filled voxels itself when they are few and shallow (thin surfaces): exact local
+                // search along the line -- a candidate at offset d can only win while d^2 < the best so far
+                if (cls == 0 && cm != 0u && !(a.dbg & 8)) {
+                    if (many_filled) {
+                        flg[17] = 1u;
+                    } else {
+                        for (uint32_t rest = cm; rest; rest &= rest - 1u) {
+                            const int p = p0 + __ffs((int)rest) - 1;
+                            int D1 = -raw_signed(line, p);
+                            if (D1 > kDcLocalMax) { flg[17] = 1u; continue; }
+                            for (int d = 1; d * d < D1; ++d) {
+                                if (p - d >= 0) D1 = min(D1, d * d + max(-raw_signed(line, p - d), 0));
+                                if (p + d < L) D1 = min(D1, d * d + max(-raw_signed(line, p + d), 0));
                             }
-                            if (filled) mxQ = max(mxQ, Dk); else mxF = max(mxF, Dk);
-                            const float f = (Dk >= kInf32) ? __builtin_inff() : (float)(sqrt((double)Dk) * a.resolution);
-                            reinterpret_cast<float*>(a.out)[oi] = filled ? -f : f;
+                            emit(line, p, D1, true, true);
                         }
                     }
                 }

@@ -69,6 +69,12 @@ def dc_line(F, FINF):
             assert lo <= (k & mask) <= hi
             return k & mask
 
+        if a8 - a0 < 24:            # few candidates: every position of the chunk against all of [a0, a8] (pairs: a8 + 1 may be read)
+            for k in range(8):
+                if p0 + k < L:
+                    best = min(scan(p0 + k, a0, a8), 0xFFFFFFFF)
+                    D[p0 + k] = best >> B
+            continue
         pos(p0, a0, a0)
         a4 = pos(p0 + 4, a0, a8)
         a2 = pos(p0 + 2, a0, a4)
