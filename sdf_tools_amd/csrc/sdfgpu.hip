@@ -350,7 +350,8 @@ DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, 
     DcGeometry g{};
     const int64_t L = stage == 2 ? ny : nx;
     const int64_t group = stage == 2 ? nz : ny * nz;          // lines that are contiguous in memory
-    if (!h->envelope_dc || L < 1 || L > 1024 || (group % kDcLines) != 0 || (nz % 4) != 0) return g;
+    if (!h->envelope_dc || L < 1 || L > 1024 || (group % kDcLines) != 0 || (nz % 4) != 0 ||
+        nx * ny * nz >= (1ll << 31)) return g;                  // (the kernel uses 32-bit element offsets inside a tile's lines)
     int B = 1;
     while ((1ll << B) < L) ++B;
     const int64_t finf = (nx - 1) * (nx - 1) + (ny - 1) * (ny - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2

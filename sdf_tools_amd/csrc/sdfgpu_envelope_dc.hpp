@@ -102,16 +102,18 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     const int64_t o = tile / a.tiles_per_outer;
     const int64_t c0 = (tile - o * a.tiles_per_outer) * kDcLines;
     const int64_t base = o * a.outer_stride + c0;               // element index of (line 0, position 0)
-    const int64_t ls = a.line_stride;
+    const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
+    const int16_t* const in16 = a.in16 + base;
+    const int32_t* const side_in = STAGE == 3 ? a.side_in + base : nullptr;
 
     // one candidate range for one position: lanes u = 0 .. G-1 of a group take the pairs lo + 2u, lo + 2u + 2G, ...
     // (the second key of the last pair may be candidate hi + 1: it can tie but never beat the range's minimum, and on a
     // tie the smaller position wins the unsigned min, so the argmin stays inside [lo, hi])
     auto scan = [&](const uint32_t* kl, uint32_t p, int lo, int hi, int u, int G) -> uint32_t {
-        const uint32_t c = (2u * p) << B;
+        const uint32_t c = (2u * p) << B;                       // < 2^22: 24-bit multiplies are exact mod 2^32
         int q = lo + 2 * u;
-        uint32_t R = ((p * p) << B) - c * (uint32_t)q;
-        const uint32_t dR = c * (uint32_t)(2 * G);
+        uint32_t R = (__umul24(p, p) << B) - __umul24(c, (uint32_t)q);
+        const uint32_t dR = __umul24(c, (uint32_t)(2 * G));
         uint32_t best = 0xFFFFFFFFu;
         for (; q <= hi; q += 2 * G) {
             const uint32_t k0 = kl[q], k1 = kl[q + 1];
@@ -137,23 +139,23 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
 
     // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
     auto raw_signed = [&](int line, int q) -> int {
-        const int64_t idx = base + line + (int64_t)q * ls;
-        int v = a.in16[idx];
+        const uint32_t idx = (uint32_t)line + (uint32_t)q * ls;
+        int v = in16[idx];
         if constexpr (STAGE == 2) {
             const int g = abs(v);
             const int sq = g >= kInf16 ? kInf32 : g * g;
             return v < 0 ? -sq : sq;
         } else {
-            if (abs(v) >= kSat16) v = a.side_in[idx];
+            if (abs(v) >= kSat16) v = side_in[idx];
             return v;
         }
     };
     // finish one voxel: STAGE 2 plane field (+ side table on request), STAGE 3 the reference's merge arithmetic
     auto emit = [&](int line, int p, int D, bool filled, bool side) {
-        const int64_t oi = base + line + (int64_t)p * ls;
+        const uint32_t oi = (uint32_t)line + (uint32_t)p * ls;
         if constexpr (STAGE == 2) {
-            reinterpret_cast<int16_t*>(a.out)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
-            if (side) a.side_out[oi] = filled ? -D : D;
+            (reinterpret_cast<int16_t*>(a.out) + base)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
+            if (side) (a.side_out + base)[oi] = filled ? -D : D;
         } else {
             if (a.vb) {
                 int b = byz;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             }
             if (filled) mxQ = max(mxQ, D); else mxF = max(mxF, D);
             const float f = (D >= kInf32) ? __builtin_inff() : (float)(sqrt((double)D) * a.resolution);
-            reinterpret_cast<float*>(a.out)[oi] = filled ? -f : f;
+            (reinterpret_cast<float*>(a.out) + base)[oi] = filled ? -f : f;
         }
     };
 
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
 #pragma unroll
                 for (int it = 0; it < kDcBatch; ++it) {
                     const int p = min(pb + 64 * it + r, L - 1);
-                    raw[it] = *reinterpret_cast<const uint2*>(a.in16 + base + (int64_t)p * ls + 4 * sub);
+                    raw[it] = *reinterpret_cast<const uint2*>(in16 + ((uint32_t)p * ls + 4u * sub));
                 }
                 if constexpr (STAGE == 3) {
                     int4 ex[kDcBatch];
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                         const uint32_t x = raw[it].x, y = raw[it].y;
                         const bool sat = ((x & 0xffffu) == 0x7fffu) | ((x & 0xffffu) == 0x8001u) | ((x >> 16) == 0x7fffu) | ((x >> 16) == 0x8001u) |
                                          ((y & 0xffffu) == 0x7fffu) | ((y & 0xffffu) == 0x8001u) | ((y >> 16) == 0x7fffu) | ((y >> 16) == 0x8001u);
-                        if (sat) { ex[it] = *reinterpret_cast<const int4*>(a.side_in + base + (int64_t)p * ls + 4 * sub); satm |= 1u << it; }
+                        if (sat) { ex[it] = *reinterpret_cast<const int4*>(side_in + ((uint32_t)p * ls + 4u * sub)); satm |= 1u << it; }
                     }
 #pragma unroll
                     for (int it = 0; it < kDcBatch; ++it) {
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                     none = !nb;
                 }
                 if (inl) {
-                    kl[p] = (((none ? finf : F) + (uint32_t)p * (uint32_t)p) << B) | (uint32_t)p;
+                    kl[p] = (((none ? finf : F) + __umul24((uint32_t)p, (uint32_t)p)) << B) | (uint32_t)p;
                     if (!none) { mn = min(mn, (uint32_t)p); mx = max(mx, (uint32_t)p); }
                 }
             }
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                     // ((2 (p0 - a0) + 2k - 1) << B).
                     uint32_t R[kDcChunk], nc[kDcChunk], best[kDcChunk];
                     const uint32_t W = (uint32_t)(2 * (p0 - a0)) << B;
-                    R[0] = (((uint32_t)p0 * (uint32_t)p0) << B) - (((uint32_t)(2 * p0)) << B) * (uint32_t)a0;
+                    R[0] = (__umul24((uint32_t)p0, (uint32_t)p0) << B) - __umul24(((uint32_t)(2 * p0)) << B, (uint32_t)a0);
                     nc[0] = 0u - ((uint32_t)(2 * p0) << B);
                     best[0] = 0xFFFFFFFFu;
 #pragma unroll
@@ -429,9 +431,9 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                             const int p = p0 + __ffs((int)rest) - 1;
                             int D1 = -raw_signed(line, p);
                             if (D1 > kDcLocalMax) { flg[17] = 1u; continue; }
-                            for (int d = 1; d * d < D1; ++d) {
-                                if (p - d >= 0) D1 = min(D1, d * d + max(-raw_signed(line, p - d), 0));
-                                if (p + d < L) D1 = min(D1, d * d + max(-raw_signed(line, p + d), 0));
+                            for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
+                                if (p - d >= 0) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(line, p - d), 0));
+                                if (p + d < L) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(line, p + d), 0));
                             }
                             emit(line, p, D1, true, true);
                         }
