@@ -193,10 +193,18 @@ def run_leg(torch, capi, dev, shape, res, masks, opts, steps, warmup, label):
     def fence():
         torch.cuda.synchronize(dev)
 
+    # a fresh context on this scene (what a one-shot caller of the reference API pays); a throw-away context builds the
+    # scene once first so that process-level one-time costs (first launch of each kernel) are not billed to it
+    warm = capi.SdfGpu(dev.index)
+    for k, v in opts.items():
+        warm.set_option(k, v)
+    warm.build_device(masks[0].data_ptr(), shape, out.data_ptr(), res, False, stream)
+    fence()
+    warm.close()
     t_first0 = time.perf_counter()
     step(0)
     fence()
-    first_ms = (time.perf_counter() - t_first0) * 1e3        # a fresh context on this scene (one-shot callers)
+    first_ms = (time.perf_counter() - t_first0) * 1e3
     for i in range(warmup):
         step(i)
         fence()
@@ -226,6 +234,11 @@ def streaming_leg(torch, dev, n, res, frames):
 
     st = StreamingSdf((n, n, n), res, (0.0, 0.0, 0.0), dev.index, gradient=True)
     clouds = [torch.from_numpy(synth.two_box_points(200000, seed=f, scale=n * res)).to(dev) for f in range(4)]
+    warm = StreamingSdf((n, n, n), res, (0.0, 0.0, 0.0), dev.index, gradient=True)      # process-level warm-up (see run_leg)
+    warm.frame(clouds[0])
+    torch.cuda.synchronize(dev)
+    warm.ctx.close()
+    del warm
     t0 = time.perf_counter()
     st.frame(clouds[0])
     torch.cuda.synchronize(dev)

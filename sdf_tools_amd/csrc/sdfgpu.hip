@@ -77,6 +77,10 @@ struct sdfgpu_context {
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
     bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
+    bool tier_select = true;         // pick marching vs envelope sweep per axis on the device, inside the build (probe + decide)
+    int force_env = -1;              // -1 automatic, 1 = envelope kernels only (option "envelope_mode")
+    int far_num = 1, far_den = 8;    // an axis is far-field when more than num / den of the probed voxels have d^2 >= far_thr
+    int far_thr = 64;
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
@@ -367,9 +371,11 @@ DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, 
 // KE2 / KE3: exact far-field sweeps.  guard: run iff (*guard != 0) != guard_invert (nullptr: always).
 int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int32_t* d_side_in, void* d_out,
                     int32_t* d_side_out, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
-                    uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s, int guard_invert = 0) {
+                    uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s, int guard_invert = 0,
+                    uint32_t* probe_out = nullptr) {
     (void)d_maxdsq;
     const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz);
+    if (probe_out && !g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "probe needs the divide-and-conquer envelope kernel");
     if (g.ok) {
         EnvDcArgs a{};
         a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
@@ -380,6 +386,16 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert; a.dbg = h->dc_debug;
         if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
+        if (probe_out) {                                        // sample ~256 tiles spread over the grid, store nothing
+            a.probe_stride = (int)std::max<int64_t>(1, std::min<int64_t>(64, ntiles / 256));
+            a.probe_thr = h->far_thr;
+            a.probe_out = probe_out;
+            ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
+            // the sampled tile index b * stride + (7 b mod stride) must stay inside the grid: drop the last block if needed
+            const int64_t all = stage == 2 ? nx * (nz / kDcLines) : ny * nz / kDcLines;
+            while (ntiles > 0 && (ntiles - 1) * a.probe_stride + ((ntiles - 1) * 7) % a.probe_stride >= all) --ntiles;
+            if (ntiles == 0) return SDFGPU_OK;
+        }
         const size_t lds = envelope_dc_lds_bytes(a.L, a.pitch);
         if (lds > 64 * 1024 && !h->dc_lds_attr[stage - 2]) {
             const void* fn = stage == 2 ? (const void*)k_envelope_dc<2> : (const void*)k_envelope_dc<3>;
@@ -586,18 +602,26 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
             const bool near = max_d <= (uint32_t)((kScanExpectNear / 4) * (kScanExpectNear / 4));
             h->env_mode_y = h->prev_env_y ? !near : (h->h_flags[4] != 0);
             h->env_mode_x = h->prev_env_x ? !near : (h->h_flags[5] != 0);
+            if (h->force_env > 0) h->env_mode_y = h->env_mode_x = true;      // option "envelope_mode" is sticky
         } else {
             h->env_mode_y = h->env_mode_x = false;
         }
     }
     if (dense && h->dense_skip > 0) { --h->dense_skip; dense = false; }
     const bool envelope = p16 && h->envelope_on && !(h->expect_dense && dense);
-    const bool env_y = envelope && h->env_mode_y, env_x = envelope && h->env_mode_x;
+    // Device-side tier selection (needs the divide-and-conquer envelope kernel on both axes): the marching-vs-envelope
+    // choice of each axis is made INSIDE this build from a probe of the sweep's own input, so a fresh context (the
+    // reference's API is one-shot: collision_map.hpp:680-712 builds and returns) never runs a sweep that is thrown away.
+    // Other shapes keep the host policy below (choice learned from the previous build on the handle).
+    const bool dev_select = envelope && h->tier_select &&
+                            envelope_dc_geometry(h, 2, nx, ny, nz).ok && envelope_dc_geometry(h, 3, nx, ny, nz).ok;
+    const bool env_y = envelope && !dev_select && h->env_mode_y, env_x = envelope && !dev_select && h->env_mode_x;
     // K12 (fused z+y) only as the guarded stand-by behind a dense build that is expected to be certified
     // again; everywhere else K1 + K2 (rows from the int16 z field) scan much faster than the fused kernel
     // recomputes, and only they can hand a far-field y sweep to the envelope kernel.
     const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
+    const bool select = dev_select && !fused;
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
@@ -605,7 +629,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // ordered by the stream; a build issued on ANOTHER stream first waits for the previous build's last kernel.
     if (h->have_result && s != h->last_stream) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
     if (!h->small_clean) {
-        HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 32, s));
+        HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
         HIP_TRY(h, hipMemsetAsync(h->d_slots, 0, (size_t)kSlots * kSlotWords * 4, s));   // a failed build may have left maxima behind
     }
     h->small_clean = false;
@@ -672,7 +696,23 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     }
     HIP_TRY(h, mark(3));
     // y sweep: marching (bounded scan, may raise far_y) + guarded envelope, or the envelope kernel alone
-    if (fused) {
+    const uint32_t* const general_guard = h->guard;           // nullptr, or "the dense tier left voxels undecided"
+    auto decide = [&](int stage) -> int {                     // probe counters -> guard word of the marching sweep / envelope flag
+        hipLaunchKernelGGL(k_decide_tier, dim3(1), dim3(1), 0, s, h->d_small, stage, dense ? 1 : 0, h->force_env,
+                           h->far_num, h->far_den);
+        HIP_TRY(h, hipGetLastError());
+        return SDFGPU_OK;
+    };
+    if (select) {
+        if (h->force_env < 0)
+            if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
+                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12)) return rc;
+        if (int rc = decide(0)) return rc;
+        h->guard = h->d_small + 8;                              // marching y sweep: general pipeline needed AND near-field
+        if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s)) return rc;
+        h->guard = general_guard;
+        launched_since_mark = true;
+    } else if (fused) {
         if (int rc = launch_sweep_zy_fused(h, d_filled, zy_out, zy_side, nx, ny, nz, s)) return rc;
         launched_since_mark = true;
     } else if (!env_y) {
@@ -689,7 +729,17 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // x sweep: same choice
     if (!envelope || fused) h->far_y = nullptr;
     else h->far_y = h->d_small + 4;             // (K3/16 raises far_y + 1 = far_x)
-    if (p16) {
+    if (select) {
+        if (h->force_env < 0)
+            if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
+                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12)) return rc;
+        if (int rc = decide(1)) return rc;
+        h->guard = h->d_small + 10;
+        if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
+                                      0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+        h->guard = general_guard;
+        launched_since_mark = true;
+    } else if (p16) {
         if (!env_x) {
             if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
                                           0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
@@ -1290,7 +1340,10 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; }
     else if (n == "fixup_mode") h->fix_mode = value != 0;
     else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; }
-    else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; }
+    else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; h->force_env = value != 0 ? 1 : -1; }
+    else if (n == "tier_select") h->tier_select = value != 0;
+    else if (n == "far_threshold") h->far_thr = value;
+    else if (n == "far_fraction_den") h->far_den = value > 0 ? value : 8;
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;

@@ -64,6 +64,11 @@ struct EnvDcArgs {
     uint32_t* maxdsq;         // slot array (STAGE 3)
     const uint32_t* guard;    // nullptr: always run; else run iff (*guard != 0) != guard_invert
     int guard_invert;
+    // probe mode (device-side tier selection): only every probe_stride-th tile is processed, nothing is stored; the first
+    // pass counts the voxels it produced ([1]) and those whose squared distance is >= probe_thr ([0]) into probe_out
+    int probe_stride;
+    int probe_thr;
+    uint32_t* probe_out;
     int dbg;                  // profiling aid (wrong results!): bit0 skip upper levels, bit1 skip chunk search, bit2 skip stores,
                               // bit3 skip the second class, bit4 skip key conversion
 };
@@ -95,7 +100,10 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     // themselves are dealt round-robin, so that every XCD sees every part of the grid (work is not uniform in space:
     // a tile far from every object is trivial)
     int64_t tile = blockIdx.x;
-    if ((gridDim.x & 31u) == 0u) {
+    const bool probe = a.probe_stride > 0;
+    if (probe) {                                                // a sample spread over the whole grid
+        tile = (int64_t)blockIdx.x * a.probe_stride + (blockIdx.x * 7u) % (uint32_t)a.probe_stride;
+    } else if ((gridDim.x & 31u) == 0u) {
         const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
         tile = ((int64_t)(seq >> 2) * 8 + xcd) * 4 + (seq & 3u);
     }
@@ -151,7 +159,9 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
     };
     // finish one voxel: STAGE 2 plane field (+ side table on request), STAGE 3 the reference's merge arithmetic
+    int probe_far = 0, probe_tot = 0;
     auto emit = [&](int line, int p, int D, bool filled, bool side) {
+        if (probe) { probe_tot += 1; probe_far += D >= a.probe_thr ? 1 : 0; return; }
         const uint32_t oi = (uint32_t)line + (uint32_t)p * ls;
         if constexpr (STAGE == 2) {
             (reinterpret_cast<int16_t*>(a.out) + base)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
@@ -170,14 +180,14 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
 
 #pragma unroll 1
     for (int cls = 0; cls < 2; ++cls) {         // 0: sites of "distance to filled" (for free voxels); 1: the reverse
-        if (cls == 0 && t == 0) { flg[16] = 0u; flg[17] = 0u; }   // (ordered before their users by the barriers of pass 0)
+        if (cls == 0 && t == 0) { flg[16] = 0u; flg[17] = 0u; flg[18] = 0u; flg[19] = 0u; }   // (ordered before their users by the barriers of pass 0)
         // ---- stage the tile ----------------------------------------------------------------------------------------------
         // step 1: rows -> LDS, the exact signed value of every voxel parked in its key slot.  Nothing but loads and LDS
         //         writes, a batch of independent row loads in flight per lane (a lane reads 4 lines x 1 position = 8 B; STAGE 3
         //         adds the 16-B side-table group where the 16-bit value is saturated).
         // step 2: slots -> keys in place, lane = (line, 16 consecutive positions per step): sign bits by ballot, first / last
         //         site by a 16-lane reduction, no atomics.
-        if (cls == 1 && (a.dbg & 8)) break;
+        if (cls == 1 && ((a.dbg & 8) || probe)) break;
         // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose
         // in-row squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can
         // only matter while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises flg[17] for the rest.
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                 }
                 // pass 0 finishes the tile's filled voxels itself when they are few and shallow (thin surfaces): exact local
                 // search along the line -- a candidate at offset d can only win while d^2 < the best so far
-                if (cls == 0 && cm != 0u && !(a.dbg & 8)) {
+                if (cls == 0 && cm != 0u && !(a.dbg & 8) && !probe) {
                     if (many_filled) {
                         flg[17] = 1u;
                     } else {
@@ -444,6 +454,18 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         __syncthreads();                        // keys / args are rebuilt by the next class
     }
 
+    if (probe) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            probe_far += __shfl_xor(probe_far, off);
+            probe_tot += __shfl_xor(probe_tot, off);
+        }
+        // one pair of global atomics per workgroup (same-address atomics serialise at ~12 ns each)
+        if ((t & 63) == 0) { atomicAdd(&flg[18], (uint32_t)probe_far); atomicAdd(&flg[19], (uint32_t)probe_tot); }
+        __syncthreads();
+        if (t == 0) { atomicAdd(a.probe_out, flg[18]); atomicAdd(a.probe_out + 1, flg[19]); }
+        return;
+    }
     if constexpr (STAGE == 3) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -452,6 +474,23 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
         if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * 4 + (t >> 6), mxF, mxQ);
     }
+}
+
+// Device-side tier selection for one axis (stage 0 = y, 1 = x), one thread.  small = the context's status block:
+// [3] uncertified (dense tier could not decide the scene), [4] / [5] "y / x sweep belongs to the envelope kernel" (also
+// raised by a marching sweep that hits its scan bound), [8 + 2 stage] guard word of the marching sweep, [12] / [13] the
+// probe's counters.  The marching sweep runs iff the general pipeline is needed at all and the probe found the axis
+// near-field; otherwise the envelope flag is raised and the (flag-guarded) envelope kernel does the sweep.
+__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den) {
+    const bool active = dense_tried ? small[3] != 0u : true;
+    const uint32_t far_n = small[12], tot = small[13];
+    // far when more than num / den of the sampled voxels need a long scan (64-bit: counts are < 2^24, factors small)
+    const bool far = force >= 0 ? force != 0 : (uint64_t)far_n * (uint64_t)den > (uint64_t)tot * (uint64_t)num;
+    small[8 + 2 * stage] = (active && !far) ? 1u : 0u;
+    if (active && far) small[4 + stage] = 1u;
+    small[12] = 0u;
+    small[13] = 0u;
+    small[14 + stage] = tot ? (far_n * 1000u) / tot : 0u;         // per-mille of far voxels in the sample (diagnostics)
 }
 
 }  // namespace sdfgpu
