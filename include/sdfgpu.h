@@ -160,6 +160,24 @@ int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled,
                            int64_t nxs, int64_t ny, int64_t nz,
                            int32_t* d_plane_dsq, void* stream);
 
+/* Same as sdfgpu_sweep_zy_device, and reports which y sweep ran: *d_far (uint32 device word, may be NULL) is set to 1
+ * when the device-side probe found the slab far-field and the envelope kernel did the y sweep (a hint that the x
+ * sweep will need whole lines too), else to 0.  sdfgpu_sweep_zy_device is this call with d_far = NULL. */
+int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled,
+                                  int64_t nxs, int64_t ny, int64_t nz,
+                                  int32_t* d_plane_dsq, uint32_t* d_far, void* stream);
+
+/* Exact x sweep + signed merge on COMPLETE lines of a y slab: d_plane_dsq is [nx][nys][nz] (what an all-to-all
+ * re-partition of the x-slab plane fields delivers), rows y_global .. y_global + nys of a grid
+ * whose y extent is ny_global (the virtual border needs both).  Any distance: the marching sweep (bounded scan)
+ * or the envelope kernel, chosen on the device.  d_out_sdf: [nx][nys][nz]; d_maxdsq[2] as in
+ * sdfgpu_sweep_x_device. */
+int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq,
+                                int64_t nx, int64_t nys, int64_t nz,
+                                int64_t y_global, int64_t ny_global,
+                                double resolution, int add_virtual_border,
+                                float* d_out_sdf, uint32_t* d_maxdsq, void* stream);
+
 int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq,
                           int64_t halo_lo, int64_t nxs, int64_t halo_hi,
                           int64_t ny, int64_t nz,

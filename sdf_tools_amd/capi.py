@@ -23,7 +23,7 @@ EXPORTS = [
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
     "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
-    "sdfgpu_gradient",
+    "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device",
 ]
 
 
@@ -71,6 +71,8 @@ def load_library():
     L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
     L.sdfgpu_sweep_zy_device.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.sdfgpu_sweep_zy_tiered_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+    L.sdfgpu_sweep_x_lines_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_sweep_x_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, ci, ci, i64, i64, dbl, ci, vp, vp, vp, vp]
     L.sdfgpu_pack_bits_device.argtypes = [vp, vp, i64, i64, vp, vp]
     L.sdfgpu_dense_ball_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, dbl, vp, vp, vp, vp]
@@ -219,6 +221,17 @@ class SdfGpu:
     def sweep_zy_device(self, d_filled, slab_shape, d_plane_dsq, stream=0):
         nxs, ny, nz = (int(s) for s in slab_shape)
         self._check(self._lib.sdfgpu_sweep_zy_device(self._h, d_filled, nxs, ny, nz, d_plane_dsq, stream or None))
+
+    def sweep_zy_tiered_device(self, d_filled, slab_shape, d_plane_dsq, d_far=0, stream=0):
+        nxs, ny, nz = (int(s) for s in slab_shape)
+        self._check(self._lib.sdfgpu_sweep_zy_tiered_device(self._h, d_filled, nxs, ny, nz, d_plane_dsq, d_far or None,
+                                                            stream or None))
+
+    def sweep_x_lines_device(self, d_plane_dsq, nx, nys, nz, y_global, ny_global, resolution, add_virtual_border, d_out,
+                             d_maxdsq, stream=0):
+        self._check(self._lib.sdfgpu_sweep_x_lines_device(self._h, d_plane_dsq, int(nx), int(nys), int(nz), int(y_global),
+                                                          int(ny_global), float(resolution), int(bool(add_virtual_border)),
+                                                          d_out, d_maxdsq, stream or None))
 
     def sweep_x_device(self, d_plane_dsq, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated,
                        x_global, nx_global, resolution, add_virtual_border, d_out, d_maxdsq, d_status, stream=0):

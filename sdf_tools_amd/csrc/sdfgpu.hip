@@ -230,7 +230,7 @@ int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, void* d_out, int32_t* d
     a.in = d_in; a.out = d_out;
     a.out16 = d_side ? 1 : 0; a.side = d_side;
     a.guard = h->guard;
-    if (d_side && h->far_y) { a.max_scan = h->scan_y; a.far_flag = h->far_y; }
+    if (h->far_y) { a.max_scan = h->scan_y; a.far_flag = h->far_y; }
     a.cpl = nz / V;
     a.ncols = nx * a.cpl;
     a.outer_stride = ny * nz;
@@ -325,7 +325,7 @@ int launch_sweep_x16(sdfgpu_handle h, const int16_t* d_in16, const int32_t* d_si
 int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t halo_lo, int64_t nxs,
                    int64_t halo_hi, int64_t ny, int64_t nz, int lo_trunc, int hi_trunc, int64_t x_global,
                    int64_t nx_global, double resolution, int vb, uint32_t* d_maxdsq, uint32_t* d_status,
-                   hipStream_t s) {
+                   hipStream_t s, int64_t y_off = 0, int64_t ny_glob = -1, int max_scan = 0, uint32_t* far_flag = nullptr) {
     const int64_t plane = ny * nz;
     const bool vec4 = (plane % 4) == 0 && (reinterpret_cast<uintptr_t>(d_in) % 16) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_out) % 16) == 0;
@@ -342,6 +342,8 @@ int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t h
     a.resolution = resolution;
     a.lo_truncated = lo_trunc; a.hi_truncated = hi_trunc;
     a.x_global = x_global; a.nx_global = nx_global; a.ny = ny; a.nz = nz;
+    a.y_off = y_off; a.ny_glob = ny_glob < 0 ? ny : ny_glob;
+    a.max_scan = max_scan; a.far_flag = far_flag;
     (void)d_maxdsq;                             // maxima go to the slot array; the caller folds them (fold_slots)
     a.maxdsq = h->d_slots; a.status = d_status;
     a.guard = h->guard;
@@ -350,15 +352,22 @@ int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t h
 
 // Shapes the divide-and-conquer envelope kernel takes: tiles of 16 memory-adjacent lines, keys that fit 32 bits.
 struct DcGeometry { bool ok; int B; uint32_t finf; int pitch; int M, Kp; };
-DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz) {
+struct DcExtra {                 // slab pipelines: int32 plane fields instead of p16 + side table, y-slab geometry
+    const int32_t* in_i32 = nullptr;
+    int32_t* out_i32 = nullptr;
+    int64_t y_off = 0, ny_glob = -1;
+};
+DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz,
+                                int64_t ny_full = -1) {
     DcGeometry g{};
+    if (ny_full < 0) ny_full = ny;                            // (a y slab of a larger grid holds distances of the whole grid)
     const int64_t L = stage == 2 ? ny : nx;
     const int64_t group = stage == 2 ? nz : ny * nz;          // lines that are contiguous in memory
     if (!h->envelope_dc || L < 1 || L > 1024 || (group % kDcLines) != 0 || (nz % 4) != 0 ||
         nx * ny * nz >= (1ll << 31)) return g;                  // (the kernel uses 32-bit element offsets inside a tile's lines)
     int B = 1;
     while ((1ll << B) < L) ++B;
-    const int64_t finf = (nx - 1) * (nx - 1) + (ny - 1) * (ny - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2
+    const int64_t finf = (nx - 1) * (nx - 1) + (ny_full - 1) * (ny_full - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2
     if (finf + L * L >= (1ll << (32 - B))) return g;
     g.ok = true; g.B = B; g.finf = (uint32_t)finf;
     g.pitch = (int)(((L + 2 + 31) / 32) * 32 + 1);
@@ -372,9 +381,10 @@ DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, 
 int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int32_t* d_side_in, void* d_out,
                     int32_t* d_side_out, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
                     uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s, int guard_invert = 0,
-                    uint32_t* probe_out = nullptr) {
+                    uint32_t* probe_out = nullptr, const DcExtra* ex = nullptr) {
     (void)d_maxdsq;
-    const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz);
+    const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz, ex ? ex->ny_glob : -1);
+    if (ex && !g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "int32 plane fields need the divide-and-conquer envelope kernel");
     if (probe_out && !g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "probe needs the divide-and-conquer envelope kernel");
     if (g.ok) {
         EnvDcArgs a{};
@@ -384,6 +394,11 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         else { ntiles = ny * nz / kDcLines; a.tiles_per_outer = ntiles; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
         a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = g.Kp;
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
+        a.y_off = 0; a.ny_glob = ny;
+        if (ex) {
+            a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off;
+            if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
+        }
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert; a.dbg = h->dc_debug;
         if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
         if (probe_out) {                                        // sample ~256 tiles spread over the grid, store nothing
@@ -420,6 +435,13 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
     dim3 grid((unsigned)((a.nlines + kBlock - 1) / kBlock)), block(kBlock);
     if (stage == 2) hipLaunchKernelGGL(k_envelope<2>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(k_envelope<3>, grid, block, 0, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
+int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s) {
+    hipLaunchKernelGGL(k_decide_tier, dim3(1), dim3(1), 0, s, h->d_small, stage, dense_tried ? 1 : 0, h->force_env,
+                       h->far_num, h->far_den);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -697,12 +719,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     HIP_TRY(h, mark(3));
     // y sweep: marching (bounded scan, may raise far_y) + guarded envelope, or the envelope kernel alone
     const uint32_t* const general_guard = h->guard;           // nullptr, or "the dense tier left voxels undecided"
-    auto decide = [&](int stage) -> int {                     // probe counters -> guard word of the marching sweep / envelope flag
-        hipLaunchKernelGGL(k_decide_tier, dim3(1), dim3(1), 0, s, h->d_small, stage, dense ? 1 : 0, h->force_env,
-                           h->far_num, h->far_den);
-        HIP_TRY(h, hipGetLastError());
-        return SDFGPU_OK;
-    };
+    auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s); };   // probe counters -> guard words
     if (select) {
         if (h->force_env < 0)
             if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
@@ -991,8 +1008,8 @@ int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min) {
     return sdfgpu_extrema_from_dsq(v[0], v[1], h->last_resolution, out_max, out_min);
 }
 
-int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
-                           int32_t* d_plane_dsq, void* stream) {
+int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
+                                  int32_t* d_plane_dsq, uint32_t* d_far, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     h->guard = nullptr;
     h->far_y = nullptr;
@@ -1001,10 +1018,83 @@ int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nxs * ny * nz;
     hipStream_t s = (hipStream_t)stream;
-    if (fused_zy_eligible(h, d_filled, d_plane_dsq, nz)) return launch_sweep_zy_fused(h, d_filled, d_plane_dsq, nullptr, nxs, ny, nz, s);
+    const bool tiered = h->envelope_on && h->tier_select && envelope_dc_geometry(h, 2, nxs, ny, nz).ok &&
+                        (nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
+    if (!tiered) {
+        if (fused_zy_eligible(h, d_filled, d_plane_dsq, nz)) return launch_sweep_zy_fused(h, d_filled, d_plane_dsq, nullptr, nxs, ny, nz, s);
+        if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
+        if (int rc = launch_sweep_z(h, d_filled, nullptr, 0, 0, 0, nxs, ny, nz, (int16_t*)h->zfield.ptr, s)) return rc;
+        return launch_sweep_y(h, (const int16_t*)h->zfield.ptr, d_plane_dsq, nullptr, nxs, ny, nz, s);
+    }
+    // K1, then the y sweep picked on the device: probe -> decide -> marching (bounded scan) / envelope, int32 output
     if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    h->small_clean = false;
     if (int rc = launch_sweep_z(h, d_filled, nullptr, 0, 0, 0, nxs, ny, nz, (int16_t*)h->zfield.ptr, s)) return rc;
-    return launch_sweep_y(h, (const int16_t*)h->zfield.ptr, d_plane_dsq, nullptr, nxs, ny, nz, s);
+    DcExtra ex;
+    ex.out_i32 = d_plane_dsq;
+    if (h->force_env < 0)
+        if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nxs, ny, nz, 1.0, 0,
+                                     h->d_small, nullptr, s, 0, h->d_small + 12, &ex)) return rc;
+    if (int rc = launch_decide(h, 0, false, s)) return rc;
+    h->guard = h->d_small + 8;
+    h->far_y = h->d_small + 4;
+    h->scan_y = kScanExpectNear;
+    int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, d_plane_dsq, nullptr, nxs, ny, nz, s);
+    h->guard = nullptr;
+    h->far_y = nullptr;
+    if (rc) return rc;
+    if (int rc2 = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nxs, ny, nz, 1.0, 0,
+                                  h->d_small, h->d_small + 4, s, 0, nullptr, &ex)) return rc2;
+    if (d_far) HIP_TRY(h, hipMemcpyAsync(d_far, h->d_small + 4, 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    h->small_clean = true;
+    return SDFGPU_OK;
+}
+
+int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
+                           int32_t* d_plane_dsq, void* stream) {
+    return sdfgpu_sweep_zy_tiered_device(h, d_filled, nxs, ny, nz, d_plane_dsq, nullptr, stream);
+}
+
+int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t nx, int64_t nys, int64_t nz,
+                                int64_t y_global, int64_t ny_global, double resolution, int add_virtual_border,
+                                float* d_out_sdf, uint32_t* d_maxdsq, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_plane_dsq || !d_out_sdf || !d_maxdsq) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (y_global < 0 || y_global + nys > ny_global) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "inconsistent slab geometry");
+    if (int rc = check_dims(h, nx, nys, nz)) return rc;
+    if (int rc = check_dims(h, nx, ny_global, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    h->guard = nullptr;
+    h->far_y = nullptr;
+    const bool tiered = h->envelope_on && h->tier_select && envelope_dc_geometry(h, 3, nx, nys, nz, ny_global).ok &&
+                        (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
+    if (!tiered) {
+        if (int rc = launch_sweep_x(h, d_plane_dsq, d_out_sdf, 0, nx, 0, nys, nz, 0, 0, 0, nx, resolution, add_virtual_border,
+                                    d_maxdsq, nullptr, s, y_global, ny_global)) return rc;
+        return h->defer_fold ? SDFGPU_OK : fold_slots(h, d_maxdsq, s);
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    h->small_clean = false;
+    DcExtra ex;
+    ex.in_i32 = d_plane_dsq; ex.y_off = y_global; ex.ny_glob = ny_global;
+    if (h->force_env < 0)
+        if (int rc = launch_envelope(h, 3, nullptr, nullptr, d_out_sdf, nullptr, nx, nys, nz, resolution, add_virtual_border,
+                                     h->d_small, nullptr, s, 0, h->d_small + 12, &ex)) return rc;
+    if (int rc = launch_decide(h, 1, false, s)) return rc;
+    h->guard = h->d_small + 10;
+    int rc = launch_sweep_x(h, d_plane_dsq, d_out_sdf, 0, nx, 0, nys, nz, 0, 0, 0, nx, resolution, add_virtual_border,
+                            d_maxdsq, nullptr, s, y_global, ny_global, kScanExpectNear, h->d_small + 5);
+    h->guard = nullptr;
+    if (rc) return rc;
+    if (int rc2 = launch_envelope(h, 3, nullptr, nullptr, d_out_sdf, nullptr, nx, nys, nz, resolution, add_virtual_border,
+                                  h->d_small, h->d_small + 5, s, 0, nullptr, &ex)) return rc2;
+    if (!h->defer_fold) if (int rc3 = fold_slots(h, d_maxdsq, s)) return rc3;
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    h->small_clean = true;
+    return SDFGPU_OK;
 }
 
 int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t halo_lo, int64_t nxs,

@@ -50,6 +50,9 @@ struct EnvDcArgs {
     const int32_t* side_in;   // STAGE 3: exact values where p16 is saturated (valid for the whole group of 4)
     void* out;                // STAGE 2: int16 plane field; STAGE 3: float sdf
     int32_t* side_out;        // STAGE 2: exact plane values for groups of 4 that hold a saturated value
+    const int32_t* in_i32;    // STAGE 3, slab pipelines: the input is an int32 plane field (in16 / side_in unused)
+    int32_t* out_i32;         // STAGE 2, slab pipelines: write an int32 plane field (+-2^30 = none) instead of p16 + side
+    int64_t y_off, ny_glob;   // STAGE 3 on a y slab: grid y of local row 0 and the full y extent (virtual border)
     int64_t tiles_per_outer;  // STAGE 2: nz / 16 tiles per x-plane; STAGE 3: all tiles
     int64_t outer_stride;     // elements between outer units (STAGE 2: ny*nz; STAGE 3: 0)
     int64_t line_stride;      // elements between successive positions of a line
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
     const int16_t* const in16 = a.in16 + base;
     const int32_t* const side_in = STAGE == 3 ? a.side_in + base : nullptr;
+    const int32_t* const in32 = (STAGE == 3 && a.in_i32) ? a.in_i32 + base : nullptr;
 
     // one candidate range for one position: lanes u = 0 .. G-1 of a group take the pairs lo + 2u, lo + 2u + 2G, ...
     // (the second key of the last pair may be candidate hi + 1: it can tie but never beat the range's minimum, and on a
@@ -137,9 +141,10 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     if constexpr (STAGE == 3) {
         if (a.vb) {
             const int64_t c = c0 + (t & 15);
-            const int64_t vy = c / a.nz, vz = c - vy * a.nz;
+            const int64_t vyl = c / a.nz, vz = c - vyl * a.nz;
+            const int64_t vy = vyl + a.y_off;
             int64_t b = kInf32;
-            if (a.ny > 1) b = min(b, min(vy + 1, a.ny - vy));
+            if (a.ny_glob > 1) b = min(b, min(vy + 1, a.ny_glob - vy));
             if (a.nz > 1) b = min(b, min(vz + 1, a.nz - vz));
             byz = (int)b;
         }
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
     auto raw_signed = [&](int line, int q) -> int {
         const uint32_t idx = (uint32_t)line + (uint32_t)q * ls;
+        if (STAGE == 3 && in32) return in32[idx];
         int v = in16[idx];
         if constexpr (STAGE == 2) {
             const int g = abs(v);
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         if (probe) { probe_tot += 1; probe_far += D >= a.probe_thr ? 1 : 0; return; }
         const uint32_t oi = (uint32_t)line + (uint32_t)p * ls;
         if constexpr (STAGE == 2) {
+            if (a.out_i32) { (a.out_i32 + base)[oi] = filled ? -D : D; return; }
             (reinterpret_cast<int16_t*>(a.out) + base)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
             if (side) (a.side_out + base)[oi] = filled ? -D : D;
         } else {
@@ -195,6 +202,24 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         {
             const int sub = t & 3, r = t >> 2;
             int32_t* slots = reinterpret_cast<int32_t*>(keys);
+            if (STAGE == 3 && in32) {                           // int32 plane field: 4 lines x 1 position = one 16-B load
+                for (int pb = 0; pb < L; pb += 64 * kDcBatch) {
+                    int4 rw4[kDcBatch];
+#pragma unroll
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        const int p = min(pb + 64 * it + r, L - 1);
+                        rw4[it] = *reinterpret_cast<const int4*>(in32 + ((uint32_t)p * ls + 4u * sub));
+                    }
+#pragma unroll
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        const int p = pb + 64 * it + r;
+                        if (p < L) {
+                            int32_t* d = slots + (4 * sub) * pitch + p;
+                            d[0] = rw4[it].x; d[pitch] = rw4[it].y; d[2 * pitch] = rw4[it].z; d[3 * pitch] = rw4[it].w;
+                        }
+                    }
+                }
+            } else
             for (int pb = 0; pb < L; pb += 64 * kDcBatch) {
                 uint2 raw[kDcBatch];
 #pragma unroll

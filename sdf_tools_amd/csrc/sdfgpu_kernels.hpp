@@ -285,6 +285,7 @@ struct SweepArgs {
     int lo_truncated, hi_truncated;   // real rows exist beyond the buffer (slab mode)
     int64_t x_global;                 // grid x of position out_lo
     int64_t nx_global, ny, nz;        // full extents (virtual border)
+    int64_t y_off, ny_glob;           // K3 on a y slab: grid y of local row 0 and the full y extent (0 / ny otherwise)
     uint32_t* maxdsq;                 // [0] free, [1] filled
     uint32_t* status;                 // bit 0: unresolved voxel (slab mode)
     // K2 with 16-bit output (plane16 + side table, see sdfgpu_sweep_x16.hpp)
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
                     int64_t b = kInf32;
                     const int64_t gx = a.x_global + (p - a.out_lo);
                     if (a.nx_global > 1) b = min(b, min(gx + 1, a.nx_global - gx));
-                    if (a.ny > 1) b = min(b, min((int64_t)vy[k] + 1, a.ny - vy[k]));
+                    if (a.ny_glob > 1) b = min(b, min((int64_t)vy[k] + a.y_off + 1, a.ny_glob - a.y_off - vy[k]));
                     if (a.nz > 1) b = min(b, min((int64_t)vz[k] + 1, a.nz - vz[k]));
                     if (b < 32768) D = min(D, (int)(b * b));
                 }

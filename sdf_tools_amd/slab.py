@@ -15,10 +15,18 @@ Dense path (scenes whose every voxel has an opposite-class voxel within squared 
                      build's halo exchange (or by ``finish``) so it never delays that exchange
 
 General path (only if some rank raised the flag; exact for any input)
-  1. ``sweep_zy``    mask slab -> signed in-plane d^2 (int32) into an extended buffer with `halo` planes
-  2. halo exchange   `halo` int32 planes per neighbour, overlapped with the interior sweeps
+  1. ``sweep_zy``    mask slab -> signed in-plane d^2 (int32); the y sweep's tier (marching / envelope kernel) is
+                     chosen on the device, and a "far" hint comes back with it
+  near-field scenes (hint clear on every rank):
+  2. halo exchange   `halo` int32 planes per neighbour
   3. ``sweep_x``     x sweep + signed merge; raises a status bit if a voxel needed planes beyond the halo
-  4. all-reduce(MAX); if the bit is set anywhere: all-gather the plane field along x, sweep whole lines
+  far-field scenes (hint set somewhere, or the status bit of step 3):
+  4. re-partition    x slabs -> y slabs: every rank sends the rows of every other rank's y slab, ONE message per peer
+                     and direction (grouped isend/irecv = one message per direct xGMI link; 64 MiB per peer at
+                     1024^3 on 8 GPUs), and receives complete x lines of its own y slab: [nx, ny/G, nz]
+  5. ``sweep_x_lines``  exact x sweep on complete lines (marching or envelope kernel, chosen on the device)
+  6. re-partition back to x slabs (fp32), all-reduce(MAX) of the integer extrema
+  No rank ever holds more than 1/G of any field.
 
 A build is validated one step late (:meth:`SlabSdfBuilder.build_async` / :meth:`finish`): the
 all-reduced status lands in pinned host memory through a side stream, so the GPU never idles waiting
@@ -59,10 +67,18 @@ class HipStages:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     # ---- general path --------------------------------------------------------------------------
-    def sweep_zy(self, mask_slab, plane_dsq_rows):
+    def sweep_zy(self, mask_slab, plane_dsq_rows, far=None):
+        """far: optional int32[1] device tensor, set to 1 when the envelope kernel did the y sweep (far-field slab)."""
         assert mask_slab.is_contiguous() and plane_dsq_rows.is_contiguous()
-        self.ctx.sweep_zy_device(mask_slab.data_ptr(), tuple(mask_slab.shape), plane_dsq_rows.data_ptr(),
-                                 self.stream())
+        self.ctx.sweep_zy_tiered_device(mask_slab.data_ptr(), tuple(mask_slab.shape), plane_dsq_rows.data_ptr(),
+                                        far.data_ptr() if far is not None else 0, self.stream())
+
+    def sweep_x_lines(self, lines, y_global, ny_global, resolution, vb, out, small):
+        """Exact x sweep on complete lines of a y slab: lines [nx, nys, nz] int32 -> out [nx, nys, nz] fp32."""
+        assert lines.is_contiguous() and out.is_contiguous()
+        nx, nys, nz = lines.shape
+        self.ctx.sweep_x_lines_device(lines.data_ptr(), nx, nys, nz, y_global, ny_global, resolution, vb,
+                                      out.data_ptr(), small.data_ptr(), self.stream())
 
     def sweep_x(self, ext, halo_lo, nxs, halo_hi, lo_trunc, hi_trunc, x_global, nx_global, resolution, vb,
                 out, small):
@@ -142,8 +158,12 @@ class SlabSdfBuilder:
         rows = self.halo_lo + self.nxs + self.halo_hi
         self.ext = None                 # int32 plane field of the general path, allocated on first use
         self.ext_rows = rows
-        self.full = None                # all-gather target, allocated on first whole-line fallback
-        self.fallbacks = 0              # whole-line (all-gather) re-sweeps of the general path
+        self.y0, self.y1 = slab_range(self.ny, self.rank, self.world)      # this rank's y slab (whole-line x sweep)
+        self.lines = None               # [nx, nys, nz] int32: complete x lines of the y slab, allocated on first use
+        self.out_y = None               # [nx, nys, nz] fp32
+        self.hint = None                # int32[1]: "far-field" hint of the y sweep
+        self.general_exchange = "halo (near-field) / all-to-all re-partition to y slabs (far-field)"
+        self.fallbacks = 0              # whole-line (re-partitioned) x sweeps of the general path
         self.general_builds = 0         # builds the dense path could not certify
         # dense path
         self.dense = (bool(dense) and not self.vb and dense_shape_ok(self.nz) and min_slab >= BALL_HALO
@@ -302,55 +322,90 @@ class SlabSdfBuilder:
         return len(t), sum(e0.elapsed_time(e1) for e0, e1, _ in t), t[0][2]
 
     # -- general path (synchronous; exact for any input) -----------------------------------------------
-    def _gather_full(self):
-        if self.full is None:
-            self.full = torch.empty((self.nx, self.ny, self.nz), dtype=torch.int32, device=self.device)
-        own = self.ext[self.halo_lo:self.halo_lo + self.nxs]
-        chunks = [self.full[slice(*slab_range(self.nx, r, self.world))] for r in range(self.world)]
-        even = all(c.shape[0] == chunks[0].shape[0] for c in chunks)
-        if even:
-            dist.all_gather_into_tensor(self.full, own.contiguous(), group=self.group)
-        else:
-            dist.all_gather(chunks, own.contiguous(), group=self.group)
-        return self.full
+    def _p2p(self, sends, recvs):
+        """One grouped batch of point-to-point messages: sends / recvs = [(tensor, group rank)]."""
+        ops = [dist.P2POp(dist.isend, t, self._peer(r), self.group) for t, r in sends]
+        ops += [dist.P2POp(dist.irecv, t, self._peer(r), self.group) for t, r in recvs]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+
+    def _whole_lines(self, own, slot):
+        """Steps 4-6: x slabs -> y slabs, exact x sweep on complete lines, back to x slabs.  Returns the maxima."""
+        nys = self.y1 - self.y0
+        if self.lines is None:
+            self.lines = torch.empty((self.nx, max(nys, 1), self.nz), dtype=torch.int32, device=self.device)
+            self.out_y = torch.empty((self.nx, max(nys, 1), self.nz), dtype=torch.float32, device=self.device)
+        small = slot.small
+        ranges_x = [slab_range(self.nx, r, self.world) for r in range(self.world)]
+        ranges_y = [slab_range(self.ny, r, self.world) for r in range(self.world)]
+        # forward: my rows of peer r's y slab -> peer r; peer s's rows of MY y slab land at x in [x0_s, x1_s)
+        sends, recvs = [], []
+        for r in range(self.world):
+            ya, yb = ranges_y[r]
+            xa, xb = ranges_x[r]
+            if r == self.rank:
+                if nys > 0:
+                    self.lines[self.x0:self.x1].copy_(own[:, self.y0:self.y1])
+            else:
+                if yb > ya:
+                    sends.append((own[:, ya:yb].contiguous(), r))
+                if nys > 0:
+                    recvs.append((self.lines[xa:xb], r))
+        self._p2p(sends, recvs)
+        small.zero_()
+        if nys > 0:
+            self.stages.sweep_x_lines(self.lines, self.y0, self.ny, self.resolution, self.vb, self.out_y, small)
+            if hasattr(self.stages, "fold"):
+                self.stages.fold(small)     # (HipStages sets defer_fold: the stage call leaves its maxima in the slots)
+        # backward: the x rows of peer r's slab (contiguous) -> peer r; placed into my y columns of peer s
+        sends, recvs, tmp = [], [], {}
+        for r in range(self.world):
+            xa, xb = ranges_x[r]
+            ya, yb = ranges_y[r]
+            if r == self.rank:
+                if nys > 0:
+                    slot.out[:, self.y0:self.y1].copy_(self.out_y[self.x0:self.x1])
+            else:
+                if nys > 0:
+                    sends.append((self.out_y[xa:xb], r))
+                if yb > ya:
+                    tmp[r] = torch.empty((self.nxs, yb - ya, self.nz), dtype=torch.float32, device=self.device)
+                    recvs.append((tmp[r], r))
+        self._p2p(sends, recvs)
+        for r, t in tmp.items():
+            ya, yb = ranges_y[r]
+            slot.out[:, ya:yb].copy_(t)
+        self._allreduce_small(small)
+        max_f, max_q, _, _ = (int(v) for v in small.tolist())
+        return max_f, max_q
 
     def _build_general(self, mask_slab, slot):
         if self.ext is None:
             self.ext = torch.empty((self.ext_rows, self.ny, self.nz), dtype=torch.int32, device=self.device)
+            self.hint = torch.zeros(1, dtype=torch.int32, device=self.device)
         lo, n, hi, h = self.halo_lo, self.nxs, self.halo_hi, self.halo
         own = self.ext[lo:lo + n]
-        if self.world > 1 and 0 < h and 2 * h < n:
-            # boundary planes first, so their exchange over xGMI overlaps the interior z/y sweeps
-            self.stages.sweep_zy(mask_slab[:h], own[:h])
-            self.stages.sweep_zy(mask_slab[n - h:], own[n - h:])
-            works = self._exchange(self.ext, lo, n, h)
-            self.stages.sweep_zy(mask_slab[h:n - h], own[h:n - h])
-        else:
-            self.stages.sweep_zy(mask_slab, own)
-            works = self._exchange(self.ext, lo, n, h)
-        for w in works:
-            w.wait()
+        self.hint.zero_()
+        self.stages.sweep_zy(mask_slab, own, self.hint)
+        if self.world > 1:
+            dist.all_reduce(self.hint, op=dist.ReduceOp.MAX, group=self.group)
+        far = int(self.hint.item()) != 0
         small = slot.small
-        small.zero_()
-        self.stages.sweep_x(self.ext, lo, n, hi, self.x0 - lo > 0, self.x1 + hi < self.nx, self.x0, self.nx,
-                            self.resolution, self.vb, slot.out, small)
-        if hasattr(self.stages, "fold"):
-            self.stages.fold(small)
-        self._allreduce_small(small)
-        max_f, max_q, status, _ = (int(v) for v in small.tolist())
-        if status:
-            # some voxel anywhere needed a plane beyond its halo: redo the x sweep on complete lines
-            self.fallbacks += 1
-            full = self._gather_full()
+        if not far:
+            for w in self._exchange(self.ext, lo, n, h):
+                w.wait()
             small.zero_()
-            self.stages.sweep_x(full, self.x0, n, self.nx - self.x1, False, False, self.x0, self.nx,
+            self.stages.sweep_x(self.ext, lo, n, hi, self.x0 - lo > 0, self.x1 + hi < self.nx, self.x0, self.nx,
                                 self.resolution, self.vb, slot.out, small)
             if hasattr(self.stages, "fold"):
                 self.stages.fold(small)
             self._allreduce_small(small)
             max_f, max_q, status, _ = (int(v) for v in small.tolist())
-            assert status == 0
-        return max_f, max_q
+            if not status:
+                return max_f, max_q
+        # far-field scene, or some voxel needed a plane beyond its halo: sweep complete lines
+        self.fallbacks += 1
+        return self._whole_lines(own, slot)
 
     # -- public API --------------------------------------------------------------------------------
     def build_async(self, mask_slab):

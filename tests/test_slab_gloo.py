@@ -57,7 +57,11 @@ class OracleStages:
         if (~found).any():
             small[3] = 1
 
-    def sweep_zy(self, mask_slab, rows):
+    far_hint = 0                    # what the y sweep reports as "far-field" (the HIP stage decides it from a probe)
+
+    def sweep_zy(self, mask_slab, rows, far=None):
+        if far is not None:
+            far[0] = self.far_hint
         m = mask_slab.numpy()
         for x in range(m.shape[0]):
             plane = m[x:x + 1]
@@ -100,6 +104,41 @@ class OracleStages:
             if filled.any():
                 small[1] = max(int(small[1]), int(D[filled].max()))
         small[2] = max(int(small[2]), status)
+
+
+    def sweep_x_lines(self, lines, y_global, ny_global, res, vb, out, small):
+        """Contract of sdfgpu_sweep_x_lines_device: complete x lines of a y slab."""
+        e = lines.numpy().astype(np.int64)
+        nx, nys, nz = e.shape
+        for p in range(nx):
+            cen = e[p]
+            filled = cen < 0
+            best = np.abs(cen)
+            for q in range(nx):
+                same = (e[q] < 0) == filled
+                best = np.minimum(best, np.where(same, np.abs(e[q]), 0) + (p - q) ** 2)
+            D = np.minimum(best, INF)
+            if vb:
+                yy, zz = np.meshgrid(np.arange(nys) + y_global, np.arange(nz), indexing="ij")
+                b = np.full((nys, nz), INF, np.int64)
+                if nx > 1:
+                    b = np.minimum(b, min(p + 1, nx - p))
+                if ny_global > 1:
+                    b = np.minimum(b, np.minimum(yy + 1, ny_global - yy))
+                if nz > 1:
+                    b = np.minimum(b, np.minimum(zz + 1, nz - zz))
+                D = np.where(b < 32768, np.minimum(D, b * b), D)
+            with np.errstate(over="ignore"):
+                f = np.where(D >= INF, np.inf, np.sqrt(D.astype(np.float64)) * res).astype(np.float32)
+            out[p] = torch.from_numpy(np.where(filled, -f, f))
+            if (~filled).any():
+                small[0] = max(int(small[0]), int(D[~filled].max()))
+            if filled.any():
+                small[1] = max(int(small[1]), int(D[filled].max()))
+
+
+class FarOracleStages(OracleStages):
+    far_hint = 1                    # every y sweep reports far-field: the builder re-partitions without trying the halo
 
 
 class OraclePhaseStages(OracleStages):
@@ -149,15 +188,15 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, p, seed, res, vb, halo, q, dense=False, steps=1, phases=False):
+def _worker(rank, world, port, shape, p, seed, res, vb, halo, q, dense=False, steps=1, phases=False, far=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         x0, x1 = slab.slab_range(shape[0], rank, world)
         mask = torch.from_numpy(synth.bernoulli_mask(shape, p, seed, x_range=(x0, x1)))
-        b = slab.SlabSdfBuilder(OraclePhaseStages() if phases else OracleStages(), shape, res, vb, halo=halo, rank=rank,
-                                world=world, dense=dense)
+        stages = OraclePhaseStages() if phases else (FarOracleStages() if far else OracleStages())
+        b = slab.SlabSdfBuilder(stages, shape, res, vb, halo=halo, rank=rank, world=world, dense=dense)
         if steps == 1:
             sdf, ext = b.build(mask)
         else:                                   # pipelined use: validate one build behind
@@ -173,11 +212,11 @@ def _worker(rank, world, port, shape, p, seed, res, vb, halo, q, dense=False, st
         dist.destroy_process_group()
 
 
-def _run(world, shape, p, seed, res=1.0, vb=False, halo=4, dense=False, steps=1, phases=False):
+def _run(world, shape, p, seed, res=1.0, vb=False, halo=4, dense=False, steps=1, phases=False, far=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, p, seed, res, vb, halo, q, dense, steps, phases))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, p, seed, res, vb, halo, q, dense, steps, phases, far))
              for r in range(world)]
     for pr in procs:
         pr.start()
@@ -212,14 +251,25 @@ def test_three_ranks_uneven_slabs_virtual_border():
     assert np.array_equal(got, want) and ext == want_ext
 
 
-def test_two_ranks_sparse_grid_takes_allgather_fallback():
+def test_two_ranks_sparse_grid_takes_whole_line_repartition():
     shape = (32, 8, 8)
     got, ext, (fallbacks, _, _) = _run(2, shape, 0.004, 5, halo=2)
     m = synth.bernoulli_mask(shape, 0.004, 5)
     assert 0 < m.sum() < 16 and m[:13].sum() == 0      # rank 0's slab sees sites only far away
     want, want_ext, _ = O.exact_sdf(m, 1.0)
     assert np.array_equal(got, want) and ext == want_ext
-    assert fallbacks == 1                       # distances exceed the halo: whole-line re-sweep
+    assert fallbacks == 1                       # distances exceed the halo: re-partition to y slabs, whole-line sweep
+
+
+@pytest.mark.parametrize("world,shape,vb", [(2, (18, 10, 8), False), (3, (20, 11, 6), True), (3, (9, 2, 8), True)])
+def test_far_field_hint_goes_straight_to_the_repartition(world, shape, vb):
+    """x slabs -> y slabs (one message per peer and direction), exact x sweep on complete lines, back.
+    Uneven x and y slabs, fewer y rows than ranks (an empty y slab), virtual border with the y offset."""
+    m = synth.bernoulli_mask(shape, 0.01, 7)
+    got, ext, (fallbacks, _, _) = _run(world, shape, 0.01, 7, res=0.5, vb=vb, halo=2, far=True)
+    want, want_ext, _ = O.exact_sdf(m, 0.5, vb)
+    assert np.array_equal(got, want) and ext == want_ext
+    assert fallbacks == 1
 
 
 def test_two_ranks_one_class_only():
