@@ -264,6 +264,11 @@ int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf,
                                int enable_edge_gradients,
                                double* d_distance, double* d_gradient, uint8_t* d_flags, void* stream);
 
+/* CollisionMapGrid predicate (collision_map.hpp:689-704) on raw cell records -> byte mask (1 = filled), for callers
+ * of the slab stages, which take masks: occupancy > 0.5f || (unknown_is_filled && occupancy == 0.5f). */
+int sdfgpu_classify_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
+                                 int unknown_is_filled, int64_t n_cells, uint8_t* d_mask, void* stream);
+
 /* Next-row N2: point cloud -> occupancy grid, the convention of scripts/3d_sdf_demo_rviz.py:22-29:
  * index = trunc((p - origin) / resolution) per axis (fp64 arithmetic on fp32 points), mask[ix][iy][iz] = 1
  * with explicit x, y, z axis order; points outside the grid are dropped.  d_points: n_points x 3 floats

@@ -1,0 +1,77 @@
+/*
+ * sdfgpu_multi.h -- the SDF build path across the GPUs of one node behind a C ABI (libsdfgpu_multi.so).
+ *
+ * SURVEY.md 8(b) asks for "sdfgpu_init(int n_gpus)": this is it, as a handle-based API like sdfgpu.h.  One host
+ * process drives n ranks, one rank per GPU; the grid is cut into x slabs (x = the slowest axis of the reference's
+ * VoxelGrid layout, so a rank's slab is one contiguous block of the caller's array), exactly the decomposition of
+ * sdf_tools_amd/slab.py, built from the same stage entry points of sdfgpu.h:
+ *
+ *   dense scenes   pack -> exchange of 2 bit-planes per neighbour -> bit-parallel ball kernel
+ *   other scenes   slab-local z / y sweeps -> (near-field) halo planes + x sweep, or (far-field / unresolved)
+ *                  all-to-all re-partition x slabs -> y slabs, exact x sweep on complete lines, and back
+ *
+ * All inter-GPU traffic goes through RCCL (rccl.h: ncclSend / ncclRecv inside one group = one message per peer and
+ * direction over the direct xGMI links).  `devices` may name the same GPU more than once (several logical ranks on
+ * one GPU); RCCL allows one rank per device, so such a context moves the same messages with device-to-device
+ * copies instead -- that form exists so the multi-rank schedule can be tested on a single-GPU box.
+ *
+ * Replaces, for a caller with several GPUs, the same reference interface as sdfgpu_build:
+ * sdf_generation::ExtractSignedDistanceField (include/sdf_tools/sdf_generation.hpp:273-420) and
+ * CollisionMapGrid::ExtractSignedDistanceField (include/sdf_tools/collision_map.hpp:680-712).
+ * Results are bit-identical to sdfgpu_build on one GPU.  No CPU fallback.
+ */
+#ifndef SDFGPU_MULTI_H
+#define SDFGPU_MULTI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sdfgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdfgpu_multi_context* sdfgpu_multi_handle;
+
+/* n_ranks >= 1; devices[n_ranks] = HIP device of each rank (NULL: rank r on device r). */
+int sdfgpu_multi_create(int n_ranks, const int* devices, sdfgpu_multi_handle* out_handle);
+int sdfgpu_multi_destroy(sdfgpu_multi_handle h);
+/* Message of the last failure on this handle (h == NULL: of the last failed sdfgpu_multi_create). */
+const char* sdfgpu_multi_last_error(sdfgpu_multi_handle h);
+int sdfgpu_multi_ranks(sdfgpu_multi_handle h);
+
+/* x range [*x0, *x1) of `rank` for a grid with nx planes (balanced contiguous slabs). */
+int sdfgpu_multi_slab_range(sdfgpu_multi_handle h, int64_t nx, int rank, int64_t* x0, int64_t* x1);
+
+/* Whole-path entry points, host buffers holding the WHOLE grid (same contract as sdfgpu_build / sdfgpu_build_cells). */
+int sdfgpu_multi_build(sdfgpu_multi_handle h, const uint8_t* filled,
+                       int64_t nx, int64_t ny, int64_t nz,
+                       double resolution, int add_virtual_border,
+                       float* out_sdf, double* out_max, double* out_min);
+int sdfgpu_multi_build_cells(sdfgpu_multi_handle h, const void* cells,
+                             size_t cell_stride, size_t occupancy_offset, int unknown_is_filled,
+                             int64_t nx, int64_t ny, int64_t nz,
+                             double resolution, int add_virtual_border,
+                             float* out_sdf, double* out_max, double* out_min);
+
+/* Device-resident form: d_mask_slabs[r] / d_out_slabs[r] are device pointers on rank r's GPU to its x slab
+ * ([x1 - x0][ny][nz] uint8 / fp32).  Synchronous (returns when every rank has finished). */
+int sdfgpu_multi_build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask_slabs,
+                              int64_t nx, int64_t ny, int64_t nz,
+                              double resolution, int add_virtual_border,
+                              float* const* d_out_slabs, double* out_max, double* out_min);
+
+/* What the last build did: bit 0 = the dense tier certified every rank's slab, bit 1 = the x sweep ran on
+ * re-partitioned complete lines (far-field scene), bit 2 = the exchange used RCCL (0: device-to-device copies,
+ * i.e. several ranks share a GPU). */
+int sdfgpu_multi_last_path(sdfgpu_multi_handle h, int* out_bits);
+
+/* Option passed to every rank's sdfgpu context (sdfgpu_set_option), plus "halo" (int32 planes exchanged per side on
+ * the near-field general path, default 3) and "dense" (0 = skip the dense tier). */
+int sdfgpu_multi_set_option(sdfgpu_multi_handle h, const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFGPU_MULTI_H */

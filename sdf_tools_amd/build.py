@@ -16,6 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libsdfgpu.so")
+LIB_MULTI = os.path.join(PKG, "libsdfgpu_multi.so")
 
 
 def _newer(target, sources):
@@ -47,6 +48,21 @@ def build_libsdfgpu(force=False, verbose=False):
     return LIB
 
 
+def build_libsdfgpu_multi(force=False, verbose=False):
+    """libsdfgpu_multi.so: the multi-GPU C ABI (include/sdfgpu_multi.h) over libsdfgpu.so + RCCL.  Host code only."""
+    src = os.path.join(CSRC, "sdfgpu_multi.cpp")
+    deps = [src, os.path.join(INCLUDE, "sdfgpu_multi.h"), os.path.join(INCLUDE, "sdfgpu.h")]
+    build_libsdfgpu(force=False, verbose=verbose)
+    if not force and not _newer(LIB_MULTI, deps + [LIB]):
+        return LIB_MULTI
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", "/opt/rocm/include",
+           src, "-o", LIB_MULTI, "-L", PKG, "-lsdfgpu", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_MULTI
+
+
 def pysdf_tools_path():
     suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
     return os.path.join(PKG, "pysdf_tools" + suffix)
@@ -76,7 +92,7 @@ def build_pysdf_tools(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    out = [build_libsdfgpu(force, verbose)]
+    out = [build_libsdfgpu(force, verbose), build_libsdfgpu_multi(force, verbose)]
     p = build_pysdf_tools(force, verbose)
     if p:
         out.append(p)

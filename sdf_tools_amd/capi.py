@@ -23,7 +23,7 @@ EXPORTS = [
     "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
     "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
-    "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device",
+    "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
 ]
 
 
@@ -71,6 +71,7 @@ def load_library():
     L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
     L.sdfgpu_sweep_zy_device.argtypes = [vp, vp, i64, i64, i64, vp, vp]
+    L.sdfgpu_classify_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, vp, vp]
     L.sdfgpu_sweep_zy_tiered_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
     L.sdfgpu_sweep_x_lines_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_sweep_x_device.argtypes = [vp, vp, i64, i64, i64, i64, i64, ci, ci, i64, i64, dbl, ci, vp, vp, vp, vp]
@@ -315,3 +316,117 @@ class SdfGpu:
 
     def set_tuning(self, rows_per_chunk_y=0, rows_per_chunk_x=0):
         self._check(self._lib.sdfgpu_set_tuning(self._h, int(rows_per_chunk_y), int(rows_per_chunk_x)))
+
+
+# ---- multi-GPU C ABI (include/sdfgpu_multi.h, libsdfgpu_multi.so) -------------------------------------------------
+MULTI_EXPORTS = [
+    "sdfgpu_multi_create", "sdfgpu_multi_destroy", "sdfgpu_multi_last_error", "sdfgpu_multi_ranks",
+    "sdfgpu_multi_slab_range", "sdfgpu_multi_build", "sdfgpu_multi_build_cells", "sdfgpu_multi_build_device",
+    "sdfgpu_multi_last_path", "sdfgpu_multi_set_option",
+]
+_multi_lib = None
+
+
+def load_multi_library():
+    """dlopen sdf_tools_amd/libsdfgpu_multi.so (x-slab multi-GPU build over RCCL; no CPU fallback)."""
+    global _multi_lib
+    if _multi_lib is not None:
+        return _multi_lib
+    load_library()                               # libsdfgpu.so (and torch's HIP / RCCL runtimes) first
+    path = _build.LIB_MULTI
+    if not os.path.exists(path):
+        raise ImportError("libsdfgpu_multi.so is not built (run `python -m sdf_tools_amd.build`)")
+    L = ctypes.CDLL(path)
+    i64, dbl, ci, vp, sz = ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    L.sdfgpu_multi_create.argtypes = [ci, vp, ctypes.POINTER(vp)]
+    L.sdfgpu_multi_destroy.argtypes = [vp]
+    L.sdfgpu_multi_last_error.argtypes = [vp]
+    L.sdfgpu_multi_last_error.restype = ctypes.c_char_p
+    L.sdfgpu_multi_ranks.argtypes = [vp]
+    L.sdfgpu_multi_slab_range.argtypes = [vp, i64, ci, vp, vp]
+    L.sdfgpu_multi_build.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_multi_build_cells.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_multi_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_multi_last_path.argtypes = [vp, vp]
+    L.sdfgpu_multi_set_option.argtypes = [vp, ctypes.c_char_p, ci]
+    for name in MULTI_EXPORTS:
+        if name != "sdfgpu_multi_last_error":
+            getattr(L, name).restype = ci
+    _multi_lib = L
+    return L
+
+
+class MultiSdfGpu:
+    """n ranks (one per GPU; the same GPU may be named several times for single-GPU testing) behind sdfgpu_multi_*."""
+
+    def __init__(self, n_ranks, devices=None):
+        self._lib = load_multi_library()
+        h = ctypes.c_void_p()
+        devs = None
+        if devices is not None:
+            devs = (ctypes.c_int * n_ranks)(*[int(d) for d in devices])
+        rc = self._lib.sdfgpu_multi_create(int(n_ranks), devs, ctypes.byref(h))
+        if rc != 0:
+            raise SdfGpuError(rc, self._lib.sdfgpu_multi_last_error(None).decode())
+        self._h = h
+        self.n_ranks = int(n_ranks)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdfgpu_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SdfGpuError(rc, self._lib.sdfgpu_multi_last_error(self._h).decode())
+
+    def slab_range(self, nx, rank):
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self._lib.sdfgpu_multi_slab_range(self._h, int(nx), int(rank), ctypes.byref(a), ctypes.byref(b)))
+        return int(a.value), int(b.value)
+
+    def set_option(self, name, value):
+        self._check(self._lib.sdfgpu_multi_set_option(self._h, name.encode(), int(value)))
+
+    def last_path(self):
+        v = ctypes.c_int()
+        self._check(self._lib.sdfgpu_multi_last_path(self._h, ctypes.byref(v)))
+        return {"dense_certified": bool(v.value & 1), "whole_lines": bool(v.value & 2), "rccl": bool(v.value & 4)}
+
+    def build(self, filled, resolution=1.0, add_virtual_border=False):
+        m = np.ascontiguousarray(filled, dtype=np.uint8)
+        out = np.empty(m.shape, dtype=np.float32)
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_multi_build(self._h, m.ctypes.data, *m.shape, float(resolution),
+                                                 int(bool(add_virtual_border)), out.ctypes.data,
+                                                 ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return out, (float(ext[0]), float(ext[1]))
+
+    def build_cells(self, cells, shape, cell_stride=8, occupancy_offset=0, unknown_is_filled=False, resolution=1.0,
+                    add_virtual_border=False):
+        c = np.ascontiguousarray(cells)
+        nx, ny, nz = (int(s) for s in shape)
+        out = np.empty((nx, ny, nz), dtype=np.float32)
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_multi_build_cells(self._h, c.ctypes.data, cell_stride, occupancy_offset,
+                                                       int(bool(unknown_is_filled)), nx, ny, nz, float(resolution),
+                                                       int(bool(add_virtual_border)), out.ctypes.data,
+                                                       ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return out, (float(ext[0]), float(ext[1]))
+
+    def build_device(self, d_mask_slabs, shape, d_out_slabs, resolution=1.0, add_virtual_border=False):
+        """d_mask_slabs / d_out_slabs: per-rank device pointers (ints) of the x slabs."""
+        nx, ny, nz = (int(s) for s in shape)
+        pm = (ctypes.c_void_p * self.n_ranks)(*[int(p) for p in d_mask_slabs])
+        po = (ctypes.c_void_p * self.n_ranks)(*[int(p) for p in d_out_slabs])
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_multi_build_device(self._h, pm, nx, ny, nz, float(resolution),
+                                                        int(bool(add_virtual_border)), po, ctypes.byref(ext, 0),
+                                                        ctypes.byref(ext, 8)))
+        return float(ext[0]), float(ext[1])

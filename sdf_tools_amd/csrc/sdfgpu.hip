@@ -1250,6 +1250,21 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
     return SDFGPU_OK;
 }
 
+int sdfgpu_classify_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
+                                 int unknown_is_filled, int64_t n_cells, uint8_t* d_mask, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_cells || !d_mask || n_cells < 0) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad classify arguments");
+    if (cell_stride < 4 || (cell_stride % 4) || (occupancy_offset % 4) || occupancy_offset + 4 > cell_stride)
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (n_cells == 0) return SDFGPU_OK;
+    CellLoader ld{reinterpret_cast<const char*>(d_cells), (int64_t)cell_stride, (int64_t)occupancy_offset, unknown_is_filled};
+    hipLaunchKernelGGL(k_classify_cells, dim3((unsigned)((n_cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       ld, n_cells, d_mask);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
 int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
                                   double resolution, int64_t nx, int64_t ny, int64_t nz, uint8_t* d_mask, int clear_first,
                                   void* stream) {

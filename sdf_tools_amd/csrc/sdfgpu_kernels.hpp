@@ -587,6 +587,12 @@ __global__ __launch_bounds__(kBlock) void k_classify_tagged(const char* __restri
     mask[i] = (pass && occupied) ? 1 : 0;
 }
 
+// collision_map.hpp:680-712 predicate on raw COLLISION_CELL records -> byte mask (slab pipelines take masks)
+__global__ __launch_bounds__(kBlock) void k_classify_cells(CellLoader ld, int64_t n, uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) mask[i] = ld.filled(i) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------
 // N2: point cloud -> occupancy (scripts/3d_sdf_demo_rviz.py:22-29): idx = trunc((p - origin) / res),
 // vg[ix, iy, iz] = 1.  Points whose index falls outside the grid are dropped.  fp32 points (the

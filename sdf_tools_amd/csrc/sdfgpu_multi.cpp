@@ -1,0 +1,557 @@
+// sdfgpu_multi.cpp -- libsdfgpu_multi.so: the x-slab multi-GPU build behind a C ABI (include/sdfgpu_multi.h).
+//
+// One host thread drives n ranks (one per GPU): per rank a libsdfgpu context, a compute stream and a
+// communication stream.  The schedule is the one of sdf_tools_amd/slab.py (which runs it with one process per GPU
+// on torch.distributed), built from the same stage entry points of include/sdfgpu.h; the inter-GPU messages go
+// through RCCL (one group of ncclSend / ncclRecv per exchange = one message per peer and direction over the
+// direct xGMI links), or -- when several ranks share a GPU, which RCCL does not allow: the single-GPU test form --
+// through device-to-device copies of the same messages.
+// Host code only (no kernels): compiled with hipcc for the HIP / RCCL headers.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/sdfgpu_multi.h"
+
+namespace {
+
+thread_local std::string g_multi_create_error;
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Rank {
+    int dev = 0;
+    sdfgpu_handle ctx = nullptr;
+    hipStream_t s = nullptr, cs = nullptr;      // compute / communication stream
+    hipEvent_t ev_s = nullptr, ev_cs = nullptr;
+    ncclComm_t comm = nullptr;
+    int64_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    Buf mask, out, cells, bits, ext, lines, out_y, sendbuf, recvtmp;
+    uint32_t* d_small = nullptr;                // [0] max d^2 free, [1] filled, [2] status, [3] uncertified, [4] far hint
+    uint32_t* h_small = nullptr;                // pinned
+};
+
+struct Msg {
+    int src, dst;
+    const void* sp;
+    void* dp;
+    size_t bytes;
+};
+
+}  // namespace
+
+struct sdfgpu_multi_context {
+    std::vector<Rank> r;
+    bool use_rccl = false;
+    std::string error;
+    int halo = 3;
+    bool dense_on = true;
+    int last_path = 0;
+};
+
+namespace {
+
+int mfail(sdfgpu_multi_handle h, int code, const char* fmt, ...) {
+    char buf[640];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->error = buf; else g_multi_create_error = buf;
+    return code;
+}
+
+#define M_HIP(h, expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return mfail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #expr); \
+    } while (0)
+#define M_NCCL(h, expr)                                                                                      \
+    do {                                                                                                     \
+        ncclResult_t e_ = (expr);                                                                            \
+        if (e_ != ncclSuccess)                                                                               \
+            return mfail(h, SDFGPU_ERR_HIP, "RCCL error %d (%s) at %s", (int)e_, ncclGetErrorString(e_), #expr); \
+    } while (0)
+#define M_SDF(h, rk, expr)                                                                                   \
+    do {                                                                                                     \
+        int rc_ = (expr);                                                                                    \
+        if (rc_ != SDFGPU_OK) return mfail(h, rc_, "rank %d: %s", (int)(rk), sdfgpu_last_error((h)->r[rk].ctx)); \
+    } while (0)
+
+int ensure(sdfgpu_multi_handle h, Rank& k, Buf& b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return SDFGPU_OK;
+    M_HIP(h, hipSetDevice(k.dev));
+    if (b.p) { M_HIP(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    bytes = std::max<size_t>(bytes, 256);
+    M_HIP(h, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return SDFGPU_OK;
+}
+
+void slab_range(int64_t n, int rank, int world, int64_t* a, int64_t* b) {
+    *a = (rank * n) / world;
+    *b = ((rank + 1) * n) / world;
+}
+
+bool dense_shape_ok(int64_t nz) {
+    const int64_t nzw = nz / 32;
+    return (nz % 32) == 0 && nzw >= 1 && nzw <= 64 && (nzw & (nzw - 1)) == 0;
+}
+
+// Every rank's communication stream waits for what the compute streams have enqueued so far.
+int comm_after_compute(sdfgpu_multi_handle h) {
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        M_HIP(h, hipEventRecord(k.ev_s, k.s));
+    }
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        if (h->use_rccl) {
+            M_HIP(h, hipStreamWaitEvent(k.cs, k.ev_s, 0));
+        } else {                                // a copy reads the sender's buffer: wait for every rank's producer
+            for (Rank& o : h->r) M_HIP(h, hipStreamWaitEvent(k.cs, o.ev_s, 0));
+        }
+    }
+    return SDFGPU_OK;
+}
+
+// ... and the compute streams wait for the exchange (receivers for their data, senders before they reuse buffers).
+int compute_after_comm(sdfgpu_multi_handle h) {
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        M_HIP(h, hipEventRecord(k.ev_cs, k.cs));
+    }
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        if (h->use_rccl) {
+            M_HIP(h, hipStreamWaitEvent(k.s, k.ev_cs, 0));
+        } else {
+            for (Rank& o : h->r) M_HIP(h, hipStreamWaitEvent(k.s, o.ev_cs, 0));
+        }
+    }
+    return SDFGPU_OK;
+}
+
+// One exchange: all messages of all ranks, issued on the communication streams.
+int exchange_msgs(sdfgpu_multi_handle h, const std::vector<Msg>& msgs) {
+    if (msgs.empty()) return SDFGPU_OK;
+    if (h->use_rccl) {
+        M_NCCL(h, ncclGroupStart());
+        for (const Msg& m : msgs) {
+            if (m.bytes == 0) continue;
+            M_HIP(h, hipSetDevice(h->r[m.src].dev));
+            M_NCCL(h, ncclSend(m.sp, m.bytes, ncclChar, m.dst, h->r[m.src].comm, h->r[m.src].cs));
+            M_HIP(h, hipSetDevice(h->r[m.dst].dev));
+            M_NCCL(h, ncclRecv(m.dp, m.bytes, ncclChar, m.src, h->r[m.dst].comm, h->r[m.dst].cs));
+        }
+        M_NCCL(h, ncclGroupEnd());
+    } else {
+        for (const Msg& m : msgs) {
+            if (m.bytes == 0) continue;
+            M_HIP(h, hipSetDevice(h->r[m.dst].dev));
+            M_HIP(h, hipMemcpyAsync(m.dp, m.sp, m.bytes, hipMemcpyDeviceToDevice, h->r[m.dst].cs));
+        }
+    }
+    return SDFGPU_OK;
+}
+
+int read_small(sdfgpu_multi_handle h) {         // status blocks of all ranks -> pinned host memory, then wait
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        M_HIP(h, hipMemcpyAsync(k.h_small, k.d_small, 32, hipMemcpyDeviceToHost, k.s));
+    }
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        M_HIP(h, hipStreamSynchronize(k.s));
+    }
+    return SDFGPU_OK;
+}
+
+int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx, int64_t ny, int64_t nz, double res, int vb,
+                 float* const* d_out, double* out_max, double* out_min) {
+    const int G = (int)h->r.size();
+    if (nx <= 0 || ny <= 0 || nz <= 0) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid dimensions must be positive");
+    if (nx < G) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid has fewer x planes (%lld) than ranks (%d)", (long long)nx, G);
+    const int64_t plane = ny * nz;
+    int64_t min_slab = nx;
+    for (int q = 0; q < G; ++q) {
+        Rank& k = h->r[q];
+        slab_range(nx, q, G, &k.x0, &k.x1);
+        slab_range(ny, q, G, &k.y0, &k.y1);
+        min_slab = std::min(min_slab, k.x1 - k.x0);
+        if (!d_mask[q] || !d_out[q]) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null slab pointer for rank %d", q);
+    }
+    h->last_path = h->use_rccl ? 4 : 0;
+    uint32_t max_f = 0, max_q = 0;
+
+    // ---- dense tier: pack -> 2 bit-planes per neighbour -> ball kernel -----------------------------------------------
+    const int64_t hb = 2;
+    const bool dense = h->dense_on && !vb && dense_shape_ok(nz) && min_slab >= hb;
+    bool need_general = true;
+    if (dense) {
+        const int64_t wplane = ny * (nz / 32);
+        for (int q = 0; q < G; ++q) {
+            Rank& k = h->r[q];
+            const int64_t hl = q > 0 ? hb : 0, hh = q < G - 1 ? hb : 0, nxs = k.x1 - k.x0;
+            if (int rc = ensure(h, k, k.bits, (size_t)(hl + nxs + hh) * wplane * 4)) return rc;
+            M_SDF(h, q, sdfgpu_slab_dense_phase(k.ctx, 0, d_mask[q], nxs, ny, nz, (uint32_t*)k.bits.p, hl, hh, res, d_out[q],
+                                                k.d_small, k.s));
+        }
+        if (int rc = comm_after_compute(h)) return rc;
+        std::vector<Msg> msgs;
+        for (int q = 0; q + 1 < G; ++q) {       // boundary planes between rank q and q + 1, both directions
+            Rank& a = h->r[q];
+            Rank& b = h->r[q + 1];
+            const int64_t al = q > 0 ? hb : 0, an = a.x1 - a.x0;
+            uint32_t* abits = (uint32_t*)a.bits.p;
+            uint32_t* bbits = (uint32_t*)b.bits.p;
+            msgs.push_back({q, q + 1, abits + (al + an - hb) * wplane, bbits, (size_t)hb * wplane * 4});
+            msgs.push_back({q + 1, q, bbits + hb * wplane, abits + (al + an) * wplane, (size_t)hb * wplane * 4});
+        }
+        if (int rc = exchange_msgs(h, msgs)) return rc;
+        for (int q = 0; q < G; ++q) {           // interior planes while the messages fly
+            Rank& k = h->r[q];
+            const int64_t hl = q > 0 ? hb : 0, hh = q < G - 1 ? hb : 0;
+            M_SDF(h, q, sdfgpu_slab_dense_phase(k.ctx, 1, d_mask[q], k.x1 - k.x0, ny, nz, (uint32_t*)k.bits.p, hl, hh, res,
+                                                d_out[q], k.d_small, k.s));
+        }
+        if (int rc = compute_after_comm(h)) return rc;
+        for (int q = 0; q < G; ++q) {
+            Rank& k = h->r[q];
+            const int64_t hl = q > 0 ? hb : 0, hh = q < G - 1 ? hb : 0;
+            M_SDF(h, q, sdfgpu_slab_dense_phase(k.ctx, 2, d_mask[q], k.x1 - k.x0, ny, nz, (uint32_t*)k.bits.p, hl, hh, res,
+                                                d_out[q], k.d_small, k.s));
+        }
+        if (int rc = read_small(h)) return rc;
+        need_general = false;
+        for (Rank& k : h->r) {
+            need_general |= k.h_small[3] != 0;
+            max_f = std::max(max_f, k.h_small[0]);
+            max_q = std::max(max_q, k.h_small[1]);
+        }
+        if (!need_general) h->last_path |= 1;
+    }
+
+    if (need_general) {
+        // ---- slab-local z / y sweeps (tier picked on the device), far hint ------------------------------------------
+        const int64_t halo = std::max<int64_t>(0, std::min<int64_t>(h->halo, min_slab));
+        for (int q = 0; q < G; ++q) {
+            Rank& k = h->r[q];
+            const int64_t hl = q > 0 ? halo : 0, hh = q < G - 1 ? halo : 0, nxs = k.x1 - k.x0;
+            if (int rc = ensure(h, k, k.ext, (size_t)(hl + nxs + hh) * plane * 4)) return rc;
+            M_HIP(h, hipSetDevice(k.dev));
+            M_HIP(h, hipMemsetAsync(k.d_small, 0, 32, k.s));
+            M_SDF(h, q, sdfgpu_sweep_zy_tiered_device(k.ctx, d_mask[q], nxs, ny, nz, (int32_t*)k.ext.p + hl * plane,
+                                                      k.d_small + 4, k.s));
+        }
+        if (int rc = read_small(h)) return rc;
+        bool far = false;
+        for (Rank& k : h->r) far |= k.h_small[4] != 0;
+        if (!far) {
+            // ---- near-field: `halo` int32 planes per neighbour, x sweep that reports voxels needing more ----------------
+            if (int rc = comm_after_compute(h)) return rc;
+            std::vector<Msg> msgs;
+            for (int q = 0; q + 1 < G && halo > 0; ++q) {
+                Rank& a = h->r[q];
+                Rank& b = h->r[q + 1];
+                const int64_t al = q > 0 ? halo : 0, an = a.x1 - a.x0;
+                int32_t* ae = (int32_t*)a.ext.p;
+                int32_t* be = (int32_t*)b.ext.p;
+                msgs.push_back({q, q + 1, ae + (al + an - halo) * plane, be, (size_t)halo * plane * 4});
+                msgs.push_back({q + 1, q, be + halo * plane, ae + (al + an) * plane, (size_t)halo * plane * 4});
+            }
+            if (int rc = exchange_msgs(h, msgs)) return rc;
+            if (int rc = compute_after_comm(h)) return rc;
+            for (int q = 0; q < G; ++q) {
+                Rank& k = h->r[q];
+                const int64_t hl = q > 0 ? halo : 0, hh = q < G - 1 ? halo : 0, nxs = k.x1 - k.x0;
+                M_SDF(h, q, sdfgpu_sweep_x_device(k.ctx, (const int32_t*)k.ext.p, hl, nxs, hh, ny, nz, k.x0 - hl > 0,
+                                                  k.x1 + hh < nx, k.x0, nx, res, vb, d_out[q], k.d_small, k.d_small + 2, k.s));
+            }
+            if (int rc = read_small(h)) return rc;
+            max_f = max_q = 0;
+            for (Rank& k : h->r) {
+                far |= k.h_small[2] != 0;
+                max_f = std::max(max_f, k.h_small[0]);
+                max_q = std::max(max_q, k.h_small[1]);
+            }
+        }
+        if (far) {
+            // ---- far-field: x slabs -> y slabs, exact x sweep on complete lines, back to x slabs ------------------------
+            h->last_path |= 2;
+            const int64_t halo_of = halo;
+            std::vector<Msg> msgs;
+            for (int q = 0; q < G; ++q) {       // pack: my rows of every rank's y slab, contiguous per destination
+                Rank& k = h->r[q];
+                const int64_t hl = q > 0 ? halo_of : 0, nxs = k.x1 - k.x0, nys = k.y1 - k.y0;
+                if (int rc = ensure(h, k, k.sendbuf, (size_t)nxs * plane * 4)) return rc;
+                if (int rc = ensure(h, k, k.recvtmp, (size_t)nxs * plane * 4)) return rc;
+                if (int rc = ensure(h, k, k.lines, (size_t)nx * std::max<int64_t>(nys, 1) * nz * 4)) return rc;
+                if (int rc = ensure(h, k, k.out_y, (size_t)nx * std::max<int64_t>(nys, 1) * nz * 4)) return rc;
+                M_HIP(h, hipSetDevice(k.dev));
+                const int32_t* own = (const int32_t*)k.ext.p + hl * plane;
+                for (int d = 0; d < G; ++d) {
+                    Rank& o = h->r[d];
+                    const int64_t dys = o.y1 - o.y0;
+                    if (dys == 0) continue;
+                    const size_t width = (size_t)dys * nz * 4;
+                    if (d == q) {               // my own y slab: straight into my line buffer
+                        M_HIP(h, hipMemcpy2DAsync((int32_t*)k.lines.p + k.x0 * dys * nz, width, own + o.y0 * nz, (size_t)plane * 4,
+                                                  width, (size_t)nxs, hipMemcpyDeviceToDevice, k.s));
+                    } else {
+                        int32_t* dst = (int32_t*)k.sendbuf.p + nxs * o.y0 * nz;      // blocks laid out in y order
+                        M_HIP(h, hipMemcpy2DAsync(dst, width, own + o.y0 * nz, (size_t)plane * 4, width, (size_t)nxs,
+                                                  hipMemcpyDeviceToDevice, k.s));
+                        msgs.push_back({q, d, dst, nullptr, (size_t)nxs * dys * nz * 4});
+                    }
+                }
+            }
+            for (Msg& m : msgs) {               // destination: rows [x0_src, x1_src) of the receiver's line buffer
+                Rank& o = h->r[m.dst];
+                m.dp = (int32_t*)o.lines.p + h->r[m.src].x0 * (o.y1 - o.y0) * nz;
+            }
+            if (int rc = comm_after_compute(h)) return rc;
+            if (int rc = exchange_msgs(h, msgs)) return rc;
+            if (int rc = compute_after_comm(h)) return rc;
+            for (int q = 0; q < G; ++q) {
+                Rank& k = h->r[q];
+                const int64_t nys = k.y1 - k.y0;
+                M_HIP(h, hipSetDevice(k.dev));
+                M_HIP(h, hipMemsetAsync(k.d_small, 0, 32, k.s));
+                if (nys > 0)
+                    M_SDF(h, q, sdfgpu_sweep_x_lines_device(k.ctx, (const int32_t*)k.lines.p, nx, nys, nz, k.y0, ny, res, vb,
+                                                            (float*)k.out_y.p, k.d_small, k.s));
+            }
+            // back: rows [x0_d, x1_d) of my y slab (contiguous) -> rank d, which scatters them into its x slab
+            msgs.clear();
+            for (int q = 0; q < G; ++q) {
+                Rank& k = h->r[q];
+                const int64_t nys = k.y1 - k.y0;
+                if (nys == 0) continue;
+                for (int d = 0; d < G; ++d) {
+                    Rank& o = h->r[d];
+                    const int64_t dxs = o.x1 - o.x0;
+                    const float* src = (const float*)k.out_y.p + o.x0 * nys * nz;
+                    if (d == q) {
+                        M_HIP(h, hipSetDevice(k.dev));
+                        M_HIP(h, hipMemcpy2DAsync(d_out[q] + k.y0 * nz, (size_t)plane * 4, src, (size_t)nys * nz * 4, (size_t)nys * nz * 4,
+                                                  (size_t)dxs, hipMemcpyDeviceToDevice, k.s));
+                    } else {
+                        msgs.push_back({q, d, src, (float*)o.recvtmp.p + dxs * k.y0 * nz, (size_t)dxs * nys * nz * 4});
+                    }
+                }
+            }
+            if (int rc = comm_after_compute(h)) return rc;
+            if (int rc = exchange_msgs(h, msgs)) return rc;
+            if (int rc = compute_after_comm(h)) return rc;
+            for (const Msg& m : msgs) {         // unpack on the receiver
+                Rank& o = h->r[m.dst];
+                Rank& src = h->r[m.src];
+                const int64_t nys = src.y1 - src.y0, dxs = o.x1 - o.x0;
+                M_HIP(h, hipSetDevice(o.dev));
+                M_HIP(h, hipMemcpy2DAsync(d_out[m.dst] + src.y0 * nz, (size_t)plane * 4, m.dp, (size_t)nys * nz * 4, (size_t)nys * nz * 4,
+                                          (size_t)dxs, hipMemcpyDeviceToDevice, o.s));
+            }
+            if (int rc = read_small(h)) return rc;
+            max_f = max_q = 0;
+            for (Rank& k : h->r) {
+                max_f = std::max(max_f, k.h_small[0]);
+                max_q = std::max(max_q, k.h_small[1]);
+            }
+        }
+    }
+    for (Rank& k : h->r) {                      // everything enqueued has finished (read_small synchronised the compute
+        M_HIP(h, hipSetDevice(k.dev));          // streams; the communication streams are ordered before them)
+        M_HIP(h, hipStreamSynchronize(k.s));
+    }
+    return sdfgpu_extrema_from_dsq(max_f, max_q, res, out_max, out_min);
+}
+
+int build_host(sdfgpu_multi_handle h, const uint8_t* filled, const void* cells, size_t stride, size_t off, int unknown,
+               int64_t nx, int64_t ny, int64_t nz, double res, int vb, float* out, double* out_max, double* out_min) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if ((!filled && !cells) || !out) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
+    const int G = (int)h->r.size();
+    if (nx <= 0 || ny <= 0 || nz <= 0) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid dimensions must be positive");
+    if (nx < G) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid has fewer x planes (%lld) than ranks (%d)", (long long)nx, G);
+    const int64_t plane = ny * nz;
+    std::vector<const uint8_t*> dm((size_t)G);
+    std::vector<float*> dout((size_t)G);
+    for (int q = 0; q < G; ++q) {
+        Rank& k = h->r[q];
+        slab_range(nx, q, G, &k.x0, &k.x1);
+        const int64_t nxs = k.x1 - k.x0;
+        if (int rc = ensure(h, k, k.mask, (size_t)nxs * plane)) return rc;
+        if (int rc = ensure(h, k, k.out, (size_t)nxs * plane * 4)) return rc;
+        M_HIP(h, hipSetDevice(k.dev));
+        if (cells) {
+            if (int rc = ensure(h, k, k.cells, (size_t)nxs * plane * stride)) return rc;
+            M_HIP(h, hipMemcpyAsync(k.cells.p, (const char*)cells + (size_t)k.x0 * plane * stride, (size_t)nxs * plane * stride,
+                                    hipMemcpyHostToDevice, k.s));
+            M_SDF(h, q, sdfgpu_classify_cells_device(k.ctx, k.cells.p, stride, off, unknown, nxs * plane, (uint8_t*)k.mask.p, k.s));
+        } else {
+            M_HIP(h, hipMemcpyAsync(k.mask.p, filled + (size_t)k.x0 * plane, (size_t)nxs * plane, hipMemcpyHostToDevice, k.s));
+        }
+        dm[(size_t)q] = (const uint8_t*)k.mask.p;
+        dout[(size_t)q] = (float*)k.out.p;
+    }
+    if (int rc = build_device(h, dm.data(), nx, ny, nz, res, vb, dout.data(), out_max, out_min)) return rc;
+    for (int q = 0; q < G; ++q) {
+        Rank& k = h->r[q];
+        M_HIP(h, hipSetDevice(k.dev));
+        M_HIP(h, hipMemcpyAsync(out + (size_t)k.x0 * plane, k.out.p, (size_t)(k.x1 - k.x0) * plane * 4, hipMemcpyDeviceToHost, k.s));
+    }
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        M_HIP(h, hipStreamSynchronize(k.s));
+    }
+    return SDFGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdfgpu_multi_create(int n_ranks, const int* devices, sdfgpu_multi_handle* out_handle) {
+    if (!out_handle) return mfail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "out_handle is null");
+    *out_handle = nullptr;
+    if (n_ranks < 1 || n_ranks > 64) return mfail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "n_ranks must be 1..64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return mfail(nullptr, SDFGPU_ERR_NO_DEVICE, "no HIP device available; this library has no CPU fallback");
+    sdfgpu_multi_context* h = new (std::nothrow) sdfgpu_multi_context();
+    if (!h) return mfail(nullptr, SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
+    h->r.resize((size_t)n_ranks);
+    std::set<int> distinct;
+    std::vector<int> devs((size_t)n_ranks);
+    for (int q = 0; q < n_ranks; ++q) {
+        devs[(size_t)q] = devices ? devices[q] : q;
+        if (devs[(size_t)q] < 0 || devs[(size_t)q] >= ndev) {
+            delete h;
+            return mfail(nullptr, SDFGPU_ERR_NO_DEVICE, "rank %d: device index %d out of range (0..%d)", q, devs[(size_t)q], ndev - 1);
+        }
+        distinct.insert(devs[(size_t)q]);
+    }
+    h->use_rccl = (int)distinct.size() == n_ranks;          // RCCL: one rank per device
+    auto bail = [&](int code, const std::string& msg) {
+        g_multi_create_error = msg;
+        sdfgpu_multi_destroy(h);
+        return code;
+    };
+    for (int q = 0; q < n_ranks; ++q) {
+        Rank& k = h->r[(size_t)q];
+        k.dev = devs[(size_t)q];
+        if (hipSetDevice(k.dev) != hipSuccess) return bail(SDFGPU_ERR_HIP, "hipSetDevice failed");
+        const int rc = sdfgpu_create(k.dev, &k.ctx);
+        if (rc != SDFGPU_OK) return bail(rc, std::string("sdfgpu_create: ") + sdfgpu_last_error(nullptr));
+        if (hipStreamCreateWithFlags(&k.s, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&k.cs, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&k.ev_s, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&k.ev_cs, hipEventDisableTiming) != hipSuccess ||
+            hipMalloc((void**)&k.d_small, 64) != hipSuccess || hipMemset(k.d_small, 0, 64) != hipSuccess ||
+            hipHostMalloc((void**)&k.h_small, 64, hipHostMallocDefault) != hipSuccess)
+            return bail(SDFGPU_ERR_HIP, "HIP stream / event / status-block allocation failed");
+    }
+    if (h->use_rccl) {
+        std::vector<ncclComm_t> comms((size_t)n_ranks);
+        const ncclResult_t e = ncclCommInitAll(comms.data(), n_ranks, devs.data());
+        if (e != ncclSuccess) return bail(SDFGPU_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(e));
+        for (int q = 0; q < n_ranks; ++q) h->r[(size_t)q].comm = comms[(size_t)q];
+        // peers exchange device buffers directly: make sure peer access is on where the runtime needs it asked for
+        for (int a = 0; a < n_ranks; ++a)
+            for (int b = 0; b < n_ranks; ++b) {
+                int can = 0;
+                if (a != b && hipDeviceCanAccessPeer(&can, devs[(size_t)a], devs[(size_t)b]) == hipSuccess && can) {
+                    (void)hipSetDevice(devs[(size_t)a]);
+                    (void)hipDeviceEnablePeerAccess(devs[(size_t)b], 0);   // "already enabled" is fine
+                    (void)hipGetLastError();
+                }
+            }
+    }
+    *out_handle = h;
+    return SDFGPU_OK;
+}
+
+int sdfgpu_multi_destroy(sdfgpu_multi_handle h) {
+    if (!h) return SDFGPU_OK;
+    for (Rank& k : h->r) {
+        (void)hipSetDevice(k.dev);
+        if (k.s) (void)hipStreamSynchronize(k.s);
+        if (k.cs) (void)hipStreamSynchronize(k.cs);
+        if (k.comm) (void)ncclCommDestroy(k.comm);
+        for (Buf* b : {&k.mask, &k.out, &k.cells, &k.bits, &k.ext, &k.lines, &k.out_y, &k.sendbuf, &k.recvtmp})
+            if (b->p) (void)hipFree(b->p);
+        if (k.d_small) (void)hipFree(k.d_small);
+        if (k.h_small) (void)hipHostFree(k.h_small);
+        if (k.ev_s) (void)hipEventDestroy(k.ev_s);
+        if (k.ev_cs) (void)hipEventDestroy(k.ev_cs);
+        if (k.s) (void)hipStreamDestroy(k.s);
+        if (k.cs) (void)hipStreamDestroy(k.cs);
+        if (k.ctx) (void)sdfgpu_destroy(k.ctx);
+    }
+    delete h;
+    return SDFGPU_OK;
+}
+
+const char* sdfgpu_multi_last_error(sdfgpu_multi_handle h) { return h ? h->error.c_str() : g_multi_create_error.c_str(); }
+
+int sdfgpu_multi_ranks(sdfgpu_multi_handle h) { return h ? (int)h->r.size() : 0; }
+
+int sdfgpu_multi_slab_range(sdfgpu_multi_handle h, int64_t nx, int rank, int64_t* x0, int64_t* x1) {
+    if (!h || !x0 || !x1 || rank < 0 || rank >= (int)h->r.size()) return SDFGPU_ERR_INVALID_ARGUMENT;
+    slab_range(nx, rank, (int)h->r.size(), x0, x1);
+    return SDFGPU_OK;
+}
+
+int sdfgpu_multi_build(sdfgpu_multi_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                       int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    return build_host(h, filled, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, out_sdf, out_max, out_min);
+}
+
+int sdfgpu_multi_build_cells(sdfgpu_multi_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                             int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                             int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    if (h && !cells) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cells is null");
+    return build_host(h, nullptr, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz, resolution,
+                      add_virtual_border, out_sdf, out_max, out_min);
+}
+
+int sdfgpu_multi_build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask_slabs, int64_t nx, int64_t ny, int64_t nz,
+                              double resolution, int add_virtual_border, float* const* d_out_slabs, double* out_max,
+                              double* out_min) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_mask_slabs || !d_out_slabs) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer array");
+    // the caller's buffers may have been produced on other streams: settle them first
+    for (Rank& k : h->r) {
+        M_HIP(h, hipSetDevice(k.dev));
+        M_HIP(h, hipDeviceSynchronize());
+    }
+    return build_device(h, d_mask_slabs, nx, ny, nz, resolution, add_virtual_border, d_out_slabs, out_max, out_min);
+}
+
+int sdfgpu_multi_last_path(sdfgpu_multi_handle h, int* out_bits) {
+    if (!h || !out_bits) return SDFGPU_ERR_INVALID_ARGUMENT;
+    *out_bits = h->last_path;
+    return SDFGPU_OK;
+}
+
+int sdfgpu_multi_set_option(sdfgpu_multi_handle h, const char* name, int value) {
+    if (!h || !name) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!strcmp(name, "halo")) { h->halo = std::max(0, value); return SDFGPU_OK; }
+    if (!strcmp(name, "dense")) h->dense_on = value != 0;     // (also forwarded: the ranks' own dense tier is not used here)
+    for (size_t q = 0; q < h->r.size(); ++q) M_SDF(h, q, sdfgpu_set_option(h->r[q].ctx, name, value));
+    return SDFGPU_OK;
+}
+
+}  // extern "C"

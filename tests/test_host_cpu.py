@@ -67,3 +67,21 @@ def test_bernoulli_mask_torch_matches_numpy():
     a = synth.bernoulli_mask((5, 5, 8), 0.93, 9)
     b = synth.bernoulli_mask_torch((5, 5, 8), 0.93, 9, device="cpu").numpy()
     assert np.array_equal(a, b)
+
+
+def test_multi_gpu_library_exports_every_declared_symbol_and_refuses_without_gpu():
+    """include/sdfgpu_multi.h (the sdfgpu_init(n_gpus) row of SURVEY 8(b)): libsdfgpu_multi.so loads next to
+    libsdfgpu.so + RCCL, exports what the header declares, and has no CPU fallback."""
+    hdr = open(os.path.join(ROOT, "include", "sdfgpu_multi.h")).read()
+    declared = set(re.findall(r"\b(sdfgpu_multi_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sdfgpu_multi_context", "sdfgpu_multi_handle"}
+    assert declared == set(capi.MULTI_EXPORTS)
+    lib = capi.load_multi_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    data = open(os.path.join(ROOT, "sdf_tools_amd", "libsdfgpu_multi.so"), "rb").read()
+    assert b"librccl.so" in data                      # inter-GPU traffic goes through RCCL
+    if capi.device_count() == 0:
+        with pytest.raises(capi.SdfGpuError) as ei:
+            capi.MultiSdfGpu(2)
+        assert ei.value.code == -4 and "no CPU fallback" in str(ei.value)
