@@ -39,6 +39,15 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
     sdf_tools::SignedDistanceField new_sdf(grid_origin_tranform, frame, grid_resolution, grid_num_x_cells, grid_num_y_cells,
                                            grid_num_z_cells, oob_value);
     double max_distance = 0.0, min_distance = 0.0;
+#ifdef SDF_TOOLS_MULTI_GPU
+    if (MultiGpuContext::NumGpus() > 1 && grid_num_x_cells >= MultiGpuContext::NumGpus()) {
+        sdfgpu_multi_handle mh = MultiGpuContext::Get();
+        ThrowOnMultiStatus(mh, sdfgpu_multi_build(mh, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells,
+                                                  grid_resolution, add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(),
+                                                  &max_distance, &min_distance));
+        return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+    }
+#endif
     sdfgpu_handle h = GpuContext::Get();
     ThrowOnStatus(h, sdfgpu_build(h, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells, grid_resolution,
                                   add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(), &max_distance, &min_distance));
@@ -78,6 +87,15 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
         throw std::invalid_argument("Grid must have uniform resolution");
     sdf_tools::SignedDistanceField new_sdf(origin, frame, cell_sizes.x(), nx, ny, nz, oob_value);
     double max_distance = 0.0, min_distance = 0.0;
+#ifdef SDF_TOOLS_MULTI_GPU
+    if (MultiGpuContext::NumGpus() > 1 && nx >= MultiGpuContext::NumGpus()) {
+        sdfgpu_multi_handle mh = MultiGpuContext::Get();
+        ThrowOnMultiStatus(mh, sdfgpu_multi_build_cells(mh, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny,
+                                                        nz, cell_sizes.x(), add_virtual_border ? 1 : 0,
+                                                        new_sdf.MutableDataForBuild(), &max_distance, &min_distance));
+        return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+    }
+#endif
     sdfgpu_handle h = GpuContext::Get();
     ThrowOnStatus(h, sdfgpu_build_cells(h, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny, nz,
                                         cell_sizes.x(), add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(),

@@ -76,15 +76,15 @@ def build_pysdf_tools(force=False, verbose=False):
         return None
     out = pysdf_tools_path()
     hdr_dir = os.path.join(INCLUDE, "sdf_tools")
-    deps = [src, os.path.join(INCLUDE, "sdfgpu.h")] + \
+    deps = [src, os.path.join(INCLUDE, "sdfgpu.h"), os.path.join(INCLUDE, "sdfgpu_multi.h")] + \
         [os.path.join(hdr_dir, f) for f in sorted(os.listdir(hdr_dir))] + \
         [os.path.join(INCLUDE, "arc_utilities", f) for f in sorted(os.listdir(os.path.join(INCLUDE, "arc_utilities")))]
     if not force and not _newer(out, deps):
         return out
-    build_libsdfgpu(force=False, verbose=verbose)
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+    build_libsdfgpu_multi(force=False, verbose=verbose)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DSDF_TOOLS_MULTI_GPU",
            "-I", INCLUDE, "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
-           src, "-o", out, "-L", PKG, "-lsdfgpu", "-Wl,-rpath,$ORIGIN", "-lz"]
+           src, "-o", out, "-L", PKG, "-lsdfgpu_multi", "-lsdfgpu", "-Wl,-rpath,$ORIGIN", "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

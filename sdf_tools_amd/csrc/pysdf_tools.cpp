@@ -157,6 +157,8 @@ PYBIND11_MODULE(pysdf_tools, m) {
     m.def("DeserializeFixedSizePODFloat", &arc_utilities::DeserializeFixedSizePOD<float>);
     m.def("DeserializeFixedSizePODd", &arc_utilities::DeserializeVectorOfDoubles);
     m.def("SetDevice", [](int device) { sdf_generation::GpuContext::DeviceIndex() = device; }, "GPU used by ExtractSignedDistanceField");
+    m.def("SetNumGpus", [](int n) { sdf_generation::MultiGpuContext::SetNumGpus(n); },
+          "n > 1: ExtractSignedDistanceField cuts the grid into x slabs over GPUs 0..n-1 (RCCL exchange); 1 = single GPU");
 
     py::class_<VoxelGridVecd>(m, "VoxelGrid")
         .def(py::init<>())
