@@ -22,7 +22,10 @@ def find(dirname, pattern):
 
 
 def short(name):
-    for key, label in (("k_pack_bits", "pack_bits"), ("k_ball_dense", "dense_ball"), ("k_sweep_zy_fused", "sweep_zy"),
+    for key, label in (("k_envelope_dc<2>", "envelope_y"), ("k_envelope_dc<3>", "envelope_x"),
+                       ("k_envelope_dcILi2", "envelope_y"), ("k_envelope_dcILi3", "envelope_x"),
+                       ("k_envelope<2>", "envelope_y_gen1"), ("k_envelope<3>", "envelope_x_gen1"),
+                       ("k_pack_bits", "pack_bits"), ("k_ball_dense", "dense_ball"), ("k_sweep_zy_fused", "sweep_zy"),
                        ("k_sweep_x16", "sweep_x16"), ("k_sweep_z_vec16", "sweep_z"), ("k_sweep_z_generic", "sweep_z_generic"),
                        ("k_sweep_march<2", "sweep_y"), ("k_sweep_march<3", "sweep_x"),
                        ("k_sweep_marchILi2", "sweep_y"), ("k_sweep_marchILi3", "sweep_x"),
@@ -55,7 +58,7 @@ def pmc(dirs, out_json):
         for f in find(d, "*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 name = r.get("Kernel_Name", "")
-                label = short(name) or ("copy" if "direct_copy" in name else None)
+                label = short(name) or ("copy" if ("direct_copy" in name or "elementwise_kernel" in name) else None)
                 if label:
                     per[label][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_units": "bytes per launch; raw = counter * 1024 (KiB); read_corrected = 2 * raw FETCH_SIZE "
