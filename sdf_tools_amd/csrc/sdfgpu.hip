@@ -77,6 +77,7 @@ struct sdfgpu_context {
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
     bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
+    bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool tier_select = true;         // pick marching vs envelope sweep per axis on the device, inside the build (probe + decide)
     int force_env = -1;              // -1 automatic, 1 = envelope kernels only (option "envelope_mode")
     int far_num = 1, far_den = 8;    // an axis is far-field when more than num / den of the probed voxels have d^2 >= far_thr
@@ -97,6 +98,7 @@ struct sdfgpu_context {
     bool flags_pending = false;
     hipEvent_t build_done_ev = nullptr;   // recorded behind every build: a build on another stream waits for it first
     bool prev_dense = false;
+    bool prev_generic = false;       // ... and it was the generic form (no fix-up kernel behind it)
     bool expect_dense = false;
     bool last_dense = false;
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
@@ -562,6 +564,34 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     return SDFGPU_OK;
 }
 
+// Generic dense tier (any nz, virtual border): k_pack_bits_rows + k_ball_dense_generic
+int launch_dense_generic(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, size_t stride, size_t off, int unknown,
+                         int64_t nx, int64_t ny, int64_t nz, double resolution, int vb, float* d_out, uint32_t* d_uncert,
+                         hipStream_t s) {
+    const int64_t nzw = (nz + 31) / 32, nrows = nx * ny, nwords = nrows * nzw;
+    if (nwords > 0x7fffffffLL * (int64_t)kBlock) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
+    if (int rc = ensure(h, h->bits, (size_t)nwords * 4)) return rc;
+    const dim3 grid((unsigned)((nwords + kBlock - 1) / kBlock)), block(kBlock);
+    if (d_cells) {
+        CellLoader ld{reinterpret_cast<const char*>(d_cells), (int64_t)stride, (int64_t)off, unknown};
+        hipLaunchKernelGGL(k_pack_bits_rows<CellLoader>, grid, block, 0, s, ld, (uint32_t*)h->bits.ptr, nrows, (int)nz, (int)nzw);
+    } else {
+        MaskLoader ld{d_mask};
+        hipLaunchKernelGGL(k_pack_bits_rows<MaskLoader>, grid, block, 0, s, ld, (uint32_t*)h->bits.ptr, nrows, (int)nz, (int)nzw);
+    }
+    HIP_TRY(h, hipGetLastError());
+    DenseGenArgs a{};
+    a.bits = (const uint32_t*)h->bits.ptr; a.out = d_out;
+    a.nx = (int)nx; a.ny = (int)ny; a.nz = (int)nz; a.nzw = (int)nzw; a.vb = vb;
+    static const int level_d2[7] = {1, 2, 3, 4, 5, 6, 8};
+    for (int l = 0; l < 7; ++l) a.mag[l] = (float)(std::sqrt((double)level_d2[l]) * resolution);
+    a.mag[7] = 0.0f;
+    a.slots = h->d_slots; a.uncertified = d_uncert;
+    hipLaunchKernelGGL(k_ball_dense_generic, grid, block, 0, s, a);
+    HIP_TRY(h, hipGetLastError());
+    return SDFGPU_OK;
+}
+
 int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_cells, size_t stride, size_t off,
                       int unknown, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
                       float* d_out, hipStream_t s) {
@@ -579,6 +609,9 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     void* zy_out = p16 ? h->plane16.ptr : h->yzfield.ptr;
     int32_t* zy_side = p16 ? (int32_t*)h->yzfield.ptr : nullptr;
     bool dense = dense_eligible(h, nz, vb) && ny <= 0x7fffffff;
+    // shapes / modes the tuned dense kernels do not take go through their generic forms (any nz, virtual border)
+    const bool dense_generic = !dense && h->dense_on && h->dense_generic_on && nx <= 0x7fffffff && ny <= 0x7fffffff;
+    dense = dense || dense_generic;
     // Learn from the previous build on this handle, if its flags have arrived (never a wait).  Every
     // setting below is exact; the policy only moves work around:
     //   dense-certified  -> the general kernels will exit on their guard: enqueue the cheapest form of them
@@ -594,7 +627,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         //                       next dense_retry - 1 builds, then try once more
         //   almost dense (the ball kernel left voxels undecided): first try the fix-up kernel behind it; only if that
         //   cannot certify the scene either are the dense kernels left out of the next builds
-        if (h->prev_dense && h->fixup_on) {
+        if (h->prev_dense && h->fixup_on && !h->prev_generic) {
             if (!h->prev_fix_mode) { h->fix_mode = h->h_flags[3] != 0; h->fix_clean = 0; }   // uncertified without KF: try KF next
             else if (h->h_flags[3] != 0) h->fix_mode = false;                      // KF could not certify it either
             else {                                                                 // keep KF while it is needed (left after
@@ -602,7 +635,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                 if (h->fix_clean >= 8) { h->fix_mode = false; h->fix_clean = 0; }  // edge of the ball must not flap)
             }
         }
-        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on))
+        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on || h->prev_generic))
             h->dense_skip = h->dense_retry - 1;
         //   mid-sparse scenes (largest squared distance beyond the radius-3 window's 16): radius-8 register windows
         //   decide most voxels without the outward scan (measured at 512^3: y sweep 0.96 -> 0.53 ms at p = 0.02,
@@ -690,7 +723,13 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     bool cur_fix_mode = false;
     h->last_dense = dense;
     h->guard = nullptr;
-    if (dense) {
+    if (dense && dense_generic) {
+        HIP_TRY(h, mark(1));
+        if (int rc = launch_dense_generic(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz, resolution, vb, d_out,
+                                          h->d_small + 3, s)) return rc;
+        launched_since_mark = true;
+        h->guard = h->d_small + 3;
+    } else if (dense) {
         if (int rc = ensure(h, h->bits, (size_t)n / 8)) return rc;
         if (int rc = launch_pack_bits(h, d_filled, d_cells, stride, off, unknown, n, (uint32_t*)h->bits.ptr, s)) return rc;
         launched_since_mark = true;
@@ -789,6 +828,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         HIP_TRY(h, hipEventRecord(h->flags_ev, s));
         h->flags_pending = true;
         h->prev_dense = dense;
+        h->prev_generic = dense_generic;
         h->prev_fix_mode = cur_fix_mode;
         h->prev_env_y = env_y && !fused;
         h->prev_env_x = env_x;
@@ -1433,6 +1473,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "fused_window") h->fused_h = value;
     else if (n == "plane16") h->plane16_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
+    else if (n == "dense_generic") h->dense_generic_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;
     else if (n == "envelope_dc") h->envelope_dc = value != 0;
     else if (n == "dc_debug") h->dc_debug = value;

@@ -525,4 +525,145 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Generic forms of K0 / KD for the shapes the tuned kernels above do not take (round 2): any nz (rows are padded
+// to whole 32-bit words: nzw = ceil(nz / 32), the bits past the row end replicate the row's last voxel) and
+// add_virtual_border.  Same algorithm, same exactness contract (a voxel without a hit raises *uncertified), no
+// power-of-two index arithmetic and no LDS tile: a lane owns one word and reads the 25 x 3 neighbour words of the
+// ball straight from the (L2-resident) bit field.  These are the reference's own grid shapes -- 100 x 100 x 50
+// (src/compute_convex_segments_test.cpp:13-41), 40^3 (src/sdf_tools_tutorial.cpp:23-59), 25 x 20 x 15
+// (scripts/3d_sdf_demo_rviz.py:107-111) -- and every add_virtual_border = true call (sdf_generation.hpp:287-419).
+//
+// Virtual border inside the ball: the padded layer is at axis distance b = min over axes with n > 1 of
+// min(i + 1, n - i); D <- min(D, b^2) only binds for b^2 in {1, 4} (9 > 8), i.e. level 0 for the outermost layer
+// of voxels and level 3 for the second one; a voxel with b <= 2 is therefore always certified.
+// ---------------------------------------------------------------------------------------------
+template <class Loader>
+__global__ __launch_bounds__(kBlock) void k_pack_bits_rows(Loader ld, uint32_t* __restrict__ bits, int64_t nrows, int nz, int nzw) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;       // word index
+    if (i >= nrows * nzw) return;
+    const int64_t row = i / nzw;
+    const int w = (int)(i - row * nzw);
+    const int z0 = 32 * w, nv = min(32, nz - z0);
+    uint32_t word = 0;
+    bool last = false;
+    for (int k = 0; k < nv; ++k) {
+        last = ld.filled(row * nz + z0 + k);
+        word |= (last ? 1u : 0u) << k;
+    }
+    if (nv < 32 && last) word |= ~0u << nv;                             // replicate the row's last voxel
+    bits[i] = word;
+}
+
+struct DenseGenArgs {
+    const uint32_t* bits;   // [nx][ny][nzw]
+    float* out;             // [nx][ny][nz]
+    int nx, ny, nz, nzw;
+    int vb;
+    float mag[8];           // level magnitudes as in DenseArgs
+    uint32_t* slots;
+    uint32_t* uncertified;
+};
+
+__global__ __launch_bounds__(kBlock) void k_ball_dense_generic(const DenseGenArgs a) {
+    __shared__ float lut[16];                                           // [class << 3 | level] -> signed magnitude
+    if (threadIdx.x < 16) {
+        const int l = threadIdx.x & 7;
+        float m = a.mag[0];
+        m = l == 1 ? a.mag[1] : m; m = l == 2 ? a.mag[2] : m; m = l == 3 ? a.mag[3] : m;
+        m = l == 4 ? a.mag[4] : m; m = l == 5 ? a.mag[5] : m; m = l == 6 ? a.mag[6] : m;
+        m = l == 7 ? 0.0f : m;
+        lut[threadIdx.x] = (threadIdx.x & 8) ? -m : m;
+    }
+    __syncthreads();
+    const int64_t nwords = (int64_t)a.nx * a.ny * a.nzw;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < nwords;
+    const int64_t ii = live ? i : nwords - 1;
+    const int64_t row = ii / a.nzw;
+    const int w = (int)(ii - row * a.nzw);
+    const int x = (int)(row / a.ny), y = (int)(row - (int64_t)x * a.ny);
+    const uint32_t* rowp = a.bits + row * a.nzw;
+    const uint32_t O = rowp[w];
+    uint32_t acc[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int dx = -kBallR; dx <= kBallR; ++dx) {
+#pragma unroll
+        for (int dy = -kBallR; dy <= kBallR; ++dy) {
+            const int gx = min(max(x + dx, 0), a.nx - 1), gy = min(max(y + dy, 0), a.ny - 1);
+            const uint32_t* p = a.bits + ((int64_t)gx * a.ny + gy) * a.nzw;
+            const uint32_t cur = p[w];
+            const uint32_t prev = w > 0 ? p[w - 1] : ((cur & 1u) ? ~0u : 0u);                 // replicate the first voxel
+            const uint32_t next = w + 1 < a.nzw ? p[w + 1] : ((cur >> 31) ? ~0u : 0u);       // ... and the (replicated) last bit
+#pragma unroll
+            for (int dz = -kBallR; dz <= kBallR; ++dz) {
+                const int d2 = dx * dx + dy * dy + dz * dz;
+                const int lv = ball_level(d2);
+                if (lv < 0) continue;
+                const uint32_t S = dz == 0 ? cur
+                                 : dz > 0 ? __builtin_amdgcn_alignbit(next, cur, dz)
+                                          : __builtin_amdgcn_alignbit(cur, prev, 32 + dz);
+                acc[lv] |= O ^ S;
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 1; l < 7; ++l) acc[l] |= acc[l - 1];                   // cumulative: found at level <= l
+    const int z0 = 32 * w, nv = min(32, a.nz - z0);
+    const uint32_t valid = nv >= 32 ? ~0u : ((1u << nv) - 1u);
+    if (a.vb) {
+        // voxels with b == 1 are found at level 0, with b == 2 at level 3 (D <- min(D, b^2))
+        int bxy = 1 << 20;
+        if (a.nx > 1) bxy = min(bxy, min(x + 1, a.nx - x));
+        if (a.ny > 1) bxy = min(bxy, min(y + 1, a.ny - y));
+        uint32_t b1 = bxy == 1 ? ~0u : 0u, b2 = bxy <= 2 ? ~0u : 0u;
+        if (a.nz > 1) {
+            // bits of this word whose z distance to the padded layer is 1 / <= 2
+            uint32_t z1 = 0u, z2 = 0u;
+            for (int k = 0; k < nv; ++k) {
+                const int z = z0 + k, bz = min(z + 1, a.nz - z);
+                z1 |= (bz == 1 ? 1u : 0u) << k;
+                z2 |= (bz <= 2 ? 1u : 0u) << k;
+            }
+            b1 |= z1; b2 |= z2;
+        }
+        acc[0] |= b1; acc[1] |= b1; acc[2] |= b1;
+        acc[3] |= b2 | b1; acc[4] |= b2 | b1; acc[5] |= b2 | b1; acc[6] |= b2 | b1;
+    }
+    int mxF = 0, mxQ = 0;
+    {
+        uint32_t prevc = 0u;
+#pragma unroll
+        for (int l = 0; l < 7; ++l) {
+            const uint32_t first = acc[l] & ~prevc & valid;
+            if (first & ~O) mxF = kLevelD2[l];
+            if (first & O) mxQ = kLevelD2[l];
+            prevc = acc[l];
+        }
+    }
+    const bool uncert = live && ((~acc[6] & valid) != 0u);
+    if (!live) { mxF = 0; mxQ = 0; }
+    if (live) {
+        // level index = number of levels a voxel was NOT found at (7 = not found: +-0, rewritten by the general pipeline)
+        float* dst = a.out + row * a.nz + z0;
+        for (int k = 0; k < nv; ++k) {
+            int lvl = 0;
+#pragma unroll
+            for (int l = 0; l < 7; ++l) lvl += ((acc[l] >> k) & 1u) ? 0 : 1;
+            dst[k] = lut[(((O >> k) & 1u) << 3) | (uint32_t)lvl];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mxF = max(mxF, __shfl_xor(mxF, off));
+        mxQ = max(mxQ, __shfl_xor(mxQ, off));
+    }
+    const bool any_uncert = __any(uncert);
+    if ((threadIdx.x & 63) == 0) {
+        slot_max2(a.slots, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), mxF, mxQ);
+        if (any_uncert) raise_flag(a.uncertified);
+    }
+}
+
 }  // namespace sdfgpu

@@ -38,11 +38,17 @@ def test_dense_random_occupancy_is_certified_and_exact(gpu, shape):
     dims = [s for s in shape if s > 1] or [1]
     nz = dims[-1]
     nzw = nz // 32
-    eligible = nz % 32 == 0 and (nzw & (nzw - 1)) == 0 and nzw <= 64
+    tuned = nz % 32 == 0 and (nzw & (nzw - 1)) == 0 and nzw <= 64
     info, cert = _check(gpu, m, 0.01)
-    assert info["dense"] == eligible
-    if eligible and m.size >= 32 * 32:
+    assert info["dense"]                               # tuned kernels, or their generic forms for the other shapes
+    if m.size >= 32 * 32:
         assert cert                                    # D <= 8 everywhere at p = 0.5
+    gpu.set_option("dense_generic", 0)                 # without the generic forms only the tuned shapes are dense
+    try:
+        info2, _ = _check(gpu, m, 0.01)
+        assert info2["dense"] == tuned
+    finally:
+        gpu.set_option("dense_generic", 1)
     ref, ref_ext = O.reference_sdf(m, 0.01)
     sdf, ext = gpu.build(m, 0.01)
     assert np.array_equal(sdf, ref) and ext == ref_ext     # the reference algorithm, bit for bit
@@ -109,12 +115,52 @@ def test_collision_cells_take_the_dense_path(gpu):
         assert np.array_equal(got, want) and ext == want_ext
 
 
-def test_virtual_border_skips_the_dense_path(gpu):
-    m = synth.bernoulli_mask((8, 8, 32), 0.5, 1)
-    sdf, ext = gpu.build(m, 1.0, True)
-    assert not gpu.last_build_info()["dense"]
-    ex, ex_ext, _ = O.exact_sdf(m, 1.0, True)
-    assert np.array_equal(sdf, ex) and ext == ex_ext
+def test_virtual_border_takes_the_generic_dense_kernel(gpu):
+    """add_virtual_border (sdf_generation.hpp:287-419) folds into the ball: b^2 = 1 and 4 are levels 0 and 3."""
+    for shape in ((8, 8, 32), (64, 64, 64), (20, 17, 45), (1, 30, 70)):
+        m = synth.bernoulli_mask(shape, 0.5, 1)
+        sdf, ext = gpu.build(m, 1.0, True)
+        assert gpu.last_build_info()["dense"] and gpu.last_dense_certified()
+        ex, ex_ext, _ = O.exact_sdf(m, 1.0, True)
+        assert np.array_equal(sdf, ex) and ext == ex_ext
+        ref, ref_ext = O.reference_sdf(m, 1.0, True)       # the reference's pad-twice-and-combine, bit for bit
+        assert np.array_equal(sdf, ref) and ext == ref_ext
+    # one class only + virtual border: voxels deeper than 2 layers are not decided by the ball -> general pipeline
+    for fill in (0, 1):
+        m = np.full((12, 10, 40), fill, np.uint8)
+        sdf, ext = gpu.build(m, 0.5, True)
+        ex, ex_ext, _ = O.exact_sdf(m, 0.5, True)
+        assert np.array_equal(sdf, ex) and ext == ex_ext and not gpu.last_dense_certified()
+
+
+REF_SHAPES = [(100, 100, 50), (40, 40, 40), (25, 20, 15), (20, 40, 1), (7, 9, 33), (5, 5, 95), (3, 70, 31)]
+
+
+@pytest.mark.parametrize("shape", REF_SHAPES, ids=["x".join(map(str, s)) for s in REF_SHAPES])
+def test_reference_grid_shapes_take_the_dense_tier(gpu, shape):
+    """the reference's own grid shapes (100x100x50 compute_convex_segments_test.cpp:13-41, 40^3
+    sdf_tools_tutorial.cpp:23-59, 25x20x15 3d_sdf_demo_rviz.py:107-111, 20x40x1 test_bindings.py:11-20) are dense-tier
+    shapes now: certified where every voxel has D <= 8, exact (general pipeline behind the guard) otherwise."""
+    for p, vb in ((0.5, False), (0.5, True), (0.2, False), (0.02, True)):
+        m = synth.bernoulli_mask(shape, p, 11)
+        sdf, ext = gpu.build(m, 0.05, vb)
+        assert gpu.last_build_info()["dense"]
+        ex, ex_ext, dsq = O.exact_sdf(m, 0.05, vb)
+        bad = np.argwhere(sdf.view(np.uint32) != ex.view(np.uint32))
+        assert len(bad) == 0, (shape, p, vb, len(bad), bad[:3].tolist())
+        assert ext == ex_ext
+        assert gpu.last_dense_certified() == bool(np.abs(dsq).max() <= 8)
+    # the reference's scenes themselves (walls 10 cells thick / a half-filled cube: D > 8, so the sweeps finish them)
+    if shape == (100, 100, 50):
+        m, res = scenes.convex_segments_scene()
+    elif shape == (40, 40, 40):
+        m, res = scenes.tutorial_scene()
+    else:
+        return
+    sdf, ext = gpu.build(m, res)
+    ref, ref_ext = O.reference_sdf(m, res)
+    ex, ex_ext, _ = O.exact_sdf(m, res)
+    assert np.array_equal(sdf, ex) and ext == ex_ext and not gpu.last_dense_certified()
 
 
 def test_dense_retry_policy_skips_and_retries(gpu):

@@ -30,7 +30,7 @@ def test_multi_matches_exact_on_every_tier(world):
             ("mid", synth.bernoulli_mask(shape, 0.06, 2), False, dict(dense_certified=False)),
             ("far", _boxes(shape), False, dict(dense_certified=False, whole_lines=True)),
             ("far vb", _boxes(shape), True, dict(whole_lines=True)),
-            ("dense vb", synth.bernoulli_mask(shape, 0.5, 3), True, dict(dense_certified=False)),
+            ("dense vb", synth.bernoulli_mask(shape, 0.5, 3), True, dict(dense_certified=False)),   # (slabs: no vb dense tier)
             ("empty", np.zeros(shape, np.uint8), False, dict(whole_lines=True)),
             ("odd shape", synth.bernoulli_mask((29, 18, 20), 0.02, 4), True, {}),
         ]
