@@ -314,8 +314,9 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * generic forms, default; 0 = such shapes skip the dense tier), "envelope_dc" (1 = divide-and-conquer envelope kernel
  * where the shape allows, default; 0 = first-generation stack kernel), "tier_select" (1 = choose marching vs
  * envelope sweep per axis on the device inside each build from a probe of the sweep's input, default; 0 = learn
- * it from the previous build on the handle), "far_threshold" / "far_fraction_den" (an axis counts as far-field
- * when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 64 and 8). */
+ * it from the previous build on the handle), "far_threshold_y" / "far_fraction_den_y" and "..._x" (an axis counts as
+ * far-field when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 64, 8 for the
+ * y sweep and 25, 16 for the x sweep). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),

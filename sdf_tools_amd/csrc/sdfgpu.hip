@@ -72,6 +72,9 @@ struct sdfgpu_context {
     int fix_clean = 0;            // consecutive fix-mode builds that needed no fix (the mode is left after 8)
     int dense_retry = 16;         // after an uncertified dense attempt, try the dense kernels again every N-th build (0 = always)
     int dense_skip = 0;           // builds left that skip the dense kernels
+    int dense_backoff = 0;        // current length of that pause: doubles while the attempts keep failing (a caller that
+                                  // enqueues builds without synchronising feeds the policy ~30 builds late, so a fixed
+                                  // pause of dense_retry builds would leave the dense kernels in most of its builds)
     int defer_fold = 0;           // stage entry points leave their maxima in the slot array until sdfgpu_fold_extrema_device
     int ball_variant = 0;         // debugging: bit0 = bounds-checked expansion, bit1 = generic (non-ZINV) expansion
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
@@ -80,8 +83,12 @@ struct sdfgpu_context {
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool tier_select = true;         // pick marching vs envelope sweep per axis on the device, inside the build (probe + decide)
     int force_env = -1;              // -1 automatic, 1 = envelope kernels only (option "envelope_mode")
-    int far_num = 1, far_den = 8;    // an axis is far-field when more than num / den of the probed voxels have d^2 >= far_thr
-    int far_thr = 64;
+    // an axis is far-field when more than 1 / den of the probed voxels have d^2 >= thr.  Per axis, from the measured
+    // break-even of the two sweeps at 512^3 (tools/p_sweep.py): the y marching sweep (2 B rows, radius-8 windows) holds up to
+    // in-plane d^2 ~ 64 on an eighth of the voxels; the x marching sweep falls behind the far-field kernel much earlier
+    // (Bernoulli p = 0.003: 1.70 ms against ~0.9 ms), so its threshold is d^2 >= 25 on a sixteenth of the voxels
+    int far_thr[2] = {64, 25};
+    int far_den[2] = {8, 16};
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
@@ -405,7 +412,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
         if (probe_out) {                                        // sample ~256 tiles spread over the grid, store nothing
             a.probe_stride = (int)std::max<int64_t>(1, std::min<int64_t>(64, ntiles / 256));
-            a.probe_thr = h->far_thr;
+            a.probe_thr = h->far_thr[stage - 2];
             a.probe_out = probe_out;
             ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
             // the sampled tile index b * stride + (7 b mod stride) must stay inside the grid: drop the last block if needed
@@ -443,7 +450,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
 
 int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s) {
     hipLaunchKernelGGL(k_decide_tier, dim3(1), dim3(1), 0, s, h->d_small, stage, dense_tried ? 1 : 0, h->force_env,
-                       h->far_num, h->far_den);
+                       1, h->far_den[stage]);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -635,8 +642,11 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                 if (h->fix_clean >= 8) { h->fix_mode = false; h->fix_clean = 0; }  // edge of the ball must not flap)
             }
         }
-        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on || h->prev_generic))
-            h->dense_skip = h->dense_retry - 1;
+        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on || h->prev_generic)) {
+            h->dense_backoff = h->dense_backoff ? std::min(255, 2 * h->dense_backoff + 1) : h->dense_retry - 1;
+            h->dense_skip = h->dense_backoff;
+        }
+        if (h->prev_dense && h->h_flags[3] == 0) h->dense_backoff = 0;        // certified again: start over
         //   mid-sparse scenes (largest squared distance beyond the radius-3 window's 16): radius-8 register windows
         //   decide most voxels without the outward scan (measured at 512^3: y sweep 0.96 -> 0.53 ms at p = 0.02,
         //   x sweep 1.22 -> 0.60 ms at p = 0.01; the wider x window only pays from a largest squared distance of ~32 upward:
@@ -1482,14 +1492,16 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
     else if (n == "ball_variant") h->ball_variant = value;
-    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; h->fix_mode = false; h->wide_y = h->wide_x = false; }
+    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; h->dense_backoff = 0; h->fix_mode = false; h->wide_y = h->wide_x = false; }
     else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; }
     else if (n == "fixup_mode") h->fix_mode = value != 0;
-    else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; }
+    else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; h->dense_backoff = 0; }
     else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; h->force_env = value != 0 ? 1 : -1; }
     else if (n == "tier_select") h->tier_select = value != 0;
-    else if (n == "far_threshold") h->far_thr = value;
-    else if (n == "far_fraction_den") h->far_den = value > 0 ? value : 8;
+    else if (n == "far_threshold_y") h->far_thr[0] = value;
+    else if (n == "far_threshold_x") h->far_thr[1] = value;
+    else if (n == "far_fraction_den_y") h->far_den[0] = value > 0 ? value : 8;
+    else if (n == "far_fraction_den_x") h->far_den[1] = value > 0 ? value : 16;
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;

@@ -183,6 +183,15 @@ def test_dense_retry_policy_skips_and_retries(gpu):
         used.append(gpu.last_build_info()["dense"])
     assert used == [False, False, False, True, True, True, True, True]
     assert gpu.last_dense_certified()
+    # a scene that stays sparse: the pause doubles after every failed retry (3, 7, 15 builds), results stay exact
+    gpu.set_option("policy_reset", 1)
+    gpu.set_option("dense_retry", 4)
+    used = []
+    for _ in range(2 + 3 + 2 + 7 + 2 + 15 + 1):
+        sdf, ext = gpu.build(sparse, 0.1)
+        assert np.array_equal(sdf, ex_s) and ext == ext_s
+        used.append(int(gpu.last_build_info()["dense"]))
+    assert used == [1, 1] + [0] * 3 + [1, 1] + [0] * 7 + [1, 1] + [0] * 15 + [1]
     gpu.set_option("dense_retry", 0)
 
 
