@@ -181,7 +181,7 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
     const int64_t nrows = nx * ny;
     const int rpb = rows_per_block((int)nz);
     const int W = ((int)nz + 63) / 64;
-    const size_t lds = (size_t)rpb * W * 8;
+    const size_t lds = (size_t)rpb * W * 8 + (size_t)rpb * 4;     // bitmap + one class word per row (vec16 kernel)
     const int64_t nblocks = (nrows + rpb - 1) / rpb;
     // persistent row-group loop inside the kernel: 8 workgroups per CU are plenty, and a small grid
     // makes the guard early-exit (dense path certified) a ~2 us launch instead of ~10 us
@@ -1347,8 +1347,13 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
         hipLaunchKernelGGL(k_gradient<double>, grid, block, 0, s, d_sdf, (double*)d_out_grad, nx, ny, nz, resolution,
                            enable_edge_gradients);
     else if ((nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_sdf) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out_grad) % 16) == 0)
-        hipLaunchKernelGGL(k_gradient_f32x4, dim3((unsigned)((n / 4 + kBlock - 1) / kBlock)), block, 0, s, d_sdf,
-                           (float*)d_out_grad, nx, ny, nz, resolution, enable_edge_gradients);
+    {
+        const double inv2 = 1.0 / (2.0 * resolution);
+        const bool f32scale = (double)(float)inv2 == inv2 && std::isfinite(inv2) && std::fabs(inv2) < 1e30 && std::fabs(inv2) > 1e-30;
+        const dim3 g4((unsigned)((n / 4 + kBlock - 1) / kBlock));
+        if (f32scale) hipLaunchKernelGGL(k_gradient_f32x4<true>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution, enable_edge_gradients);
+        else hipLaunchKernelGGL(k_gradient_f32x4<false>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution, enable_edge_gradients);
+    }
     else
         hipLaunchKernelGGL(k_gradient<float>, grid, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution,
                            enable_edge_gradients);

@@ -188,12 +188,15 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
     uint64_t* bm = reinterpret_cast<uint64_t*>(smem_raw);
     uint16_t* bm16 = reinterpret_cast<uint16_t*>(smem_raw);
     const int W = (nz + 63) >> 6;
+    uint32_t* rowcls = reinterpret_cast<uint32_t*>(bm + (size_t)rpb * W);   // [rpb] behind the bitmap
     const int cpr = nz >> 4;                       // 16-voxel chunks per row
     const int spr = W * 4;                         // uint16 slots per row in the bitmap
     // persistent loop over row groups: a small grid keeps the guard early-exit cheap
     for (int64_t row0 = (int64_t)blockIdx.x * rpb; row0 < nrows; row0 += (int64_t)gridDim.x * rpb) {
     const int nr = (int)min((int64_t)rpb, nrows - row0);
-    // phase A: pack
+    // phase A: pack; per row: does it hold any filled (bit 0) / any free (bit 1) voxel?
+    for (int s = threadIdx.x; s < nr; s += kBlock) rowcls[s] = 0u;
+    __syncthreads();
     for (int s = threadIdx.x; s < nr * spr; s += kBlock) {
         const int r = s / spr, c = s - r * spr;
         uint32_t bits = 0;
@@ -201,6 +204,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
             const uint4 v = *reinterpret_cast<const uint4*>(mask + (row0 + r) * nz + 16 * c);
             bits = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) |
                    (nonzero_bits4(v.w) << 12);
+            const uint32_t cls = (bits != 0u ? 1u : 0u) | (bits != 0xFFFFu ? 2u : 0u);
+            if ((rowcls[r] & cls) != cls) atomicOr(&rowcls[r], cls);
         }
         bm16[s] = (uint16_t)bits;
     }
@@ -210,6 +215,15 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
         const int r = s / cpr, c = s - r * cpr;
         const uint64_t* row = bm + r * W;
         const int w = c >> 2, sub = c & 3;
+        // a row of one class only (most rows of a scene with a few objects in free space): every voxel is "none"
+        const uint32_t rc = rowcls[r];
+        if (rc != 3u) {
+            const uint32_t v = rc == 2u ? 0x7fff7fffu : 0x80018001u;       // +32767 (all free) / -32767 (all filled)
+            uint4* dst = reinterpret_cast<uint4*>(out + (row0 + r) * nz + 16 * c);
+            dst[0] = make_uint4(v, v, v, v);
+            dst[1] = make_uint4(v, v, v, v);
+            continue;
+        }
         const uint64_t word = row[w];
         const uint64_t vm = valid_mask(w, nz);
         const int LF = far_left(row, w, true), LE = far_left(row, w, false);
@@ -679,6 +693,11 @@ __device__ __forceinline__ void gradient_one(const float* __restrict__ f, int64_
     g[0] = (float)gx; g[1] = (float)gy; g[2] = (float)gz;
 }
 
+// F32SCALE: 1 / (2 res) is exactly representable in fp32 (res = 0.01, 0.02, 0.05, 0.1, 0.25, 1 ...): the product of the
+// fp32 difference with it has at most 48 significant bits, so the reference's double multiply is exact and its narrowing
+// to float is ONE rounding of the exact product -- which is what the fp32 multiply computes.  Same bits, a third of the
+// instructions (no conversions, no fp64 multiply).
+template <bool F32SCALE>
 __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restrict__ f, float* __restrict__ g,
                                                           int64_t nx, int64_t ny, int64_t nz, double res, int edge) {
     // A lane's 4 voxels give 12 consecutive floats (48 B).  Written straight from the lane, every store
@@ -686,6 +705,7 @@ __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restri
     // therefore transposed through LDS so that each of the 3 store instructions writes one contiguous 1 KiB.
     __shared__ __attribute__((aligned(16))) float stage[(kBlock / 64) * 64 * 12];
     const int64_t n4 = nx * ny * nz / 4;
+    // (tried in round 2, no gain at 512^3 -- 0.64 ms either way: an XCD-contiguous workgroup order and non-temporal stores)
     const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     float* st = stage + (threadIdx.x >> 6) * (64 * 12);
@@ -703,11 +723,21 @@ __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restri
             const float cz[6] = {zm, c.x, c.y, c.z, c.w, zp};
             const float xpv[4] = {xp.x, xp.y, xp.z, xp.w}, xmv[4] = {xm.x, xm.y, xm.z, xm.w};
             const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
+            if constexpr (F32SCALE) {
+                const float inv2f = (float)inv2;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                o[3 * k + 0] = (float)((double)(xpv[k] - xmv[k]) * inv2);
-                o[3 * k + 1] = (float)((double)(ypv[k] - ymv[k]) * inv2);
-                o[3 * k + 2] = (float)((double)(cz[k + 2] - cz[k]) * inv2);
+                for (int k = 0; k < 4; ++k) {
+                    o[3 * k + 0] = (xpv[k] - xmv[k]) * inv2f;
+                    o[3 * k + 1] = (ypv[k] - ymv[k]) * inv2f;
+                    o[3 * k + 2] = (cz[k + 2] - cz[k]) * inv2f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    o[3 * k + 0] = (float)((double)(xpv[k] - xmv[k]) * inv2);
+                    o[3 * k + 1] = (float)((double)(ypv[k] - ymv[k]) * inv2);
+                    o[3 * k + 2] = (float)((double)(cz[k + 2] - cz[k]) * inv2);
+                }
             }
         } else {
 #pragma unroll

@@ -259,16 +259,18 @@ def test_gradient_matches_reference_definition(gpu):
     assert np.array_equal(got2[1:-1, 1:-1, 1:-1], want[1:-1, 1:-1, 1:-1])
     assert np.all(np.isnan(got2[0])) and np.all(np.isnan(got2[:, :, -1]))
     # fp32 output (vectorised kernel when nz % 4 == 0) == fp64 output narrowed once
-    for shp in ((10, 9, 16), (3, 5, 8), (12, 9, 10), (1, 7, 12)):
+    # (res = 0.25, 0.01: 1 / (2 res) is an fp32 number -> the kernel scales in fp32; 0.03, 0.007: fp64 scale)
+    for shp in ((10, 9, 16), (3, 5, 8), (12, 9, 10), (1, 7, 12), (40, 33, 64)):
         mm = synth.bernoulli_mask(shp, 0.3, 4)
-        ss, _ = gpu.build(mm, res)
-        ft = torch.from_numpy(ss).cuda()
-        for edge in (True, False):
-            g64 = torch.empty(shp + (3,), dtype=torch.float64, device="cuda")
-            g32 = torch.empty(shp + (3,), dtype=torch.float32, device="cuda")
-            gpu.gradient_device(ft.data_ptr(), shp, g64.data_ptr(), res, edge, True)
-            gpu.gradient_device(ft.data_ptr(), shp, g32.data_ptr(), res, edge, False)
-            assert np.array_equal(g32.cpu().numpy(), g64.cpu().numpy().astype(np.float32), equal_nan=True), (shp, edge)
+        for r2 in (res, 0.01, 0.03, 0.007):
+            ss, _ = gpu.build(mm, r2)
+            ft = torch.from_numpy(ss).cuda()
+            for edge in (True, False):
+                g64 = torch.empty(shp + (3,), dtype=torch.float64, device="cuda")
+                g32 = torch.empty(shp + (3,), dtype=torch.float32, device="cuda")
+                gpu.gradient_device(ft.data_ptr(), shp, g64.data_ptr(), r2, edge, True)
+                gpu.gradient_device(ft.data_ptr(), shp, g32.data_ptr(), r2, edge, False)
+                assert np.array_equal(g32.cpu().numpy(), g64.cpu().numpy().astype(np.float32), equal_nan=True), (shp, r2, edge)
     # test_bindings.py:33 -- gradient at (x=4, y=1) of the 20x40x1 scene is [1.5, 0]
     m2 = np.zeros((20, 40, 1), np.uint8)
     m2[3, 1, 0] = 1
