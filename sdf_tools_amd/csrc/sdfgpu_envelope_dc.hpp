@@ -40,7 +40,7 @@ namespace sdfgpu {
 
 constexpr int kDcLines = 16;          // lines per tile
 constexpr int kDcChunk = 8;           // positions per lane in the chunk phase
-constexpr int kDcBatch = 8;           // staging: row loads in flight per lane
+constexpr int kDcBatch = 2;           // staging: row loads in flight per lane (register budget: 128 VGPRs at 4 waves per SIMD)
 constexpr int kDcBrute = 24;          // chunk phase: candidate ranges below this are searched exhaustively
 constexpr int kDcLocalMax = 64;       // pass 0 finishes filled voxels whose in-row squared distance is at most this ...
 constexpr int kDcLocalFilled = 96;    // ... when the tile holds at most this many filled voxels (of 16 x L)
@@ -75,6 +75,23 @@ struct EnvDcArgs {
     int dbg;                  // profiling aid (wrong results!): bit0 skip upper levels, bit1 skip chunk search, bit2 skip stores,
                               // bit3 skip the second class, bit4 skip key conversion
 };
+
+// Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
+// emits for sqrt(double) (rsq seed, one coupled iteration, two residual corrections), without its input scaling for
+// arguments below 2^-767 and its zero / infinity selects -- the argument here is an integer in [1, 2^30).  Same
+// operations in the same order, so the same bits; 10 instructions instead of ~20 per voxel.
+__device__ __forceinline__ double sqrt_exact_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y;
+    const double h0 = y * 0.5;
+    const double r0 = __builtin_fma(-h0, s0, 0.5);
+    const double s1 = __builtin_fma(s0, r0, s0);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-s1, s1, x);
+    const double s2 = __builtin_fma(d0, h1, s1);
+    const double d1 = __builtin_fma(-s2, s2, x);
+    return __builtin_fma(d1, h1, s2);
+}
 
 inline size_t envelope_dc_lds_bytes(int L, int pitch) {
     const int SW = (L + 31) / 32, M = (L + kDcChunk - 1) / kDcChunk;
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                 if (b < 32768) D = min(D, b * b);
             }
             if (filled) mxQ = max(mxQ, D); else mxF = max(mxF, D);
-            const float f = (D >= kInf32) ? __builtin_inff() : (float)(sqrt((double)D) * a.resolution);
+            const float f = (D >= kInf32) ? __builtin_inff() : (float)(sqrt_exact_pos((double)D) * a.resolution);
             (reinterpret_cast<float*>(a.out) + base)[oi] = filled ? -f : f;
         }
     };
@@ -188,135 +205,109 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
 #pragma unroll 1
     for (int cls = 0; cls < 2; ++cls) {         // 0: sites of "distance to filled" (for free voxels); 1: the reverse
         if (cls == 0 && t == 0) { flg[16] = 0u; flg[17] = 0u; flg[18] = 0u; flg[19] = 0u; }   // (ordered before their users by the barriers of pass 0)
-        // ---- stage the tile ----------------------------------------------------------------------------------------------
-        // step 1: rows -> LDS, the exact signed value of every voxel parked in its key slot.  Nothing but loads and LDS
-        //         writes, a batch of independent row loads in flight per lane (a lane reads 4 lines x 1 position = 8 B; STAGE 3
-        //         adds the 16-B side-table group where the 16-bit value is saturated).
-        // step 2: slots -> keys in place, lane = (line, 16 consecutive positions per step): sign bits by ballot, first / last
-        //         site by a 16-lane reduction, no atomics.
+        // ---- stage the tile: rows -> keys, one pass ----------------------------------------------------------------------
+        // A lane reads 4 lines x 1 position (8 B; STAGE 3 adds the 16-B side-table group where the 16-bit value is
+        // saturated, or reads 16 B of an int32 plane field), kDcBatch independent row loads in flight, and writes the four
+        // keys straight to LDS.  Filled voxels are rare in the scenes this kernel serves: their sign bits go to the bit
+        // array with an LDS atomic each.  First / last site of a line: a bit per (line, iteration) in registers, two LDS
+        // atomics per lane at the end.
         if (cls == 1 && ((a.dbg & 8) || probe)) break;
         // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose
         // in-row squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can
         // only matter while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises flg[17] for the rest.
         if (cls == 1 && flg[17] == 0u) break;   // (block-uniform)
-        {
-            const int sub = t & 3, r = t >> 2;
-            int32_t* slots = reinterpret_cast<int32_t*>(keys);
-            if (STAGE == 3 && in32) {                           // int32 plane field: 4 lines x 1 position = one 16-B load
-                for (int pb = 0; pb < L; pb += 64 * kDcBatch) {
-                    int4 rw4[kDcBatch];
-#pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = min(pb + 64 * it + r, L - 1);
-                        rw4[it] = *reinterpret_cast<const int4*>(in32 + ((uint32_t)p * ls + 4u * sub));
-                    }
-#pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = pb + 64 * it + r;
-                        if (p < L) {
-                            int32_t* d = slots + (4 * sub) * pitch + p;
-                            d[0] = rw4[it].x; d[pitch] = rw4[it].y; d[2 * pitch] = rw4[it].z; d[3 * pitch] = rw4[it].w;
-                        }
-                    }
-                }
-            } else
-            for (int pb = 0; pb < L; pb += 64 * kDcBatch) {
-                uint2 raw[kDcBatch];
-#pragma unroll
-                for (int it = 0; it < kDcBatch; ++it) {
-                    const int p = min(pb + 64 * it + r, L - 1);
-                    raw[it] = *reinterpret_cast<const uint2*>(in16 + ((uint32_t)p * ls + 4u * sub));
-                }
-                if constexpr (STAGE == 3) {
-                    int4 ex[kDcBatch];
-                    uint32_t satm = 0u;
-#pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = min(pb + 64 * it + r, L - 1);
-                        // |v| >= 32767 for a 16-bit lane: v == 32767 or v == -32767 (-32768 is never stored)
-                        const uint32_t x = raw[it].x, y = raw[it].y;
-                        const bool sat = ((x & 0xffffu) == 0x7fffu) | ((x & 0xffffu) == 0x8001u) | ((x >> 16) == 0x7fffu) | ((x >> 16) == 0x8001u) |
-                                         ((y & 0xffffu) == 0x7fffu) | ((y & 0xffffu) == 0x8001u) | ((y >> 16) == 0x7fffu) | ((y >> 16) == 0x8001u);
-                        if (sat) { ex[it] = *reinterpret_cast<const int4*>(side_in + ((uint32_t)p * ls + 4u * sub)); satm |= 1u << it; }
-                    }
-#pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = pb + 64 * it + r;
-                        if (p < L) {
-                            const bool sat = (satm >> it) & 1u;
-                            int32_t* d = slots + (4 * sub) * pitch + p;
-                            d[0] = sat ? ex[it].x : (int)(short)(raw[it].x & 0xffffu);
-                            d[pitch] = sat ? ex[it].y : (int)(short)(raw[it].x >> 16);
-                            d[2 * pitch] = sat ? ex[it].z : (int)(short)(raw[it].y & 0xffffu);
-                            d[3 * pitch] = sat ? ex[it].w : (int)(short)(raw[it].y >> 16);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = pb + 64 * it + r;
-                        if (p < L) {
-                            int32_t* d = slots + (4 * sub) * pitch + p;
-                            d[0] = (int)(short)(raw[it].x & 0xffffu);
-                            d[pitch] = (int)(short)(raw[it].x >> 16);
-                            d[2 * pitch] = (int)(short)(raw[it].y & 0xffffu);
-                            d[3 * pitch] = (int)(short)(raw[it].y >> 16);
-                        }
-                    }
-                }
-            }
-        }
+        if (cls == 0) for (int i = t; i < kDcLines * SW; i += 256) sgn[i] = 0u;
+        if (t < 16) { span[2 * t] = 0xFFFFFFFFu; span[2 * t + 1] = 0u; }
         __syncthreads();
         {
-            const int lineU = t >> 4, g = t & 15;
-            uint32_t* kl = keys + lineU * pitch;
-            uint16_t* sg = reinterpret_cast<uint16_t*>(sgn) + lineU * (2 * SW);      // 16 positions per half-word
-            uint32_t mn = 0xFFFFFFFFu, mx = 0u, nfilled = 0u;
-            bool anyf = false;
-            for (int p0 = 0; p0 < ((a.dbg & 16) ? 16 : L); p0 += 16) {
-                const int p = p0 + g;
-                const bool inl = p < L;
-                int sv = inl ? (int)kl[p] : 1;
-                if constexpr (STAGE == 2) {
-                    const int gz = abs(sv);
-                    const int sq = gz >= kInf16 ? kInf32 : gz * gz;
-                    sv = sv < 0 ? -sq : sq;
+            const int sub = t & 3, r = t >> 2;
+            uint32_t seen[4] = {0u, 0u, 0u, 0u};            // bit it: iteration `it` of this lane found a site on line 4 sub + k
+            uint32_t nfilled = 0u;
+            uint32_t* const kbase = keys + (4 * sub) * pitch + r;
+            for (int pb = 0, itb = 0; pb < L; pb += 64 * kDcBatch, itb += kDcBatch) {
+                int sv[kDcBatch][4];
+                if (STAGE == 3 && in32) {
+#pragma unroll
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        const int p = min(pb + 64 * it + r, L - 1);
+                        const int4 e = *reinterpret_cast<const int4*>(in32 + ((uint32_t)p * ls + 4u * sub));
+                        sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
+                    }
+                } else {
+                    uint2 raw[kDcBatch];
+#pragma unroll
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        const int p = min(pb + 64 * it + r, L - 1);
+                        raw[it] = *reinterpret_cast<const uint2*>(in16 + ((uint32_t)p * ls + 4u * sub));
+                    }
+#pragma unroll
+                    for (int it = 0; it < kDcBatch; ++it) {
+                        sv[it][0] = (int)(short)(raw[it].x & 0xffffu); sv[it][1] = (int)raw[it].x >> 16;
+                        sv[it][2] = (int)(short)(raw[it].y & 0xffffu); sv[it][3] = (int)raw[it].y >> 16;
+                    }
+                    if constexpr (STAGE == 3) {
+#pragma unroll
+                        for (int it = 0; it < kDcBatch; ++it) {
+                            // a 16-bit lane is saturated iff it holds +-32767 (-32768 is never stored): |v| + 1 has bit 15 set
+                            // per half: v >= 0 -> v, v < 0 -> ~v = |v| - 1; adding 1 (+ 1 more for the negative ones) gives |v| + 1
+                            const uint32_t n0 = (raw[it].x >> 15) & 0x00010001u, n1 = (raw[it].y >> 15) & 0x00010001u;
+                            const uint32_t m0 = (raw[it].x ^ (n0 * 0xFFFFu)) + 0x00010001u + n0;
+                            const uint32_t m1 = (raw[it].y ^ (n1 * 0xFFFFu)) + 0x00010001u + n1;
+                            const bool sat = ((m0 | m1) & 0x80008000u) != 0u;
+                            if (sat) {
+                                const int p = min(pb + 64 * it + r, L - 1);
+                                const int4 e = *reinterpret_cast<const int4*>(side_in + ((uint32_t)p * ls + 4u * sub));
+                                sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
+                            }
+                        }
+                    }
                 }
-                uint32_t F;
-                bool none;
-                if (cls == 0) {
-                    const uint64_t fb = __ballot(inl && sv < 0);
-                    const uint32_t bits = (uint32_t)(fb >> (16 * ((t >> 4) & 3))) & 0xFFFFu;
-                    if (g == 0) sg[p0 >> 4] = (uint16_t)bits;
-                    anyf |= bits != 0u;
-                    nfilled += __popc(bits);
-                    F = (uint32_t)max(sv, 0);
-                    none = sv >= kInf32;
-                } else if (sv < 0) {
-                    F = (uint32_t)(-sv);
-                    none = -sv >= kInf32;
-                } else {                        // free voxel: a zero-valued site only next to a filled voxel of its line
-                    F = 0u;
-                    bool nb = false;
-                    if (p > 0) nb |= (sg[(p - 1) >> 4] >> ((p - 1) & 15)) & 1u;
-                    if (p + 1 < L) nb |= (sg[(p + 1) >> 4] >> ((p + 1) & 15)) & 1u;
-                    none = !nb;
-                }
-                if (inl) {
-                    kl[p] = (((none ? finf : F) + __umul24((uint32_t)p, (uint32_t)p)) << B) | (uint32_t)p;
-                    if (!none) { mn = min(mn, (uint32_t)p); mx = max(mx, (uint32_t)p); }
+#pragma unroll
+                for (int it = 0; it < kDcBatch; ++it) {
+                    const int p = pb + 64 * it + r;
+                    if (p < L) {
+                        const uint32_t pp = __umul24((uint32_t)p, (uint32_t)p);
+                        const uint32_t seen_bit = 1u << (itb + it);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            int s1 = sv[it][k];
+                            if constexpr (STAGE == 2) {
+                                const int gz = abs(s1);
+                                const int sq = gz >= kInf16 ? kInf32 : (int)__umul24((uint32_t)gz, (uint32_t)gz);
+                                s1 = s1 < 0 ? -sq : sq;
+                            }
+                            uint32_t F;
+                            bool none;
+                            if (cls == 0) {
+                                if (s1 < 0) { atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31)); ++nfilled; }
+                                F = (uint32_t)max(s1, 0);
+                                none = s1 >= kInf32;
+                            } else if (s1 < 0) {
+                                F = (uint32_t)(-s1);
+                                none = -s1 >= kInf32;
+                            } else {            // free voxel: a zero-valued site only next to a filled voxel of its line
+                                F = 0u;
+                                const uint32_t* sg = sgn + (4 * sub + k) * SW;
+                                bool nb = false;
+                                if (p > 0) nb |= (sg[(p - 1) >> 5] >> ((p - 1) & 31)) & 1u;
+                                if (p + 1 < L) nb |= (sg[(p + 1) >> 5] >> ((p + 1) & 31)) & 1u;
+                                none = !nb;
+                            }
+                            kbase[k * pitch + (pb + 64 * it)] = (((none ? finf : F) + pp) << B) | (uint32_t)p;
+                            if (!none) seen[k] |= seen_bit;
+                        }
+                    }
                 }
             }
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                mn = min(mn, (uint32_t)__shfl_xor((int)mn, off));
-                mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+            for (int k = 0; k < 4; ++k) {
+                if (seen[k]) {                  // iteration it of this lane is position r + 64 it
+                    atomicMin(&span[2 * (4 * sub + k)], (uint32_t)(r + 64 * (__ffs((int)seen[k]) - 1)));
+                    atomicMax(&span[2 * (4 * sub + k) + 1], (uint32_t)(r + 64 * (31 - __clz((int)seen[k]))));
+                }
             }
-            if (g == 0) {
-                span[2 * lineU] = mn; span[2 * lineU + 1] = mx;
-                kl[L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);                  // sentinel
-                if (cls == 0 && anyf) atomicAdd(&flg[16], nfilled);
-            }
+            if (cls == 0 && nfilled) atomicAdd(&flg[16], nfilled);
+            if (t < 16) keys[t * pitch + L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);   // sentinel
         }
         __syncthreads();
 
