@@ -37,3 +37,37 @@ def test_cpp_client_reproduces_tutorial_scene():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "tutorial scene OK" in r.stdout
+
+
+C_EXE = os.path.join(ROOT, "examples", "c_client_example")
+
+
+def _build_c():
+    """examples/c_client.c with a C compiler: the two ABI headers must be plain C (what cgo / JNI / ctypes bind)."""
+    from sdf_tools_amd import build as b
+    b.build_libsdfgpu_multi()
+    src = os.path.join(ROOT, "examples", "c_client.c")
+    if not os.path.exists(C_EXE) or os.path.getmtime(C_EXE) < os.path.getmtime(src):
+        lib = os.path.join(ROOT, "sdf_tools_amd")
+        subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"), src,
+                               "-o", C_EXE, "-L", lib, "-lsdfgpu_multi", "-lsdfgpu", "-Wl,-rpath," + lib,
+                               "-Wl,-rpath-link," + lib, "-Wl,-rpath-link,/opt/rocm/lib", "-lm"])
+    return C_EXE
+
+
+def test_c_client_compiles_as_c11_and_refuses_without_gpu():
+    from sdf_tools_amd import capi
+    exe = _build_c()
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "no CPU fallback" in r.stdout and "sdfgpu_multi_create" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_client_single_and_multi_rank_fields_are_identical():
+    exe = _build_c()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fields identical" in r.stdout
