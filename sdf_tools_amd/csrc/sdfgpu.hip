@@ -1343,20 +1343,21 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
     const int64_t n = nx * ny * nz;
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
     hipStream_t s = (hipStream_t)stream;
+    // the reference's reciprocals, computed once with its own double operations (sdf.hpp:447 and :464-512)
+    GradScale sc{};
+    sc.inv2 = 1.0 / (2.0 * resolution);
+    sc.inv_w1 = 1.0 / ((double)1 * resolution);
+    sc.inv_w2 = 1.0 / ((double)2 * resolution);
+    sc.inv2f = (float)sc.inv2;
     if (out_is_f64)
-        hipLaunchKernelGGL(k_gradient<double>, grid, block, 0, s, d_sdf, (double*)d_out_grad, nx, ny, nz, resolution,
-                           enable_edge_gradients);
-    else if ((nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_sdf) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out_grad) % 16) == 0)
-    {
-        const double inv2 = 1.0 / (2.0 * resolution);
-        const bool f32scale = (double)(float)inv2 == inv2 && std::isfinite(inv2) && std::fabs(inv2) < 1e30 && std::fabs(inv2) > 1e-30;
+        hipLaunchKernelGGL(k_gradient<double>, grid, block, 0, s, d_sdf, (double*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
+    else if ((nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_sdf) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out_grad) % 16) == 0) {
+        const bool f32scale = (double)sc.inv2f == sc.inv2 && std::isfinite(sc.inv2) && std::fabs(sc.inv2) < 1e30 && std::fabs(sc.inv2) > 1e-30;
         const dim3 g4((unsigned)((n / 4 + kBlock - 1) / kBlock));
-        if (f32scale) hipLaunchKernelGGL(k_gradient_f32x4<true>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution, enable_edge_gradients);
-        else hipLaunchKernelGGL(k_gradient_f32x4<false>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution, enable_edge_gradients);
-    }
-    else
-        hipLaunchKernelGGL(k_gradient<float>, grid, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, resolution,
-                           enable_edge_gradients);
+        if (f32scale) hipLaunchKernelGGL(k_gradient_f32x4<true>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
+        else hipLaunchKernelGGL(k_gradient_f32x4<false>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
+    } else
+        hipLaunchKernelGGL(k_gradient<float>, grid, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }

@@ -628,84 +628,71 @@ __global__ __launch_bounds__(kBlock) void k_voxelize_points(const float* __restr
 
 // ---------------------------------------------------------------------------
 // N1: grid-aligned gradient of the whole field, sdf.hpp:432-526.
+// The reciprocals the reference computes per call -- 1 / (2 res) in the interior (:447), 1 / ((hi - lo) res) on the
+// boundary shell (:464-512, hi - lo = 1 or 2) -- are computed ONCE on the host with the same double operations and passed
+// in: fp64 divisions on the device cost ~30 instructions each, and at nz = 512 every wave holds a z-boundary voxel.
 // ---------------------------------------------------------------------------
+struct GradScale {
+    double inv2;      // 1.0 / (2.0 * res)               interior (:447)
+    double inv_w1;    // 1.0 / ((double)1 * res)          shell, clamped interval of 1 cell
+    double inv_w2;    // 1.0 / ((double)2 * res)          shell, interval of 2 cells
+    float inv2f;      // (float)inv2 when that is exact (F32SCALE kernels)
+};
+
+// one voxel, any position: interior -> float subtraction, double scale (:447-458); shell -> clamped indices, double
+// subtraction (:464-512); shell without edge gradients -> NaN (the reference returns an empty vector)
+__device__ __forceinline__ void gradient_one(const float* __restrict__ f, int64_t i, int64_t x, int64_t y, int64_t z,
+                                             int64_t nx, int64_t ny, int64_t nz, const GradScale& sc, int edge, double (&g)[3]) {
+    const int64_t sx = ny * nz, sy = nz;
+    const bool interior = x > 0 && y > 0 && z > 0 && x < nx - 1 && y < ny - 1 && z < nz - 1;
+    if (interior) {
+        g[0] = (double)(f[i + sx] - f[i - sx]) * sc.inv2;
+        g[1] = (double)(f[i + sy] - f[i - sy]) * sc.inv2;
+        g[2] = (double)(f[i + 1] - f[i - 1]) * sc.inv2;
+    } else if (edge) {
+        const int64_t lx = max((int64_t)0, x - 1), hx = min(nx - 1, x + 1);
+        const int64_t ly = max((int64_t)0, y - 1), hy = min(ny - 1, y + 1);
+        const int64_t lz = max((int64_t)0, z - 1), hz = min(nz - 1, z + 1);
+        const int wx = (int)(hx - lx), wy = (int)(hy - ly), wz = (int)(hz - lz);
+        g[0] = g[1] = g[2] = 0.0;
+        if (wx > 0) g[0] = ((double)f[i + (hx - x) * sx] - (double)f[i - (x - lx) * sx]) * (wx == 2 ? sc.inv_w2 : sc.inv_w1);
+        if (wy > 0) g[1] = ((double)f[i + (hy - y) * sy] - (double)f[i - (y - ly) * sy]) * (wy == 2 ? sc.inv_w2 : sc.inv_w1);
+        if (wz > 0) g[2] = ((double)f[i + (hz - z)] - (double)f[i - (z - lz)]) * (wz == 2 ? sc.inv_w2 : sc.inv_w1);
+    } else {
+        g[0] = g[1] = g[2] = __builtin_nan("");
+    }
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(kBlock) void k_gradient(const float* __restrict__ f, OutT* __restrict__ g,
-                                                    int64_t nx, int64_t ny, int64_t nz,
-                                                    double res, int edge) {
+                                                    int64_t nx, int64_t ny, int64_t nz, const GradScale sc, int edge) {
     const int64_t n = nx * ny * nz;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int64_t z = i % nz, y = (i / nz) % ny, x = i / (nz * ny);
-    const int64_t sx = ny * nz, sy = nz;
-    double gx, gy, gz;
-    const bool interior = x > 0 && y > 0 && z > 0 && x < nx - 1 && y < ny - 1 && z < nz - 1;
-    if (interior) {
-        // sdf.hpp:447-458: float subtraction, then double multiply
-        const double inv2 = 1.0 / (2.0 * res);
-        gx = (double)(f[i + sx] - f[i - sx]) * inv2;
-        gy = (double)(f[i + sy] - f[i - sy]) * inv2;
-        gz = (double)(f[i + 1] - f[i - 1]) * inv2;
-    } else if (edge) {
-        // sdf.hpp:464-512: clamped indices, double subtraction
-        const int64_t lx = max((int64_t)0, x - 1), hx = min(nx - 1, x + 1);
-        const int64_t ly = max((int64_t)0, y - 1), hy = min(ny - 1, y + 1);
-        const int64_t lz = max((int64_t)0, z - 1), hz = min(nz - 1, z + 1);
-        const double ix = (double)(hx - lx) * res, iy = (double)(hy - ly) * res, iz = (double)(hz - lz) * res;
-        gx = gy = gz = 0.0;
-        if (ix > 0.0) gx = ((double)f[i + (hx - x) * sx] - (double)f[i - (x - lx) * sx]) * (1.0 / ix);
-        if (iy > 0.0) gy = ((double)f[i + (hy - y) * sy] - (double)f[i - (y - ly) * sy]) * (1.0 / iy);
-        if (iz > 0.0) gz = ((double)f[i + (hz - z)] - (double)f[i - (z - lz)]) * (1.0 / iz);
-    } else {
-        gx = gy = gz = __builtin_nan("");
-    }
-    g[3 * i + 0] = (OutT)gx;
-    g[3 * i + 1] = (OutT)gy;
-    g[3 * i + 2] = (OutT)gz;
+    double v[3];
+    gradient_one(f, i, x, y, z, nx, ny, nz, sc, edge, v);
+    g[3 * i + 0] = (OutT)v[0];
+    g[3 * i + 1] = (OutT)v[1];
+    g[3 * i + 2] = (OutT)v[2];
 }
 
-// fp32 output, 4 consecutive z per lane (nz % 4 == 0, 16-byte aligned): interior groups take 16-byte
-// loads of the six neighbour rows and write 48 contiguous bytes; groups touching a grid face use the
-// per-voxel formulas above.  Same arithmetic as k_gradient<float> (float subtraction then double scale in
-// the interior, double subtraction on the boundary shell), narrowed to float once.
-__device__ __forceinline__ void gradient_one(const float* __restrict__ f, int64_t i, int64_t x, int64_t y, int64_t z,
-                                             int64_t nx, int64_t ny, int64_t nz, double res, int edge, float (&g)[3]) {
-    const int64_t sx = ny * nz, sy = nz;
-    const bool interior = x > 0 && y > 0 && z > 0 && x < nx - 1 && y < ny - 1 && z < nz - 1;
-    double gx, gy, gz;
-    if (interior) {
-        const double inv2 = 1.0 / (2.0 * res);
-        gx = (double)(f[i + sx] - f[i - sx]) * inv2;
-        gy = (double)(f[i + sy] - f[i - sy]) * inv2;
-        gz = (double)(f[i + 1] - f[i - 1]) * inv2;
-    } else if (edge) {
-        const int64_t lx = max((int64_t)0, x - 1), hx = min(nx - 1, x + 1);
-        const int64_t ly = max((int64_t)0, y - 1), hy = min(ny - 1, y + 1);
-        const int64_t lz = max((int64_t)0, z - 1), hz = min(nz - 1, z + 1);
-        const double ix = (double)(hx - lx) * res, iy = (double)(hy - ly) * res, iz = (double)(hz - lz) * res;
-        gx = gy = gz = 0.0;
-        if (ix > 0.0) gx = ((double)f[i + (hx - x) * sx] - (double)f[i - (x - lx) * sx]) * (1.0 / ix);
-        if (iy > 0.0) gy = ((double)f[i + (hy - y) * sy] - (double)f[i - (y - ly) * sy]) * (1.0 / iy);
-        if (iz > 0.0) gz = ((double)f[i + (hz - z)] - (double)f[i - (z - lz)]) * (1.0 / iz);
-    } else {
-        gx = gy = gz = __builtin_nan("");
-    }
-    g[0] = (float)gx; g[1] = (float)gy; g[2] = (float)gz;
-}
-
+// fp32 output, 4 consecutive z per lane (nz % 4 == 0, 16-byte aligned): interior groups take 16-byte loads of the six
+// neighbour rows and write 48 contiguous bytes; a group that touches a grid face finishes its voxels one by one with
+// gradient_one (at nz = 512 that is one lane in every wave, so that path is kept lean: no divisions, see GradScale).
 // F32SCALE: 1 / (2 res) is exactly representable in fp32 (res = 0.01, 0.02, 0.05, 0.1, 0.25, 1 ...): the product of the
 // fp32 difference with it has at most 48 significant bits, so the reference's double multiply is exact and its narrowing
 // to float is ONE rounding of the exact product -- which is what the fp32 multiply computes.  Same bits, a third of the
 // instructions (no conversions, no fp64 multiply).
 template <bool F32SCALE>
 __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restrict__ f, float* __restrict__ g,
-                                                          int64_t nx, int64_t ny, int64_t nz, double res, int edge) {
-    // A lane's 4 voxels give 12 consecutive floats (48 B).  Written straight from the lane, every store
-    // instruction would touch 64 x 16 B at a 48 B stride (24 cache lines instead of 8); the wave's 3 KiB are
-    // therefore transposed through LDS so that each of the 3 store instructions writes one contiguous 1 KiB.
+                                                          int64_t nx, int64_t ny, int64_t nz, const GradScale sc, int edge) {
+    // A lane's 4 voxels give 12 consecutive floats (48 B).  Written straight from the lane, every store instruction
+    // would touch 64 x 16 B at a 48 B stride (24 cache lines instead of 8); the wave's 3 KiB are therefore transposed
+    // through LDS so that each of the 3 store instructions writes one contiguous 1 KiB.
     __shared__ __attribute__((aligned(16))) float stage[(kBlock / 64) * 64 * 12];
     const int64_t n4 = nx * ny * nz / 4;
-    // (tried in round 2, no gain at 512^3 -- 0.64 ms either way: an XCD-contiguous workgroup order and non-temporal stores)
+    // (tried in round 2, no gain at 512^3: an XCD-contiguous workgroup order and non-temporal stores)
     const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & 63;
     float* st = stage + (threadIdx.x >> 6) * (64 * 12);
@@ -714,37 +701,56 @@ __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restri
         const int64_t z = i % nz, y = (i / nz) % ny, x = i / (nz * ny);
         const int64_t sx = ny * nz, sy = nz;
         float o[12];
-        if (x > 0 && x < nx - 1 && y > 0 && y < ny - 1 && z > 0 && z + 4 < nz) {
-            const double inv2 = 1.0 / (2.0 * res);
+        if (x > 0 && x < nx - 1 && y > 0 && y < ny - 1) {
+            // x and y interior.  A group on a z face (z == 0 or z + 4 == nz: one lane of EVERY wave at nz = 512) still takes
+            // this path -- its face voxel is patched below from the rows already in registers; sending the whole group
+            // through the per-voxel path put four dependent load chains on every wave's critical path (0.63 ms at 512^3
+            // where the same stencil without them runs in 0.43)
+            const bool zlo = z == 0, zhi = z + 4 >= nz;
             const float4 c = *reinterpret_cast<const float4*>(f + i);
             const float4 xp = *reinterpret_cast<const float4*>(f + i + sx), xm = *reinterpret_cast<const float4*>(f + i - sx);
             const float4 yp = *reinterpret_cast<const float4*>(f + i + sy), ym = *reinterpret_cast<const float4*>(f + i - sy);
-            const float zm = f[i - 1], zp = f[i + 4];
+            const float zm = zlo ? c.x : f[i - 1], zp = zhi ? c.w : f[i + 4];
             const float cz[6] = {zm, c.x, c.y, c.z, c.w, zp};
             const float xpv[4] = {xp.x, xp.y, xp.z, xp.w}, xmv[4] = {xm.x, xm.y, xm.z, xm.w};
             const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
             if constexpr (F32SCALE) {
-                const float inv2f = (float)inv2;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    o[3 * k + 0] = (xpv[k] - xmv[k]) * inv2f;
-                    o[3 * k + 1] = (ypv[k] - ymv[k]) * inv2f;
-                    o[3 * k + 2] = (cz[k + 2] - cz[k]) * inv2f;
+                    o[3 * k + 0] = (xpv[k] - xmv[k]) * sc.inv2f;
+                    o[3 * k + 1] = (ypv[k] - ymv[k]) * sc.inv2f;
+                    o[3 * k + 2] = (cz[k + 2] - cz[k]) * sc.inv2f;
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    o[3 * k + 0] = (float)((double)(xpv[k] - xmv[k]) * inv2);
-                    o[3 * k + 1] = (float)((double)(ypv[k] - ymv[k]) * inv2);
-                    o[3 * k + 2] = (float)((double)(cz[k + 2] - cz[k]) * inv2);
+                    o[3 * k + 0] = (float)((double)(xpv[k] - xmv[k]) * sc.inv2);
+                    o[3 * k + 1] = (float)((double)(ypv[k] - ymv[k]) * sc.inv2);
+                    o[3 * k + 2] = (float)((double)(cz[k + 2] - cz[k]) * sc.inv2);
                 }
             }
-        } else {
+            if (zlo | zhi) {
+                // the face voxel is on the boundary shell (sdf.hpp:464-512): double subtraction, x / y over 2 cells, z over the
+                // one cell inside the grid; NaN when edge gradients are off.  (nz >= 8 here: nz % 4 == 0 and a group with both
+                // faces, nz == 4, is handled too: voxel 0 and voxel 3 are patched independently.)
+                const double nan = __builtin_nan("");
+                if (zlo) {
+                    o[0] = edge ? (float)(((double)xp.x - (double)xm.x) * sc.inv_w2) : (float)nan;
+                    o[1] = edge ? (float)(((double)yp.x - (double)ym.x) * sc.inv_w2) : (float)nan;
+                    o[2] = edge ? (float)(((double)c.y - (double)c.x) * sc.inv_w1) : (float)nan;
+                }
+                if (zhi) {
+                    o[9] = edge ? (float)(((double)xp.w - (double)xm.w) * sc.inv_w2) : (float)nan;
+                    o[10] = edge ? (float)(((double)yp.w - (double)ym.w) * sc.inv_w2) : (float)nan;
+                    o[11] = edge ? (float)(((double)c.w - (double)c.z) * sc.inv_w1) : (float)nan;
+                }
+            }
+        } else {                                  // rows on an x or y face of the grid: four independent per-voxel chains
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float t[3];
-                gradient_one(f, i + k, x, y, z + k, nx, ny, nz, res, edge, t);
-                o[3 * k] = t[0]; o[3 * k + 1] = t[1]; o[3 * k + 2] = t[2];
+                double v[3];
+                gradient_one(f, i + k, x, y, z + k, nx, ny, nz, sc, edge, v);
+                o[3 * k] = (float)v[0]; o[3 * k + 1] = (float)v[1]; o[3 * k + 2] = (float)v[2];
             }
         }
         float4* d = reinterpret_cast<float4*>(st + lane * 12);
