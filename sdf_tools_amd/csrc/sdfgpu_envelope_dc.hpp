@@ -95,7 +95,7 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
 
 inline size_t envelope_dc_lds_bytes(int L, int pitch) {
     const int SW = (L + 31) / 32, M = (L + kDcChunk - 1) / kDcChunk;
-    return ((size_t)kDcLines * pitch + (size_t)kDcLines * SW + 64) * 4 + (size_t)kDcLines * (M + 2) * 2;
+    return ((size_t)kDcLines * pitch + (size_t)kDcLines * SW + 64 + 2 * kDcLocalFilled) * 4 + (size_t)kDcLines * (M + 2) * 2;
 }
 
 template <int STAGE>
@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     uint32_t* sgn = keys + kDcLines * pitch;                    // [16][SW]   bit p: voxel p of the line is filled
     uint32_t* span = sgn + kDcLines * SW;                       // [16][2]    first / last site of the line
     uint32_t* flg = span + 32;                                  // [16] line holds a filled voxel, [16] = tile does
-    uint16_t* args = reinterpret_cast<uint16_t*>(flg + 32);     // [16][AP]   argmin of coarse position i' (1-based)
+    uint32_t* flist = flg + 32;                                 // [2 * kDcLocalFilled] filled voxels of pass 0: (line << 16 | p), S
+    uint16_t* args = reinterpret_cast<uint16_t*>(flist + 2 * kDcLocalFilled);   // [16][AP]   argmin of coarse position i' (1-based)
     const int t = threadIdx.x;
 
     // tile of this workgroup.  Four consecutive tiles share cache lines (16 lines x 2 B = 32 B of a 128-B line), so an XCD
@@ -153,19 +154,21 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     };
 
     int mxF = 0, mxQ = 0;
-    // virtual-border distance of this lane's line in the chunk phase (STAGE 3: line = (y, z))
-    int byz = kInf32;
-    if constexpr (STAGE == 3) {
-        if (a.vb) {
-            const int64_t c = c0 + (t & 15);
-            const int64_t vyl = c / a.nz, vz = c - vyl * a.nz;
-            const int64_t vy = vyl + a.y_off;
-            int64_t b = kInf32;
-            if (a.ny_glob > 1) b = min(b, min(vy + 1, a.ny_glob - vy));
-            if (a.nz > 1) b = min(b, min(vz + 1, a.nz - vz));
-            byz = (int)b;
+    // virtual-border distance of a line to the padded layer over y and z (STAGE 3: line = (y, z))
+    auto byz_of = [&](int line) -> int {
+        int64_t b = kInf32;
+        if constexpr (STAGE == 3) {
+            if (a.vb) {
+                const int64_t c = c0 + line;
+                const int64_t vyl = c / a.nz, vz = c - vyl * a.nz;
+                const int64_t vy = vyl + a.y_off;
+                if (a.ny_glob > 1) b = min(b, min(vy + 1, a.ny_glob - vy));
+                if (a.nz > 1) b = min(b, min(vz + 1, a.nz - vz));
+            }
         }
-    }
+        return (int)b;
+    };
+    const int byz = byz_of(t & 15);             // the lane's own line in the chunk phase
 
     // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
     auto raw_signed = [&](int line, int q) -> int {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     };
     // finish one voxel: STAGE 2 plane field (+ side table on request), STAGE 3 the reference's merge arithmetic
     int probe_far = 0, probe_tot = 0;
-    auto emit = [&](int line, int p, int D, bool filled, bool side) {
+    auto emit = [&](int line, int p, int D, bool filled, bool side, int b_yz) {
         if (probe) { probe_tot += 1; probe_far += D >= a.probe_thr ? 1 : 0; return; }
         const uint32_t oi = (uint32_t)line + (uint32_t)p * ls;
         if constexpr (STAGE == 2) {
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             if (side) (a.side_out + base)[oi] = filled ? -D : D;
         } else {
             if (a.vb) {
-                int b = byz;
+                int b = b_yz;
                 if (a.nx > 1) b = min(b, (int)min((int64_t)p + 1, a.nx - p));
                 if (b < 32768) D = min(D, b * b);
             }
@@ -222,7 +225,6 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         {
             const int sub = t & 3, r = t >> 2;
             uint32_t seen[4] = {0u, 0u, 0u, 0u};            // bit it: iteration `it` of this lane found a site on line 4 sub + k
-            uint32_t nfilled = 0u;
             uint32_t* const kbase = keys + (4 * sub) * pitch + r;
             for (int pb = 0, itb = 0; pb < L; pb += 64 * kDcBatch, itb += kDcBatch) {
                 int sv[kDcBatch][4];
@@ -279,7 +281,11 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                             uint32_t F;
                             bool none;
                             if (cls == 0) {
-                                if (s1 < 0) { atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31)); ++nfilled; }
+                                if (s1 < 0) {
+                                    atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31));
+                                    const uint32_t e = atomicAdd(&flg[16], 1u);          // few per tile: list them for the local search
+                                    if (e < (uint32_t)kDcLocalFilled) { flist[2 * e] = ((uint32_t)(4 * sub + k) << 16) | (uint32_t)p; flist[2 * e + 1] = (uint32_t)(-s1); }
+                                }
                                 F = (uint32_t)max(s1, 0);
                                 none = s1 >= kInf32;
                             } else if (s1 < 0) {
@@ -306,7 +312,6 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                     atomicMax(&span[2 * (4 * sub + k) + 1], (uint32_t)(r + 64 * (31 - __clz((int)seen[k]))));
                 }
             }
-            if (cls == 0 && nfilled) atomicAdd(&flg[16], nfilled);
             if (t < 16) keys[t * pitch + L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);   // sentinel
         }
         __syncthreads();
@@ -316,7 +321,6 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         // (min-reduced with shuffles); levels with many positions switch to lane = (line, slot): the 16 lanes of a row then
         // work on the SAME position of 16 neighbouring lines, whose ranges are alike (the scene is coherent across
         // lines), so the per-lane loops of a row have nearly the same trip count.
-        const bool many_filled = flg[16] > (uint32_t)kDcLocalFilled;
         const int lineT = t & 15, slotT = t >> 4;
         const uint32_t qmnT = span[2 * lineT], qmxT = span[2 * lineT + 1];
         const bool actT = qmnT <= qmxT;
@@ -442,27 +446,30 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                         const int need = mine ? (D[k] >= kSat16 ? 1 : 0) : (inl ? 1 : 0);
                         int any = need | __shfl_xor(need, 1);
                         any |= __shfl_xor(any, 2);
-                        if (mine) emit(line, p, D[k], filled, cls == 1 || any);
+                        if (mine) emit(line, p, D[k], filled, cls == 1 || any, byz);
                     } else {
-                        if (mine) emit(line, p, D[k], filled, false);
+                        if (mine) emit(line, p, D[k], filled, false, byz);
                     }
                 }
-                // pass 0 finishes the tile's filled voxels itself when they are few and shallow (thin surfaces): exact local
-                // search along the line -- a candidate at offset d can only win while d^2 < the best so far
-                if (cls == 0 && cm != 0u && !(a.dbg & 8) && !probe) {
-                    if (many_filled) {
-                        flg[17] = 1u;
-                    } else {
-                        for (uint32_t rest = cm; rest; rest &= rest - 1u) {
-                            const int p = p0 + __ffs((int)rest) - 1;
-                            int D1 = -raw_signed(line, p);
-                            if (D1 > kDcLocalMax) { flg[17] = 1u; continue; }
-                            for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
-                                if (p - d >= 0) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(line, p - d), 0));
-                                if (p + d < L) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(line, p + d), 0));
-                            }
-                            emit(line, p, D1, true, true);
+            }
+            // Pass 0 finishes the tile's filled voxels itself when they are few and shallow (thin surfaces): one lane per
+            // listed voxel, exact local search along its line -- a candidate at offset d can only win while d^2 < the best so
+            // far, and S = 1 (a free voxel next door in the rows already swept) needs no search at all.  Deep or numerous
+            // filled voxels raise flg[17] and the second pass does the class properly.
+            if (cls == 0 && !(a.dbg & 8) && !probe) {
+                const uint32_t nf = flg[16];
+                if (nf > (uint32_t)kDcLocalFilled) {
+                    if (t == 0) flg[17] = 1u;
+                } else {
+                    for (uint32_t e = (uint32_t)t; e < nf; e += 256u) {
+                        const int fl = (int)(flist[2 * e] >> 16), p = (int)(flist[2 * e] & 0xffffu);
+                        int D1 = (int)flist[2 * e + 1];
+                        if (D1 > kDcLocalMax) { flg[17] = 1u; continue; }
+                        for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
+                            if (p - d >= 0) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(fl, p - d), 0));
+                            if (p + d < L) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(fl, p + d), 0));
                         }
+                        emit(fl, p, D1, true, true, byz_of(fl));
                     }
                 }
             }
