@@ -43,7 +43,9 @@ constexpr int kDcChunk = 8;           // positions per lane in the chunk phase
 constexpr int kDcBatch = 2;           // staging: row loads in flight per lane (register budget: 128 VGPRs at 4 waves per SIMD)
 constexpr int kDcBrute = 24;          // chunk phase: candidate ranges below this are searched exhaustively
 constexpr int kDcLocalMax = 64;       // pass 0 finishes filled voxels whose in-row squared distance is at most this ...
-constexpr int kDcLocalFilled = 96;    // ... when the tile holds at most this many filled voxels (of 16 x L)
+constexpr int kDcLocalFilled = 224;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second
+                                      // pass costs as much as the first: at 96 a 1 %-occupied scene ran it on a quarter
+                                      // of its tiles; 224 keeps the list inside the LDS budget of 4 workgroups per CU)
 
 struct EnvDcArgs {
     const int16_t* in16;      // STAGE 2: z field (+-g, 32767 = none); STAGE 3: plane field p16
@@ -273,13 +275,22 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             int s1 = sv[it][k];
+                            uint32_t F;
+                            bool none;
+                            if (STAGE == 2 && cls == 0 && s1 >= 0) {
+                                // the common case of the y sweep, straight from the z distance: F = g^2, "none" = no filled voxel
+                                // in the z row (g = 32767)
+                                F = __umul24((uint32_t)s1, (uint32_t)s1);
+                                none = s1 >= kInf16;
+                                kbase[k * pitch + (pb + 64 * it)] = (((none ? finf : F) + pp) << B) | (uint32_t)p;
+                                if (!none) seen[k] |= seen_bit;
+                                continue;
+                            }
                             if constexpr (STAGE == 2) {
                                 const int gz = abs(s1);
                                 const int sq = gz >= kInf16 ? kInf32 : (int)__umul24((uint32_t)gz, (uint32_t)gz);
                                 s1 = s1 < 0 ? -sq : sq;
                             }
-                            uint32_t F;
-                            bool none;
                             if (cls == 0) {
                                 if (s1 < 0) {
                                     atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31));
@@ -346,6 +357,20 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                     if (valid) {
                         lo = (ip - h == 0) ? (int)qmn : (int)aU[ip - h];
                         hi = (ip + h > M) ? (int)qmx : (int)aU[ip + h];
+                        // The first levels scan (nearly) the whole site span per position.  Any candidate's cost is an upper
+                        // bound v of the optimum, and a candidate farther than sqrt(v) from p costs more than v: clip the
+                        // range to p +- (sqrt(v) + 1).  On lines that pass near objects (every line of a uniformly sparse
+                        // scene, every position outside the span) this shrinks the scan from the span to a few candidates.
+                        const int pp = 8 * (ip - 1);
+                        const int pc = min(max(pp, lo), hi);
+                        const uint32_t cc = (2u * (uint32_t)pp) << B, p2b = __umul24((uint32_t)pp, (uint32_t)pp) << B;
+                        const uint32_t v = min(klU[pc] + p2b - __umul24(cc, (uint32_t)pc),
+                                               min(klU[lo] + p2b - __umul24(cc, (uint32_t)lo), klU[hi] + p2b - __umul24(cc, (uint32_t)hi))) >> B;
+                        if (v < finf) {
+                            const int w = (int)__builtin_sqrtf((float)v) + 2;
+                            lo = max(lo, pp - w);
+                            hi = min(hi, pp + w);
+                        }
                     }
                     uint32_t best = scan(klU, 8u * (uint32_t)(ip - 1), lo, hi, u, G);
                     for (int off = 1; off < G; off <<= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off));
@@ -444,8 +469,9 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                         // voxel also writes its exact value when its group holds a voxel of the other class (filled voxels
                         // always write theirs).
                         const int need = mine ? (D[k] >= kSat16 ? 1 : 0) : (inl ? 1 : 0);
-                        int any = need | __shfl_xor(need, 1);
-                        any |= __shfl_xor(any, 2);
+                        // OR over the 4 lanes of the group (= 4 neighbouring lines): two DPP quad permutes, no LDS traffic
+                        int any = need | __builtin_amdgcn_mov_dpp(need, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                        any |= __builtin_amdgcn_mov_dpp(any, 0x4E, 0xF, 0xF, true);                  // quad_perm [2,3,0,1]
                         if (mine) emit(line, p, D[k], filled, cls == 1 || any, byz);
                     } else {
                         if (mine) emit(line, p, D[k], filled, false, byz);

@@ -13,7 +13,7 @@ from sdf_tools_amd import capi, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 builds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-opts = [a for a in sys.argv[3:] if "=" in a]
+opts = [a for a in sys.argv[3:] if "=" in a and not a.startswith("--")]
 res = 0.01
 ctx = capi.SdfGpu(0)
 dev = torch.device("cuda", 0)
@@ -22,6 +22,9 @@ mask = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
 out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 ctx.voxelize_points_device(pts.data_ptr(), pts.shape[0], (0.0, 0.0, 0.0), res, (n, n, n), mask.data_ptr(), True, s)
+for a in sys.argv:
+    if a.startswith("--bernoulli="):          # a uniformly sparse scene instead of the two boxes
+        mask = synth.bernoulli_mask_torch((n, n, n), float(a.split("=")[1]), 1, device=dev)
 names = ["pack_bits", "dense_ball", "sweep_z", "sweep_y", "envelope_y", "sweep_x", "envelope_x"]
 result = {}
 for dc in ([1, 0] if "--both" in sys.argv else [1]):

@@ -49,6 +49,14 @@ def dc_line(F, FINF):
             hi = qmax if ip + h > M else a[ip + h]
             assert lo <= hi
             p = 8 * (ip - 1)
+            n_pos = (M // h + 1) >> 1
+            if n_pos <= 8:      # distance-bound clipping of the first levels (any candidate's cost bounds the optimum)
+                pc = min(max(p, lo), hi)
+                v = min((key[c] >> B) - c * c + (p - c) ** 2 for c in (pc, lo, hi))
+                if v < FINF:
+                    w = int(v ** 0.5) + 2
+                    lo, hi = max(lo, p - w), min(hi, p + w)
+                    assert lo <= hi
             G = max(1, 16 >> l)
             best = min(scan(p, lo, hi, u, G) for u in range(G))
             a[ip] = best & mask
