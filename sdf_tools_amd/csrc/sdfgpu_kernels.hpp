@@ -205,7 +205,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
             bits = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) |
                    (nonzero_bits4(v.w) << 12);
             const uint32_t cls = (bits != 0u ? 1u : 0u) | (bits != 0xFFFFu ? 2u : 0u);
-            if ((rowcls[r] & cls) != cls) atomicOr(&rowcls[r], cls);
+            atomicOr(&rowcls[r], cls);        // (no return value: a fire-and-forget ds_or; reading the word first to skip the
+                                              //  atomic put an LDS round trip into every lane's pack step: +0.1 ms at 512^3)
         }
         bm16[s] = (uint16_t)bits;
     }

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Condenses gpurun_out/<tag> (written by tools/profile_round.sh on the GPU box) into the tracked profiles/<name>_* files:
+#   tools/condense_round.sh <tag> <name>          e.g.  tools/condense_round.sh r02u r02
+set -e
+tag=$1; name=$2
+G=gpurun_out/$tag; P=profiles
+cp $G/bench.json $P/${name}_bench.json
+cp $G/stream_bench.json $P/${name}_stream_bench.json
+cp $G/bench_slab_world1.json $P/${name}_bench_slab_world1.json
+[ -f $G/psweep.jsonl ] && cp $G/psweep.jsonl $P/${name}_p_sweep.jsonl
+python tools/rocprof_summary.py stats $G/stats_dense $P/${name}_dense_kernel_stats.md
+python tools/rocprof_summary.py stats $G/stats_stream $P/${name}_stream_kernel_stats.md
+python tools/rocprof_summary.py stats $G/stats_general $P/${name}_general_kernel_stats.md
+for f in dense stream; do
+  s=$(find $G/stats_$f -name '*kernel_stats.csv' | head -1); [ -n "$s" ] && cp $s $P/${name}_${f}_kernel_stats.csv
+done
+python tools/rocprof_summary.py pmc $G/pmc_dense_FETCH_SIZE $G/pmc_dense_WRITE_SIZE $P/${name}_pmc_traffic_dense.json
+python tools/rocprof_summary.py pmc $G/pmc_general_FETCH_SIZE $G/pmc_general_WRITE_SIZE $P/${name}_pmc_traffic_general.json
+python tools/rocprof_summary.py pmc $G/pmc_env_FETCH_SIZE $G/pmc_env_WRITE_SIZE $P/${name}_pmc_traffic_envelope.json
+python tools/pmc_summary.py $G/pmc_env_SQ $G/pmc_env_SQ2 k_envelope k_sweep_z > $P/${name}_sq_counters_envelope.txt
