@@ -130,6 +130,20 @@ int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells,
 
 int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min);
 
+/* Pageable host memory <-> device memory at the rate of the link.  These are the copies the host-buffer entry points
+ * above use; wrappers that keep their own device buffers (the multi-GPU library, a caller filling a std::vector such
+ * as the reference's GetImmutableRawData() storage, sdf.hpp / voxel_grid.hpp:760) can use them too.
+ *   to_host:   the destination may be memory nobody has touched yet (a fresh std::vector / numpy array): a plain
+ *              hipMemcpy then takes one first-touch page fault after the other (512^3 floats: ~40 ms); here the DMA lands
+ *              in pinned staging chunks of the handle and a team of host threads copies them out while the next chunk
+ *              is in flight (512^3 floats: ~11 ms = the PCIe transfer).
+ *   from_host: a synchronous hipMemcpy from pageable memory is staged by one host thread (~5 GB/s measured); here a
+ *              team fills the pinned chunks (128 MiB: 3 ms instead of 24 - 30).
+ * Both are enqueued on `stream` behind the work already there and return when the transfer is complete.  One transfer
+ * at a time per handle (they share the handle's staging chunks). */
+int sdfgpu_copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, void* stream);
+int sdfgpu_copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Stage-level entry points for the x-slab multi-GPU path.
  * The grid is partitioned along x (the slowest axis); a rank owns rows

@@ -24,6 +24,7 @@ EXPORTS = [
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
     "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
     "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
+    "sdfgpu_copy_to_host", "sdfgpu_copy_from_host",
 ]
 
 
@@ -88,6 +89,8 @@ def load_library():
     L.sdfgpu_last_build_info.argtypes = [vp, vp]
     L.sdfgpu_last_dense_certified.argtypes = [vp, vp]
     L.sdfgpu_set_profiling.argtypes = [vp, ci]
+    L.sdfgpu_copy_to_host.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+    L.sdfgpu_copy_from_host.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
     L.sdfgpu_get_stage_times.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -262,6 +265,16 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_gradient_device(self._h, d_sdf, nx, ny, nz, float(resolution),
                                                      int(bool(enable_edge_gradients)), d_out, int(bool(f64)),
                                                      stream or None))
+
+    def copy_to_host(self, dst, d_src, stream=0):
+        """device pointer -> numpy array (may be untouched memory) at link rate; returns dst."""
+        self._check(self._lib.sdfgpu_copy_to_host(self._h, dst.ctypes.data, int(d_src), dst.nbytes, int(stream)))
+        return dst
+
+    def copy_from_host(self, d_dst, src, stream=0):
+        """numpy array -> device pointer at link rate."""
+        a = np.ascontiguousarray(src)
+        self._check(self._lib.sdfgpu_copy_from_host(self._h, int(d_dst), a.ctypes.data, a.nbytes, int(stream)))
 
     def gradient(self, sdf, resolution=1.0, enable_edge_gradients=True, f64=True):
         """Host-buffer full-grid gradient: sdf float32 [nx,ny,nz] -> [nx,ny,nz,3] (NaN where the reference has none)."""

@@ -11,6 +11,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
@@ -55,6 +56,8 @@ struct sdfgpu_context {
     DeviceBuffer tagids;     // uint32 object id filter
     DeviceBuffer stage_in;   // host-API staging: mask / cells
     DeviceBuffer stage_out;  // host-API staging: sdf
+    void* pin[2] = {nullptr, nullptr};      // pinned host staging of copy_to_host (two chunks in flight)
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] uncertified, [4] far_y, [5] far_x
     hipStream_t last_stream = nullptr;
     double last_resolution = 1.0;
@@ -421,13 +424,15 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             if (ntiles == 0) return SDFGPU_OK;
         }
         const size_t lds = envelope_dc_lds_bytes(a.L, a.pitch);
+        // (workgroups of 512 lanes at the same LDS footprint would double the waves per SIMD, but the kernel needs ~120 VGPRs:
+        //  at the 64 that leaves it spills and runs 1.2 - 2.3x slower, measured)
+        const void* fn = stage == 2 ? (const void*)k_envelope_dc<2, 256> : (const void*)k_envelope_dc<3, 256>;
         if (lds > 64 * 1024 && !h->dc_lds_attr[stage - 2]) {
-            const void* fn = stage == 2 ? (const void*)k_envelope_dc<2> : (const void*)k_envelope_dc<3>;
             HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             h->dc_lds_attr[stage - 2] = true;
         }
-        if (stage == 2) hipLaunchKernelGGL(k_envelope_dc<2>, dim3((unsigned)ntiles), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL(k_envelope_dc<3>, dim3((unsigned)ntiles), dim3(256), lds, s, a);
+        if (stage == 2) hipLaunchKernelGGL((k_envelope_dc<2, 256>), dim3((unsigned)ntiles), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_envelope_dc<3, 256>), dim3((unsigned)ntiles), dim3(256), lds, s, a);
         HIP_TRY(h, hipGetLastError());
         return SDFGPU_OK;
     }
@@ -860,37 +865,140 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
 // behind the reference's API) spends most of its time in single-threaded page faults: measured at 512^3,
 // 512 MiB took 65 ms into fresh pages against 9.6 ms into resident ones.  Only bytes inside [p, p + bytes) are
 // written (one zero per page), and every one of them is overwritten by the result afterwards.
-class PageToucher {
-    std::vector<std::thread> workers_;
+// Device -> pageable host memory at PCIe rate, for destinations nobody has touched yet (the std::vector / numpy array
+// the reference API returns is fresh: 512^3 floats are 131 072 first-touch page faults, ~40 ms on one thread, and a plain
+// hipMemcpy takes them one by one on the runtime's copy thread).  The DMA lands in two pinned staging chunks of the
+// context; a small team of host threads copies each chunk out while the next one is in flight, so the faults are spread
+// over the team and overlap the transfer.  Enqueued on `st` (ordered after the work already there).  (Round 1 pre-touched the destination from threads running beside the upload:
+// the faults and the runtime's pinning of the source pages fought over the address space, and the 128 MiB upload took
+// 29 ms instead of 2.5.)  Returns when the data is in dst.
+constexpr size_t kPinChunk = (size_t)32 << 20;
 
-public:
-    void start(void* p, size_t bytes) {
-        constexpr size_t kPage = 4096, kMinBytes = (size_t)16 << 20;
-        if (!p || bytes < kMinBytes) return;
-        // ask for huge pages on the 2 MiB-aligned interior: one fault then maps 512 small pages' worth
+int copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, hipStream_t st = nullptr) {
+    if (bytes == 0) return SDFGPU_OK;
+    for (int i = 0; i < 2 && bytes >= kPinChunk; ++i) {
+        if (!h->pin[i] && hipHostMalloc(&h->pin[i], kPinChunk, hipHostMallocDefault) != hipSuccess) h->pin[i] = nullptr;
+        if (h->pin[i] && !h->pin_ev[i] && hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) h->pin_ev[i] = nullptr;
+    }
+    if (bytes < kPinChunk || !h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
+        HIP_TRY(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        return SDFGPU_OK;
+    }
+    {   // huge pages on the 2 MiB-aligned interior, where the kernel grants them: one fault then maps 512 small pages' worth
         constexpr uintptr_t kHuge = (uintptr_t)2 << 20;
-        const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + kHuge - 1) & ~(kHuge - 1);
-        const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(kHuge - 1);
-        if (hi > lo) madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t nthreads = std::max<size_t>(1, std::min<size_t>(16, hw / 4));
-        const size_t per = ((bytes / nthreads) + kPage - 1) / kPage * kPage;
-        for (size_t t = 0; t < nthreads; ++t) {
-            const size_t b = t * per, e = std::min(bytes, b + per);
-            if (b >= e) break;
-            workers_.emplace_back([p, b, e]() {
-                volatile char* c = static_cast<volatile char*>(p);
-                for (size_t o = b; o < e; o += kPage) c[o] = 0;
-                c[e - 1] = 0;
-            });
+        const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + kHuge - 1) & ~(kHuge - 1);
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(kHuge - 1);
+        if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+    }
+    const int64_t nchunks = (int64_t)((bytes + kPinChunk - 1) / kPinChunk);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int team = (int)std::max<size_t>(1, std::min<size_t>(16, hw / 4));
+    std::atomic<int64_t> ready{-1};                      // highest chunk whose bytes are in its staging buffer
+    std::atomic<int64_t> copied{0};                      // slices copied out so far (team slices per chunk)
+    std::atomic<bool> abort{false};
+    auto chunk_bytes = [&](int64_t i) { return std::min(kPinChunk, bytes - (size_t)i * kPinChunk); };
+    std::vector<std::thread> workers;
+    workers.reserve((size_t)team);
+    for (int w = 0; w < team; ++w) {
+        workers.emplace_back([&, w]() {
+            for (int64_t i = 0; i < nchunks; ++i) {
+                while (ready.load(std::memory_order_acquire) < i) {
+                    if (abort.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                const size_t len = chunk_bytes(i);
+                const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
+                const size_t b = std::min(len, (size_t)w * per), e = std::min(len, b + per);
+                if (e > b) memcpy(static_cast<char*>(dst) + (size_t)i * kPinChunk + b, static_cast<const char*>(h->pin[i & 1]) + b, e - b);
+                copied.fetch_add(1, std::memory_order_release);
+            }
+        });
+    }
+    auto issue = [&](int64_t i) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(h->pin[i & 1], static_cast<const char*>(d_src) + (size_t)i * kPinChunk, chunk_bytes(i),
+                                      hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(h->pin_ev[i & 1], st);
+        return e;
+    };
+    hipError_t err = issue(0);
+    if (err == hipSuccess && nchunks > 1) err = issue(1);
+    for (int64_t i = 0; i < nchunks && err == hipSuccess; ++i) {
+        err = hipEventSynchronize(h->pin_ev[i & 1]);
+        if (err != hipSuccess) break;
+        ready.store(i, std::memory_order_release);
+        while (copied.load(std::memory_order_acquire) < (i + 1) * team) std::this_thread::yield();      // buffer i & 1 is free again
+        if (i + 2 < nchunks) err = issue(i + 2);
+    }
+    if (err != hipSuccess) abort.store(true);
+    for (std::thread& w : workers) w.join();
+    if (err != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) in the device-to-host copy", (int)err, hipGetErrorString(err));
+    }
+    return SDFGPU_OK;
+}
+
+// Pageable host -> device, the mirror image of copy_to_host: a synchronous hipMemcpy from pageable memory goes through
+// the runtime's staging copy on one host thread (measured: 128 MiB in 24 - 30 ms, i.e. 5 GB/s, where the link does 52);
+// here a team of threads fills the two pinned chunks and the DMA of one chunk overlaps the filling of the next.
+// Enqueued on `st`; returns when the last chunk's DMA has completed.
+int copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, hipStream_t st = nullptr) {
+    if (bytes == 0) return SDFGPU_OK;
+    for (int i = 0; i < 2 && bytes >= kPinChunk; ++i) {
+        if (!h->pin[i] && hipHostMalloc(&h->pin[i], kPinChunk, hipHostMallocDefault) != hipSuccess) h->pin[i] = nullptr;
+        if (h->pin[i] && !h->pin_ev[i] && hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) h->pin_ev[i] = nullptr;
+    }
+    if (bytes < kPinChunk || !h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
+        HIP_TRY(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        return SDFGPU_OK;
+    }
+    const int64_t nchunks = (int64_t)((bytes + kPinChunk - 1) / kPinChunk);
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int team = (int)std::max<size_t>(1, std::min<size_t>(16, hw / 4));
+    std::atomic<int64_t> may_fill{1};                    // chunks 0 .. may_fill may be written to their staging buffer
+    std::atomic<int64_t> filled{0};                      // slices filled so far (team slices per chunk)
+    std::atomic<bool> abort{false};
+    auto chunk_bytes = [&](int64_t i) { return std::min(kPinChunk, bytes - (size_t)i * kPinChunk); };
+    std::vector<std::thread> workers;
+    workers.reserve((size_t)team);
+    for (int w = 0; w < team; ++w) {
+        workers.emplace_back([&, w]() {
+            for (int64_t i = 0; i < nchunks; ++i) {
+                while (may_fill.load(std::memory_order_acquire) < i) {
+                    if (abort.load(std::memory_order_relaxed)) return;
+                    std::this_thread::yield();
+                }
+                const size_t len = chunk_bytes(i);
+                const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
+                const size_t b = std::min(len, (size_t)w * per), e = std::min(len, b + per);
+                if (e > b) memcpy(static_cast<char*>(h->pin[i & 1]) + b, static_cast<const char*>(src) + (size_t)i * kPinChunk + b, e - b);
+                filled.fetch_add(1, std::memory_order_release);
+            }
+        });
+    }
+    hipError_t err = hipSuccess;
+    for (int64_t i = 0; i < nchunks && err == hipSuccess; ++i) {
+        while (filled.load(std::memory_order_acquire) < (i + 1) * team) std::this_thread::yield();
+        err = hipMemcpyAsync(static_cast<char*>(d_dst) + (size_t)i * kPinChunk, h->pin[i & 1], chunk_bytes(i), hipMemcpyHostToDevice, st);
+        if (err == hipSuccess) err = hipEventRecord(h->pin_ev[i & 1], st);
+        // chunk i + 1 was released for filling already; chunk i + 2 shares this chunk's buffer: release it once this DMA is done
+        if (err == hipSuccess && i + 2 < nchunks) {
+            err = hipEventSynchronize(h->pin_ev[i & 1]);
+            may_fill.store(i + 2, std::memory_order_release);
         }
     }
-    void join() {
-        for (std::thread& w : workers_) w.join();
-        workers_.clear();
+    if (err != hipSuccess) abort.store(true);
+    for (std::thread& w : workers) w.join();
+    if (err == hipSuccess) err = hipEventSynchronize(h->pin_ev[(nchunks - 1) & 1]);
+    if (err == hipSuccess && nchunks > 1) err = hipEventSynchronize(h->pin_ev[(nchunks - 2) & 1]);
+    if (err != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) in the host-to-device copy", (int)err, hipGetErrorString(err));
     }
-    ~PageToucher() { join(); }
-};
+    return SDFGPU_OK;
+}
 
 int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t stride, size_t off,
                     int unknown, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb, float* out_sdf,
@@ -903,27 +1011,22 @@ int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, s
     const size_t in_bytes = cells ? (size_t)n * stride : (size_t)n;
     if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
     if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
-    PageToucher toucher;
     const bool timing = getenv("SDFGPU_HOST_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    // (out_sdf is scratch from here on: include/sdfgpu.h documents that its contents are undefined when the call fails)
-    toucher.start(out_sdf, (size_t)n * 4);
     const double t1 = now();
-    HIP_TRY(h, hipMemcpy(h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes, hipMemcpyHostToDevice));
+    // (out_sdf is scratch from here on: include/sdfgpu.h documents that its contents are undefined when the call fails)
+    if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes)) return rc0;
     const double t2 = now();
     int rc = build_device_impl(h, cells ? nullptr : (const uint8_t*)h->stage_in.ptr,
                                cells ? h->stage_in.ptr : nullptr, stride, off, unknown, nx, ny, nz, resolution,
                                vb, (float*)h->stage_out.ptr, nullptr);
     if (rc) return rc;
     const double t3 = now();
-    toucher.join();
-    const double t4 = now();
-    HIP_TRY(h, hipMemcpy(out_sdf, h->stage_out.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (int rc2 = copy_to_host(h, out_sdf, h->stage_out.ptr, (size_t)n * 4)) return rc2;
     const double t5 = now();
     double mx, mn;
     rc = sdfgpu_get_extrema(h, &mx, &mn);
-    if (timing) fprintf(stderr, "[sdfgpu host] start %.3f h2d %.3f enqueue %.3f join %.3f d2h %.3f extrema %.3f ms\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, now() - t5);
+    if (timing) fprintf(stderr, "[sdfgpu host] h2d %.3f enqueue %.3f build + d2h %.3f extrema %.3f ms\n", t2 - t1, t3 - t2, t5 - t3, now() - t5);
     if (rc) return rc;
     if (out_max) *out_max = mx;
     if (out_min) *out_min = mn;
@@ -990,6 +1093,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->h_flags) { (void)hipHostFree(h->h_flags); (void)hipEventDestroy(h->flags_ev); }
     if (h->build_done_ev) (void)hipEventDestroy(h->build_done_ev);
+    for (int i = 0; i < 2; ++i) { if (h->pin[i]) (void)hipHostFree(h->pin[i]); if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]); }
     for (size_t i = 0; i < h->events.size(); ++i)
         if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
@@ -1028,6 +1132,20 @@ int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_
     if (h && !d_cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_cells is null");
     return build_device_impl(h, nullptr, d_cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz,
                              resolution, add_virtual_border, d_out_sdf, (hipStream_t)stream);
+}
+
+int sdfgpu_copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (bytes > 0 && (!dst || !d_src)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return copy_to_host(h, dst, d_src, bytes, (hipStream_t)stream);
+}
+
+int sdfgpu_copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (bytes > 0 && (!d_dst || !src)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return copy_from_host(h, d_dst, src, bytes, (hipStream_t)stream);
 }
 
 int sdfgpu_extrema_from_dsq(uint32_t max_dsq_free, uint32_t max_dsq_filled, double resolution, double* out_max,
@@ -1274,9 +1392,7 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
     if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
     if (int rc = ensure(h, h->tagmask, (size_t)n)) return rc;
     if (int rc = ensure(h, h->tagids, (size_t)std::max<int64_t>(n_object_ids, 1) * 4)) return rc;
-    PageToucher toucher;
-    toucher.start(out_sdf, (size_t)n * 4);
-    HIP_TRY(h, hipMemcpy(h->stage_in.ptr, cells, (size_t)n * cell_stride, hipMemcpyHostToDevice));
+    if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells, (size_t)n * cell_stride)) return rc0;
     if (n_object_ids > 0) {                        // sorted copy: the classify kernel binary-searches it
         std::vector<uint32_t> sorted_ids(object_ids, object_ids + n_object_ids);
         std::sort(sorted_ids.begin(), sorted_ids.end());
@@ -1290,8 +1406,7 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
     int rc = build_device_impl(h, (const uint8_t*)h->tagmask.ptr, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border,
                                (float*)h->stage_out.ptr, nullptr);
     if (rc) return rc;
-    toucher.join();
-    HIP_TRY(h, hipMemcpy(out_sdf, h->stage_out.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (int rc2 = copy_to_host(h, out_sdf, h->stage_out.ptr, (size_t)n * 4)) return rc2;
     double mx, mn;
     rc = sdfgpu_get_extrema(h, &mx, &mn);
     if (rc) return rc;
@@ -1379,20 +1494,17 @@ int sdfgpu_gradient(sdfgpu_handle h, const float* sdf, int64_t nx, int64_t ny, i
     if (int rc = ensure(h, h->stage_in, (size_t)(rows + 2) * plane * 4)) return rc;
     if (int rc = ensure(h, h->stage_out, (size_t)(rows + 2) * plane * 3 * esz)) return rc;
     (void)n;
-    PageToucher toucher;
-    toucher.start(out_grad, (size_t)nx * plane * 3 * esz);
     for (int64_t x0 = 0; x0 < nx; x0 += rows) {
         const int64_t x1 = std::min(nx, x0 + rows);
         const int64_t lo = std::max<int64_t>(0, x0 - 1), hi = std::min(nx, x1 + 1);     // context planes
-        HIP_TRY(h, hipMemcpy(h->stage_in.ptr, sdf + lo * plane, (size_t)(hi - lo) * plane * 4, hipMemcpyHostToDevice));
+        if (int rc0 = copy_from_host(h, h->stage_in.ptr, sdf + lo * plane, (size_t)(hi - lo) * plane * 4)) return rc0;
         // the kernel treats the chunk as a grid of its own: its first / last plane would take the one-sided boundary
         // formula, so those planes are computed only when they ARE grid faces and are otherwise context that is skipped
         if (int rc = sdfgpu_gradient_device(h, (const float*)h->stage_in.ptr, hi - lo, ny, nz, resolution, enable_edge_gradients,
                                             h->stage_out.ptr, out_is_f64, nullptr)) return rc;
-        if (x0 == 0) toucher.join();
-        HIP_TRY(h, hipMemcpy((char*)out_grad + (size_t)x0 * plane * 3 * esz,
-                             (const char*)h->stage_out.ptr + (size_t)(x0 - lo) * plane * 3 * esz,
-                             (size_t)(x1 - x0) * plane * 3 * esz, hipMemcpyDeviceToHost));
+        if (int rc = copy_to_host(h, (char*)out_grad + (size_t)x0 * plane * 3 * esz,
+                                  (const char*)h->stage_out.ptr + (size_t)(x0 - lo) * plane * 3 * esz,
+                                  (size_t)(x1 - x0) * plane * 3 * esz)) return rc;
     }
     return SDFGPU_OK;
 }

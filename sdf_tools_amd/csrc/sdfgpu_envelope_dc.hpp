@@ -100,8 +100,10 @@ inline size_t envelope_dc_lds_bytes(int L, int pitch) {
     return ((size_t)kDcLines * pitch + (size_t)kDcLines * SW + 64 + 2 * kDcLocalFilled) * 4 + (size_t)kDcLines * (M + 2) * 2;
 }
 
-template <int STAGE>
-__global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
+template <int STAGE, int NT>
+__global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) {
+    constexpr int PS = NT / 4;          // positions staged per pass of the workgroup (4 lanes per position)
+    constexpr int NS = NT / 16;         // (line, slot) mapping: slots per line
     extern __shared__ __attribute__((aligned(16))) uint32_t dc_smem[];
     if (a.guard) {
         const uint32_t gv = *a.guard;
@@ -221,19 +223,19 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         // in-row squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can
         // only matter while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises flg[17] for the rest.
         if (cls == 1 && flg[17] == 0u) break;   // (block-uniform)
-        if (cls == 0) for (int i = t; i < kDcLines * SW; i += 256) sgn[i] = 0u;
+        if (cls == 0) for (int i = t; i < kDcLines * SW; i += NT) sgn[i] = 0u;
         if (t < 16) { span[2 * t] = 0xFFFFFFFFu; span[2 * t + 1] = 0u; }
         __syncthreads();
         {
             const int sub = t & 3, r = t >> 2;
             uint32_t seen[4] = {0u, 0u, 0u, 0u};            // bit it: iteration `it` of this lane found a site on line 4 sub + k
             uint32_t* const kbase = keys + (4 * sub) * pitch + r;
-            for (int pb = 0, itb = 0; pb < L; pb += 64 * kDcBatch, itb += kDcBatch) {
+            for (int pb = 0, itb = 0; pb < L; pb += PS * kDcBatch, itb += kDcBatch) {
                 int sv[kDcBatch][4];
                 if (STAGE == 3 && in32) {
 #pragma unroll
                     for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = min(pb + 64 * it + r, L - 1);
+                        const int p = min(pb + PS * it + r, L - 1);
                         const int4 e = *reinterpret_cast<const int4*>(in32 + ((uint32_t)p * ls + 4u * sub));
                         sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
                     }
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                     uint2 raw[kDcBatch];
 #pragma unroll
                     for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = min(pb + 64 * it + r, L - 1);
+                        const int p = min(pb + PS * it + r, L - 1);
                         raw[it] = *reinterpret_cast<const uint2*>(in16 + ((uint32_t)p * ls + 4u * sub));
                     }
 #pragma unroll
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                             const uint32_t m1 = (raw[it].y ^ (n1 * 0xFFFFu)) + 0x00010001u + n1;
                             const bool sat = ((m0 | m1) & 0x80008000u) != 0u;
                             if (sat) {
-                                const int p = min(pb + 64 * it + r, L - 1);
+                                const int p = min(pb + PS * it + r, L - 1);
                                 const int4 e = *reinterpret_cast<const int4*>(side_in + ((uint32_t)p * ls + 4u * sub));
                                 sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
                             }
@@ -268,38 +270,56 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                 }
 #pragma unroll
                 for (int it = 0; it < kDcBatch; ++it) {
-                    const int p = pb + 64 * it + r;
+                    const int p = pb + PS * it + r;
                     if (p < L) {
                         const uint32_t pp = __umul24((uint32_t)p, (uint32_t)p);
                         const uint32_t seen_bit = 1u << (itb + it);
+                        if (cls == 0) {
+                            // Pass 0, branch-free: a free voxel is a site with its own value, a filled one a site with 0, "no
+                            // filled voxel in the rows swept so far" becomes finf by the clamp (finf > every real distance, and
+                            // the "none" codes 32767^2 / kInf32 are above it).  The bookkeeping of the (rare) filled voxels is
+                            // kept out of the way behind one test per group of 4.
+                            int neg = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            int s1 = sv[it][k];
-                            uint32_t F;
-                            bool none;
-                            if (STAGE == 2 && cls == 0 && s1 >= 0) {
-                                // the common case of the y sweep, straight from the z distance: F = g^2, "none" = no filled voxel
-                                // in the z row (g = 32767)
-                                F = __umul24((uint32_t)s1, (uint32_t)s1);
-                                none = s1 >= kInf16;
-                                kbase[k * pitch + (pb + 64 * it)] = (((none ? finf : F) + pp) << B) | (uint32_t)p;
-                                if (!none) seen[k] |= seen_bit;
-                                continue;
+                            for (int k = 0; k < 4; ++k) {
+                                const int s1 = sv[it][k];
+                                uint32_t F;
+                                if constexpr (STAGE == 2) {
+                                    const uint32_t m = (uint32_t)max(s1, 0);
+                                    F = min(__umul24(m, m), finf);
+                                } else {
+                                    F = (uint32_t)min(max(s1, 0), (int)finf);
+                                }
+                                kbase[k * pitch + (pb + PS * it)] = ((F + pp) << B) | (uint32_t)p;
+                                seen[k] |= F != finf ? seen_bit : 0u;
+                                neg |= s1;
                             }
+                            if (neg < 0) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const int s1 = sv[it][k];
+                                    if (s1 < 0) {
+                                        uint32_t S = (uint32_t)(-s1);        // squared distance to the nearest free voxel so far
+                                        if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
+                                        atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31));
+                                        const uint32_t e = atomicAdd(&flg[16], 1u);          // few per tile: list them for the local search
+                                        if (e < (uint32_t)kDcLocalFilled) { flist[2 * e] = ((uint32_t)(4 * sub + k) << 16) | (uint32_t)p; flist[2 * e + 1] = S; }
+                                    }
+                                }
+                            }
+                            continue;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {           // pass 1: sites of "distance to free"
+                            int s1 = sv[it][k];
                             if constexpr (STAGE == 2) {
                                 const int gz = abs(s1);
                                 const int sq = gz >= kInf16 ? kInf32 : (int)__umul24((uint32_t)gz, (uint32_t)gz);
                                 s1 = s1 < 0 ? -sq : sq;
                             }
-                            if (cls == 0) {
-                                if (s1 < 0) {
-                                    atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31));
-                                    const uint32_t e = atomicAdd(&flg[16], 1u);          // few per tile: list them for the local search
-                                    if (e < (uint32_t)kDcLocalFilled) { flist[2 * e] = ((uint32_t)(4 * sub + k) << 16) | (uint32_t)p; flist[2 * e + 1] = (uint32_t)(-s1); }
-                                }
-                                F = (uint32_t)max(s1, 0);
-                                none = s1 >= kInf32;
-                            } else if (s1 < 0) {
+                            uint32_t F;
+                            bool none;
+                            if (s1 < 0) {
                                 F = (uint32_t)(-s1);
                                 none = -s1 >= kInf32;
                             } else {            // free voxel: a zero-valued site only next to a filled voxel of its line
@@ -310,7 +330,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                                 if (p + 1 < L) nb |= (sg[(p + 1) >> 5] >> ((p + 1) & 31)) & 1u;
                                 none = !nb;
                             }
-                            kbase[k * pitch + (pb + 64 * it)] = (((none ? finf : F) + pp) << B) | (uint32_t)p;
+                            kbase[k * pitch + (pb + PS * it)] = (((none ? finf : F) + pp) << B) | (uint32_t)p;
                             if (!none) seen[k] |= seen_bit;
                         }
                     }
@@ -319,8 +339,8 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (seen[k]) {                  // iteration it of this lane is position r + 64 it
-                    atomicMin(&span[2 * (4 * sub + k)], (uint32_t)(r + 64 * (__ffs((int)seen[k]) - 1)));
-                    atomicMax(&span[2 * (4 * sub + k) + 1], (uint32_t)(r + 64 * (31 - __clz((int)seen[k]))));
+                    atomicMin(&span[2 * (4 * sub + k)], (uint32_t)(r + PS * (__ffs((int)seen[k]) - 1)));
+                    atomicMax(&span[2 * (4 * sub + k) + 1], (uint32_t)(r + PS * (31 - __clz((int)seen[k]))));
                 }
             }
             if (t < 16) keys[t * pitch + L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);   // sentinel
@@ -336,11 +356,11 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         const uint32_t qmnT = span[2 * lineT], qmxT = span[2 * lineT + 1];
         const bool actT = qmnT <= qmxT;
         {
-            const int lineU = t >> 4, g = t & 15;
+            const int lineU = (t >> 4) & 15, g = t & 15;      // (lanes beyond 256 idle through the first levels)
             const uint32_t* klU = keys + lineU * pitch;
             uint16_t* aU = args + lineU * AP;
             const uint32_t qmn = span[2 * lineU], qmx = span[2 * lineU + 1];
-            const bool actU = qmn <= qmx;
+            const bool actU = qmn <= qmx && t < 256;
             const uint32_t* klT = keys + lineT * pitch;
             uint16_t* aT = args + lineT * AP;
             for (int l = 0; l < ((a.dbg & 1) ? 0 : Kp); ++l) {
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                     for (int off = 1; off < G; off <<= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off));
                     if (valid && u == 0) aU[ip] = (uint16_t)(best & mask);
                 } else {
-                    for (int j = slotT; j < n; j += 16) {
+                    for (int j = slotT; j < n; j += NS) {
                         const int ip = h * (2 * j + 1);
                         if (actT) {
                             const int lo = (ip - h == 0) ? (int)qmnT : (int)aT[ip - h];
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             const uint16_t* al = args + line * AP;
             const uint32_t qmx = qmxT;
             const bool act = actT;
-            for (int i0 = 0; i0 < M; i0 += 16) {
+            for (int i0 = 0; i0 < M; i0 += NS) {
                 const int i = i0 + slot;
                 const bool live = i < M;
                 const int p0 = kDcChunk * i;
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                 if (nf > (uint32_t)kDcLocalFilled) {
                     if (t == 0) flg[17] = 1u;
                 } else {
-                    for (uint32_t e = (uint32_t)t; e < nf; e += 256u) {
+                    for (uint32_t e = (uint32_t)t; e < nf; e += (uint32_t)NT) {
                         const int fl = (int)(flist[2 * e] >> 16), p = (int)(flist[2 * e] & 0xffffu);
                         int D1 = (int)flist[2 * e + 1];
                         if (D1 > kDcLocalMax) { flg[17] = 1u; continue; }
@@ -521,7 +541,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             mxF = max(mxF, __shfl_xor(mxF, off));
             mxQ = max(mxQ, __shfl_xor(mxQ, off));
         }
-        if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * 4 + (t >> 6), mxF, mxQ);
+        if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * (NT / 64) + (t >> 6), mxF, mxQ);
     }
 }
 

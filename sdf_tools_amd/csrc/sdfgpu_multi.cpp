@@ -16,6 +16,7 @@
 #include <cstring>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sdfgpu_multi.h"
@@ -394,28 +395,49 @@ int build_host(sdfgpu_multi_handle h, const uint8_t* filled, const void* cells, 
         const int64_t nxs = k.x1 - k.x0;
         if (int rc = ensure(h, k, k.mask, (size_t)nxs * plane)) return rc;
         if (int rc = ensure(h, k, k.out, (size_t)nxs * plane * 4)) return rc;
-        M_HIP(h, hipSetDevice(k.dev));
-        if (cells) {
-            if (int rc = ensure(h, k, k.cells, (size_t)nxs * plane * stride)) return rc;
-            M_HIP(h, hipMemcpyAsync(k.cells.p, (const char*)cells + (size_t)k.x0 * plane * stride, (size_t)nxs * plane * stride,
-                                    hipMemcpyHostToDevice, k.s));
-            M_SDF(h, q, sdfgpu_classify_cells_device(k.ctx, k.cells.p, stride, off, unknown, nxs * plane, (uint8_t*)k.mask.p, k.s));
-        } else {
-            M_HIP(h, hipMemcpyAsync(k.mask.p, filled + (size_t)k.x0 * plane, (size_t)nxs * plane, hipMemcpyHostToDevice, k.s));
-        }
+        if (cells) if (int rc = ensure(h, k, k.cells, (size_t)nxs * plane * stride)) return rc;
         dm[(size_t)q] = (const uint8_t*)k.mask.p;
         dout[(size_t)q] = (float*)k.out.p;
     }
+    // Every rank has its own link to the host: the slabs go up (and come back) side by side, one host thread per rank
+    // driving sdfgpu_copy_from_host / sdfgpu_copy_to_host (pinned staging chunks filled / drained by a team of threads:
+    // a plain copy from or into pageable, possibly untouched memory runs at a fraction of the link rate).
+    auto per_rank = [&](auto&& fn) -> int {
+        std::vector<int> rcs((size_t)G, SDFGPU_OK);
+        std::vector<std::thread> th;
+        th.reserve((size_t)G);
+        for (int q = 0; q < G; ++q) th.emplace_back([&, q]() { rcs[(size_t)q] = fn(q); });
+        for (std::thread& t : th) t.join();
+        for (int q = 0; q < G; ++q)
+            if (rcs[(size_t)q] != SDFGPU_OK) return mfail(h, rcs[(size_t)q], "rank %d: %s", q, sdfgpu_last_error(h->r[(size_t)q].ctx));
+        return SDFGPU_OK;
+    };
+    // (ranks that share a GPU share its link and the default device of the calling thread: they go one after the other)
+    bool shared_gpu = false;
+    for (int q = 0; q < G; ++q) for (int p = 0; p < q; ++p) shared_gpu |= h->r[(size_t)p].dev == h->r[(size_t)q].dev;
+    auto upload = [&](int q) -> int {
+        Rank& k = h->r[(size_t)q];
+        const int64_t nxs = k.x1 - k.x0;
+        if (hipSetDevice(k.dev) != hipSuccess) return SDFGPU_ERR_HIP;
+        if (cells) {
+            if (int rc = sdfgpu_copy_from_host(k.ctx, k.cells.p, (const char*)cells + (size_t)k.x0 * plane * stride, (size_t)nxs * plane * stride, k.s)) return rc;
+            return sdfgpu_classify_cells_device(k.ctx, k.cells.p, stride, off, unknown, nxs * plane, (uint8_t*)k.mask.p, k.s);
+        }
+        return sdfgpu_copy_from_host(k.ctx, k.mask.p, filled + (size_t)k.x0 * plane, (size_t)nxs * plane, k.s);
+    };
+    auto download = [&](int q) -> int {
+        Rank& k = h->r[(size_t)q];
+        if (hipSetDevice(k.dev) != hipSuccess) return SDFGPU_ERR_HIP;
+        return sdfgpu_copy_to_host(k.ctx, out + (size_t)k.x0 * plane, k.out.p, (size_t)(k.x1 - k.x0) * plane * 4, k.s);
+    };
+    auto serial = [&](auto&& fn) -> int {
+        for (int q = 0; q < G; ++q)
+            if (int rc = fn(q)) return mfail(h, rc, "rank %d: %s", q, sdfgpu_last_error(h->r[(size_t)q].ctx));
+        return SDFGPU_OK;
+    };
+    if (int rc = shared_gpu ? serial(upload) : per_rank(upload)) return rc;
     if (int rc = build_device(h, dm.data(), nx, ny, nz, res, vb, dout.data(), out_max, out_min)) return rc;
-    for (int q = 0; q < G; ++q) {
-        Rank& k = h->r[q];
-        M_HIP(h, hipSetDevice(k.dev));
-        M_HIP(h, hipMemcpyAsync(out + (size_t)k.x0 * plane, k.out.p, (size_t)(k.x1 - k.x0) * plane * 4, hipMemcpyDeviceToHost, k.s));
-    }
-    for (Rank& k : h->r) {
-        M_HIP(h, hipSetDevice(k.dev));
-        M_HIP(h, hipStreamSynchronize(k.s));
-    }
+    if (int rc = shared_gpu ? serial(download) : per_rank(download)) return rc;
     return SDFGPU_OK;
 }
 

@@ -255,3 +255,33 @@ def test_tuning_does_not_change_results(gpu):
     finally:
         gpu.set_tuning(0, 0)
         gpu.set_option("dense", 1)
+
+
+def test_host_copies_chunked_path(gpu):
+    """sdfgpu_copy_from_host / sdfgpu_copy_to_host (the copies behind the host-buffer entry points): sizes that span
+    several pinned staging chunks with a ragged tail, into untouched destination memory; and the host entry points on a
+    grid large enough to take that path give the bytes of the device-resident build."""
+    import torch
+    rng = np.random.RandomState(11)
+    for nbytes in (1 << 20, (32 << 20) + 4096, (100 << 20) + 12345):
+        src = rng.randint(0, 256, size=nbytes, dtype=np.uint8)
+        d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        gpu.copy_from_host(d.data_ptr(), src)
+        assert np.array_equal(d.cpu().numpy(), src), nbytes
+        back = gpu.copy_to_host(np.empty(nbytes, np.uint8), d.data_ptr())
+        assert np.array_equal(back, src), nbytes
+    shape = (130, 256, 256)                       # 34 MB of output, 68 MB of cells
+    m = synth.bernoulli_mask(shape, 0.3, 4)
+    dm = torch.from_numpy(m).cuda()
+    dout = torch.empty(shape, dtype=torch.float32, device="cuda")
+    gpu.build_device(dm.data_ptr(), shape, dout.data_ptr(), 0.02, False, torch.cuda.current_stream().cuda_stream)
+    want_ext = gpu.get_extrema()
+    want = dout.cpu().numpy()
+    got, ext = gpu.build(m, 0.02)
+    assert np.array_equal(got, want) and ext == want_ext
+    cells = np.zeros(shape + (2,), np.float32)
+    cells[..., 0] = m
+    got, ext = gpu.build_cells(cells, shape, 8, 0, False, 0.02)
+    assert np.array_equal(got, want) and ext == want_ext
+    g = gpu.gradient(got, 0.02)
+    assert g.shape == shape + (3,) and np.isfinite(g).all()
