@@ -88,10 +88,11 @@ struct sdfgpu_context {
     int force_env = -1;              // -1 automatic, 1 = envelope kernels only (option "envelope_mode")
     // an axis is far-field when more than 1 / den of the probed voxels have d^2 >= thr.  Per axis, from the measured
     // break-even of the two sweeps at 512^3 (tools/p_sweep.py): the y marching sweep (2 B rows, radius-8 windows) holds up to
-    // in-plane d^2 ~ 64 on an eighth of the voxels; the x marching sweep falls behind the far-field kernel much earlier
-    // (Bernoulli p = 0.003: 1.70 ms against ~0.9 ms), so its threshold is d^2 >= 25 on a sixteenth of the voxels
-    int far_thr[2] = {64, 25};
-    int far_den[2] = {8, 16};
+    // in-plane d^2 ~ 64 on an eighth of the voxels; the x marching sweep falls behind the far-field kernel as soon as its
+    // radius-3 window stops deciding nearly every voxel (Bernoulli p = 0.03: 0.65 ms against 0.55; p = 0.04 and denser:
+    // marching wins), so its threshold is d^2 >= 9 on 1 / 24 of the voxels (p = 0.03: 6 %, p = 0.04: 2.4 %)
+    int far_thr[2] = {64, 9};
+    int far_den[2] = {8, 24};
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
@@ -502,8 +503,9 @@ int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s, uint32_t* res
 
 int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int64_t rows_x, int64_t out_lo, int64_t out_hi,
                       int64_t ny, int64_t nz, double resolution, uint32_t* d_maxdsq, uint32_t* d_uncert, hipStream_t s,
-                      uint32_t* d_fix_needed = nullptr) {
+                      uint32_t* d_fix_needed = nullptr, bool early_out = false) {
     DenseArgs a{};
+    a.early_out = early_out ? 1 : 0;
     a.bits = d_bits; a.out = d_out;
     a.nzw = (int)(nz / 32);
     a.log2_nzw = 0;
@@ -753,7 +755,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         // cannot decide either; otherwise the ball kernel raises it directly and nothing extra is launched
         const bool fix = h->fixup_on && h->fix_mode;
         if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
-                                       h->d_small + 3, s, fix ? h->d_small + 6 : nullptr)) return rc;
+                                       h->d_small + 3, s, fix ? h->d_small + 6 : nullptr, true)) return rc;
         launched_since_mark = true;
         h->guard = h->d_small + 3;
         cur_fix_mode = fix;
@@ -1619,7 +1621,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "far_threshold_y") h->far_thr[0] = value;
     else if (n == "far_threshold_x") h->far_thr[1] = value;
     else if (n == "far_fraction_den_y") h->far_den[0] = value > 0 ? value : 8;
-    else if (n == "far_fraction_den_x") h->far_den[1] = value > 0 ? value : 16;
+    else if (n == "far_fraction_den_x") h->far_den[1] = value > 0 ? value : 24;
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;

@@ -104,6 +104,9 @@ struct DenseArgs {
     uint32_t* unc;          // [out rows][ny][nzw] undecided bits (only written by waves that have some)
     uint32_t* tileflag;     // [tiles] bit w = wave w of the tile wrote its unc words (cleared again by k_ball_fixup)
     uint32_t* fix_needed;
+    // early out (whole-build launches only): once `uncertified` is up the general sweeps will redo the whole grid, so
+    // workgroups that start later return at once -- a far-field scene then costs one wave of workgroups, not the kernel
+    int early_out;
     int checked;            // debugging: take the bounds-checked expansion even for interior tiles
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
 };
@@ -144,6 +147,8 @@ __device__ __forceinline__ uint32_t ball_level_pass(const uint32_t* c0, int hy, 
 template <int BD, bool ZINV>
 __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // (block-uniform; an atomic load: a plain one may be served from a scalar / L1 cache line read before the flag went up)
+    if (a.early_out && __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int nzw = a.nzw, lg = a.log2_nzw;
     const int rwu = nzw + 2;                                  // words used per staged row (edge words replicated)
     // row pitch: a wave reads 64/nzw tile rows at once; pitch = nzw (mod 32) puts them on disjoint banks
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
         mxQ = max(mxQ, __shfl_xor(mxQ, off));
     }
     const bool any_uncert = __any(uncert);
+    const bool all_undecided = __all(row_in_grid && acc[6] == 0u);
     if (any_uncert && a.unc) {
         if (row_in_grid)
             a.unc[((int64_t)(x0 + tx_ - a.out_lo) * a.ny + (y0 + ty_)) * nzw + w] = ~acc[6];
@@ -359,6 +365,8 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
             if (a.unc) {
                 atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up
                 raise_flag(a.fix_needed);
+                // a wave without a single decided voxel sits in empty (or solid) space: nothing for the fix-up kernel
+                if (a.early_out && all_undecided) raise_flag(a.uncertified);
             } else {
                 raise_flag(a.uncertified);
             }
@@ -404,6 +412,10 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
     const uint32_t flags = a.tileflag[tile_id];               // wave-uniform
     if (flags == 0u) return;
+    if (*a.uncertified != 0u) {                               // the general sweeps will redo the grid anyway
+        if (threadIdx.x == 0) a.tileflag[tile_id] = 0u;       // (the flag words stay zero between builds)
+        return;
+    }
     const int t = threadIdx.x;
     const int nzw = a.nzw, lg = a.log2_nzw;
     const int rw = nzw + 2;                                   // one replicated edge word on each side

@@ -43,9 +43,10 @@ constexpr int kDcChunk = 8;           // positions per lane in the chunk phase
 constexpr int kDcBatch = 2;           // staging: row loads in flight per lane (register budget: 128 VGPRs at 4 waves per SIMD)
 constexpr int kDcBrute = 24;          // chunk phase: candidate ranges below this are searched exhaustively
 constexpr int kDcLocalMax = 64;       // pass 0 finishes filled voxels whose in-row squared distance is at most this ...
-constexpr int kDcLocalFilled = 224;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second
-                                      // pass costs as much as the first: at 96 a 1 %-occupied scene ran it on a quarter
-                                      // of its tiles; 224 keeps the list inside the LDS budget of 4 workgroups per CU)
+constexpr int kDcLocalFilled = 448;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second
+                                      // pass costs as much as the first: at 224 a 3 %-occupied scene -- 245 per tile --
+                                      // ran it everywhere, 1.9 instead of 0.57 ms; one packed word per entry keeps 448
+                                      // of them inside the LDS budget of 4 workgroups per CU)
 
 struct EnvDcArgs {
     const int16_t* in16;      // STAGE 2: z field (+-g, 32767 = none); STAGE 3: plane field p16
@@ -97,7 +98,7 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
 
 inline size_t envelope_dc_lds_bytes(int L, int pitch) {
     const int SW = (L + 31) / 32, M = (L + kDcChunk - 1) / kDcChunk;
-    return ((size_t)kDcLines * pitch + (size_t)kDcLines * SW + 64 + 2 * kDcLocalFilled) * 4 + (size_t)kDcLines * (M + 2) * 2;
+    return ((size_t)kDcLines * pitch + (size_t)kDcLines * SW + 64 + kDcLocalFilled) * 4 + (size_t)kDcLines * (M + 2) * 2;
 }
 
 template <int STAGE, int NT>
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
     uint32_t* sgn = keys + kDcLines * pitch;                    // [16][SW]   bit p: voxel p of the line is filled
     uint32_t* span = sgn + kDcLines * SW;                       // [16][2]    first / last site of the line
     uint32_t* flg = span + 32;                                  // [16] line holds a filled voxel, [16] = tile does
-    uint32_t* flist = flg + 32;                                 // [2 * kDcLocalFilled] filled voxels of pass 0: (line << 16 | p), S
-    uint16_t* args = reinterpret_cast<uint16_t*>(flist + 2 * kDcLocalFilled);   // [16][AP]   argmin of coarse position i' (1-based)
+    uint32_t* flist = flg + 32;                                 // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
+    uint16_t* args = reinterpret_cast<uint16_t*>(flist + kDcLocalFilled);   // [16][AP]   argmin of coarse position i' (1-based)
     const int t = threadIdx.x;
 
     // tile of this workgroup.  Four consecutive tiles share cache lines (16 lines x 2 B = 32 B of a 128-B line), so an XCD
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
                                         if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
                                         atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31));
                                         const uint32_t e = atomicAdd(&flg[16], 1u);          // few per tile: list them for the local search
-                                        if (e < (uint32_t)kDcLocalFilled) { flist[2 * e] = ((uint32_t)(4 * sub + k) << 16) | (uint32_t)p; flist[2 * e + 1] = S; }
+                                        if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | min(S, 255u);
                                     }
                                 }
                             }
@@ -508,8 +509,9 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
                     if (t == 0) flg[17] = 1u;
                 } else {
                     for (uint32_t e = (uint32_t)t; e < nf; e += (uint32_t)NT) {
-                        const int fl = (int)(flist[2 * e] >> 16), p = (int)(flist[2 * e] & 0xffffu);
-                        int D1 = (int)flist[2 * e + 1];
+                        const uint32_t ent = flist[e];
+                        const int fl = (int)(ent >> 24), p = (int)((ent >> 8) & 0xffffu);
+                        int D1 = (int)(ent & 0xffu);
                         if (D1 > kDcLocalMax) { flg[17] = 1u; continue; }
                         for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
                             if (p - d >= 0) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(fl, p - d), 0));
