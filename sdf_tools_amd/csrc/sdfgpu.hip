@@ -93,6 +93,7 @@ struct sdfgpu_context {
     // marching wins), so its threshold is d^2 >= 9 on 1 / 24 of the voxels (p = 0.03: 6 %, p = 0.04: 2.4 %)
     int far_thr[2] = {64, 9};
     int far_den[2] = {8, 24};
+    int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
@@ -190,6 +191,17 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
     // persistent row-group loop inside the kernel: 8 workgroups per CU are plenty, and a small grid
     // makes the guard early-exit (dense path certified) a ~2 us launch instead of ~10 us
     dim3 grid((unsigned)std::min<int64_t>(nblocks, 2048)), block(kBlock);
+    if (!d_cells && (nz % 16) == 0 && (reinterpret_cast<uintptr_t>(d_mask) % 16) == 0) {
+        // the persistent grid must fit the device in ONE round: at 70 VGPRs 7 workgroups are resident per CU, and a grid of 8
+        // per CU left 256 workgroups to run their 16 row groups alone after the others had finished
+        if (h->k1_resident <= 0) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep_z_vec16, kBlock, lds) != hipSuccess || per_cu <= 0) per_cu = 4;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) cus = 256;
+            h->k1_resident = per_cu * cus;
+        }
+        grid.x = (unsigned)std::min<int64_t>(nblocks, h->k1_resident);
+    }
     if (d_cells) {
         CellLoader ld{reinterpret_cast<const char*>(d_cells), (int64_t)stride, (int64_t)off, unknown};
         hipLaunchKernelGGL(k_sweep_z_generic<CellLoader>, grid, block, lds, s, ld, d_out, nrows, (int)nz, rpb, h->guard);

@@ -191,29 +191,58 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
     uint32_t* rowcls = reinterpret_cast<uint32_t*>(bm + (size_t)rpb * W);   // [rpb] behind the bitmap
     const int cpr = nz >> 4;                       // 16-voxel chunks per row
     const int spr = W * 4;                         // uint16 slots per row in the bitmap
+    // A lane's slot (row in group, 16-voxel chunk) is the same in every row group when a group is one pass of the
+    // workgroup (always, unless nz > 4096): the two divisions are hoisted out of the loop, and the NEXT group's 16 bytes are
+    // requested before this group's bit searches, so that the HBM round trip runs under them (the kernel sat at 2.2 TB/s
+    // with a quarter of the VALU busy: every group waited for its own load, then for its own stores)
+    const bool one_pass = rpb * spr <= kBlock;
+    const int t = threadIdx.x;
+    const int rA = t / spr, cA = t - rA * spr;     // phase A slot
+    const int rB = t / cpr, cB = t - rB * cpr;     // phase B slot
+    auto fetch = [&](int64_t row0) -> uint4 {
+        if (row0 < nrows && cA < cpr && row0 + rA < nrows && rA < rpb)
+            return *reinterpret_cast<const uint4*>(mask + (row0 + rA) * nz + 16 * cA);
+        return make_uint4(0u, 0u, 0u, 0u);
+    };
+    const int64_t step = (int64_t)gridDim.x * rpb;
+    uint4 vnext = one_pass ? fetch((int64_t)blockIdx.x * rpb) : make_uint4(0u, 0u, 0u, 0u);
     // persistent loop over row groups: a small grid keeps the guard early-exit cheap
-    for (int64_t row0 = (int64_t)blockIdx.x * rpb; row0 < nrows; row0 += (int64_t)gridDim.x * rpb) {
+    for (int64_t row0 = (int64_t)blockIdx.x * rpb; row0 < nrows; row0 += step) {
     const int nr = (int)min((int64_t)rpb, nrows - row0);
     // phase A: pack; per row: does it hold any filled (bit 0) / any free (bit 1) voxel?
     for (int s = threadIdx.x; s < nr; s += kBlock) rowcls[s] = 0u;
     __syncthreads();
-    for (int s = threadIdx.x; s < nr * spr; s += kBlock) {
-        const int r = s / spr, c = s - r * spr;
-        uint32_t bits = 0;
-        if (c < cpr) {
-            const uint4 v = *reinterpret_cast<const uint4*>(mask + (row0 + r) * nz + 16 * c);
-            bits = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) |
-                   (nonzero_bits4(v.w) << 12);
-            const uint32_t cls = (bits != 0u ? 1u : 0u) | (bits != 0xFFFFu ? 2u : 0u);
-            atomicOr(&rowcls[r], cls);        // (no return value: a fire-and-forget ds_or; reading the word first to skip the
+    if (one_pass) {
+        if (t < nr * spr) {
+            uint32_t bits = 0;
+            if (cA < cpr) {
+                const uint4 v = vnext;
+                bits = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) | (nonzero_bits4(v.w) << 12);
+                const uint32_t cls = (bits != 0u ? 1u : 0u) | (bits != 0xFFFFu ? 2u : 0u);
+                atomicOr(&rowcls[rA], cls);   // (no return value: a fire-and-forget ds_or; reading the word first to skip the
                                               //  atomic put an LDS round trip into every lane's pack step: +0.1 ms at 512^3)
+            }
+            bm16[t] = (uint16_t)bits;
         }
-        bm16[s] = (uint16_t)bits;
+        vnext = fetch(row0 + step);
+    } else {
+        for (int s = threadIdx.x; s < nr * spr; s += kBlock) {
+            const int r = s / spr, c = s - r * spr;
+            uint32_t bits = 0;
+            if (c < cpr) {
+                const uint4 v = *reinterpret_cast<const uint4*>(mask + (row0 + r) * nz + 16 * c);
+                bits = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) |
+                       (nonzero_bits4(v.w) << 12);
+                const uint32_t cls = (bits != 0u ? 1u : 0u) | (bits != 0xFFFFu ? 2u : 0u);
+                atomicOr(&rowcls[r], cls);
+            }
+            bm16[s] = (uint16_t)bits;
+        }
     }
     __syncthreads();
     // phase B: nearest opposite bit for 16 voxels per lane
     for (int s = threadIdx.x; s < nr * cpr; s += kBlock) {
-        const int r = s / cpr, c = s - r * cpr;
+        const int r = one_pass ? rB : s / cpr, c = one_pass ? cB : s - (s / cpr) * cpr;
         const uint64_t* row = bm + r * W;
         const int w = c >> 2, sub = c & 3;
         // a row of one class only (most rows of a scene with a few objects in free space): every voxel is "none"
@@ -227,15 +256,40 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
         }
         const uint64_t word = row[w];
         const uint64_t vm = valid_mask(w, nz);
-        const int LF = far_left(row, w, true), LE = far_left(row, w, false);
-        const int RF = far_right(row, w, W, nz, true), RE = far_right(row, w, W, nz, false);
+        // Two running scans over the lane's 16 voxels instead of 16 independent 64-bit bit searches (3x fewer
+        // instructions): left to right carrying the position of the last filled / last free voxel seen, right to left
+        // carrying the next ones.  The carries start from the rest of the word (one clz / ffs per class and side) or,
+        // where that is empty, from the neighbouring words (far_left / far_right: position or -+kFar).
+        const int zb0 = 16 * sub, z0 = 64 * w + zb0;
+        const uint32_t chunk = (uint32_t)(word >> zb0) & 0xFFFFu;
+        const uint64_t lowm = (1ull << zb0) - 1ull;                                   // bits left of the chunk (all valid)
+        const uint64_t higm = sub == 3 ? 0ull : (~0ull << (zb0 + 16));                // bits right of it
+        const uint64_t fl = word & lowm, el = ~word & lowm;
+        const uint64_t fr = word & vm & higm, er = ~word & vm & higm;
+        int lastF = fl ? 64 * w + 63 - __clzll((long long)fl) : far_left(row, w, true);
+        int lastE = el ? 64 * w + 63 - __clzll((long long)el) : far_left(row, w, false);
+        int nextF = fr ? 64 * w + __ffsll((unsigned long long)fr) - 1 : far_right(row, w, W, nz, true);
+        int nextE = er ? 64 * w + __ffsll((unsigned long long)er) - 1 : far_right(row, w, W, nz, false);
+        int dl[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool own = (chunk >> k) & 1u;
+            const int z = z0 + k;
+            dl[k] = z - (own ? lastE : lastF);
+            lastF = own ? z : lastF;
+            lastE = own ? lastE : z;
+        }
         uint32_t pk[8];
 #pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-            const int zb = 16 * sub + k;
-            const int a = z_signed_distance(word, vm, zb, 64 * w + zb, LF, LE, RF, RE);
-            const int b = z_signed_distance(word, vm, zb + 1, 64 * w + zb + 1, LF, LE, RF, RE);
-            pk[k >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+        for (int k = 15; k >= 0; --k) {
+            const bool own = (chunk >> k) & 1u;
+            const int z = z0 + k;
+            const int dr = (own ? nextE : nextF) - z;
+            nextF = own ? z : nextF;
+            nextE = own ? nextE : z;
+            const int d = min(min(dl[k], dr), kInf16);
+            const uint32_t v = (uint32_t)(own ? -d : d) & 0xffffu;
+            if (k & 1) pk[k >> 1] = v << 16; else pk[k >> 1] |= v;
         }
         uint4* dst = reinterpret_cast<uint4*>(out + (row0 + r) * nz + 16 * c);
         dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
