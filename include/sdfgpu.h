@@ -330,7 +330,10 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * envelope sweep per axis on the device inside each build from a probe of the sweep's input, default; 0 = learn
  * it from the previous build on the handle), "far_threshold_y" / "far_fraction_den_y" and "..._x" (an axis counts as
  * far-field when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 64, 8 for the
- * y sweep and 25, 16 for the x sweep). */
+ * y sweep and 9, 24 for the x sweep), "i32_handoff" (1 = when the y probe finds the scene far-field, the x sweep is the
+ * far-field kernel too and takes an exact int32 plane field from the y sweep, default; 0 = 16-bit plane field + side
+ * table between them and a probe of its own for the x axis), "dc_debug" (profiling aid of the far-field kernel: skips
+ * phases, results are then wrong). */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),

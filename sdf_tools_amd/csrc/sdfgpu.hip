@@ -93,6 +93,7 @@ struct sdfgpu_context {
     // marching wins), so its threshold is d^2 >= 9 on 1 / 24 of the voxels (p = 0.03: 6 %, p = 0.04: 2.4 %)
     int far_thr[2] = {64, 9};
     int far_den[2] = {8, 24};
+    bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
@@ -381,6 +382,7 @@ struct DcExtra {                 // slab pipelines: int32 plane fields instead o
     const int32_t* in_i32 = nullptr;
     int32_t* out_i32 = nullptr;
     int64_t y_off = 0, ny_glob = -1;
+    const uint32_t* i32_flag = nullptr;     // device word: use the int32 fields only when it is non-zero (nullptr: always)
 };
 DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz,
                                 int64_t ny_full = -1) {
@@ -421,7 +423,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
         a.y_off = 0; a.ny_glob = ny;
         if (ex) {
-            a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off;
+            a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
         }
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert; a.dbg = h->dc_debug;
@@ -466,9 +468,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
     return SDFGPU_OK;
 }
 
-int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s) {
+int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff = false) {
     hipLaunchKernelGGL(k_decide_tier, dim3(1), dim3(1), 0, s, h->d_small, stage, dense_tried ? 1 : 0, h->force_env,
-                       1, h->far_den[stage]);
+                       1, h->far_den[stage], handoff ? 1 : 0);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -787,7 +789,14 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     HIP_TRY(h, mark(3));
     // y sweep: marching (bounded scan, may raise far_y) + guarded envelope, or the envelope kernel alone
     const uint32_t* const general_guard = h->guard;           // nullptr, or "the dense tier left voxels undecided"
-    auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s); };   // probe counters -> guard words
+    // Both axes far-field (decided by the y probe): the y sweep hands the x sweep exact int32 values in the side-table
+    // buffer (used whole) instead of p16 + side table -- one store / one load per voxel, no saturation handling, and the
+    // x probe is skipped.  d_small[7] carries the choice on the device.
+    const bool handoff = select && h->i32_handoff;
+    DcExtra hand2{}, hand3{};
+    hand2.out_i32 = (int32_t*)h->yzfield.ptr; hand2.i32_flag = h->d_small + 7;
+    hand3.in_i32 = (const int32_t*)h->yzfield.ptr; hand3.i32_flag = h->d_small + 7;
+    auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff); };   // probe counters -> guard words
     if (select) {
         if (h->force_env < 0)
             if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
@@ -807,7 +816,8 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     HIP_TRY(h, mark(4));
     if (envelope && !fused) {
         if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
-                                     nx, ny, nz, resolution, vb, h->d_small, env_y ? h->guard : h->d_small + 4, s)) return rc;
+                                     nx, ny, nz, resolution, vb, h->d_small, env_y ? h->guard : h->d_small + 4, s, 0, nullptr,
+                                     handoff ? &hand2 : nullptr)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(5));
@@ -817,7 +827,8 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (select) {
         if (h->force_env < 0)
             if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
-                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12)) return rc;
+                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12,
+                                         handoff ? &hand3 : nullptr)) return rc;
         if (int rc = decide(1)) return rc;
         h->guard = h->d_small + 10;
         if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
@@ -838,7 +849,8 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     HIP_TRY(h, mark(6));
     if (envelope && !fused) {
         if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
-                                     nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s)) return rc;
+                                     nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s, 0, nullptr,
+                                     handoff ? &hand3 : nullptr)) return rc;
         launched_since_mark = true;
     }
     // one kernel folds the maxima, publishes the status block (device copy for get_extrema, pinned host copy for the
@@ -874,11 +886,6 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     return SDFGPU_OK;
 }
 
-// Faults in the caller's output pages with a few threads while the input travels to the GPU and the kernels run.
-// A device -> host copy into memory that was never touched (a fresh std::vector / numpy array, the normal case
-// behind the reference's API) spends most of its time in single-threaded page faults: measured at 512^3,
-// 512 MiB took 65 ms into fresh pages against 9.6 ms into resident ones.  Only bytes inside [p, p + bytes) are
-// written (one zero per page), and every one of them is overwritten by the result afterwards.
 // Device -> pageable host memory at PCIe rate, for destinations nobody has touched yet (the std::vector / numpy array
 // the reference API returns is fresh: 512^3 floats are 131 072 first-touch page faults, ~40 ms on one thread, and a plain
 // hipMemcpy takes them one by one on the runtime's copy thread).  The DMA lands in two pinned staging chunks of the
@@ -1564,7 +1571,9 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     HIP_TRY(h, hipMemcpy(out_host, h->yzfield.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (h->last_plane16) {
+    uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // status block of the last build ([7]: int32 hand-off used)
+    HIP_TRY(h, hipMemcpy(st, h->d_result, sizeof st, hipMemcpyDeviceToHost));
+    if (h->last_plane16 && st[7] == 0u) {
         // 16-bit pipeline: the int32 buffer is the side table (valid only for saturated groups of 4)
         std::vector<int16_t> p16((size_t)n);
         HIP_TRY(h, hipMemcpy(p16.data(), h->plane16.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
@@ -1619,6 +1628,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "envelope") h->envelope_on = value != 0;
     else if (n == "envelope_dc") h->envelope_dc = value != 0;
     else if (n == "dc_debug") h->dc_debug = value;
+    else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;

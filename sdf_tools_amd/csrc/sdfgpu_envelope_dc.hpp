@@ -75,6 +75,9 @@ struct EnvDcArgs {
     int probe_stride;
     int probe_thr;
     uint32_t* probe_out;
+    // both axes far-field: when *i32_flag != 0 the y sweep hands its result to the x sweep as an exact int32 plane field
+    // (out_i32 / in_i32, the side-table buffer used whole) instead of p16 + side table; nullptr = the pointers alone decide
+    const uint32_t* i32_flag;
     int dbg;                  // profiling aid (wrong results!): bit0 skip upper levels, bit1 skip chunk search, bit2 skip stores,
                               // bit3 skip the second class, bit4 skip key conversion
 };
@@ -110,6 +113,8 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
         const uint32_t gv = *a.guard;
         if ((gv != 0u) == (a.guard_invert != 0)) return;
     }
+    const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
+    if (a.probe_stride > 0 && a.i32_flag && i32) return;       // the x tier is already decided: no probe
     const int L = a.L, B = a.B, pitch = a.pitch, M = a.M, Kp = a.Kp;
     const int SW = (L + 31) >> 5, AP = M + 2;
     const uint32_t mask = (1u << B) - 1u, finf = a.finf;
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
     const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
     const int16_t* const in16 = a.in16 + base;
     const int32_t* const side_in = STAGE == 3 ? a.side_in + base : nullptr;
-    const int32_t* const in32 = (STAGE == 3 && a.in_i32) ? a.in_i32 + base : nullptr;
+    const int32_t* const in32 = (STAGE == 3 && a.in_i32 && i32) ? a.in_i32 + base : nullptr;
 
     // one candidate range for one position: lanes u = 0 .. G-1 of a group take the pairs lo + 2u, lo + 2u + 2G, ...
     // (the second key of the last pair may be candidate hi + 1: it can tie but never beat the range's minimum, and on a
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
         if (probe) { probe_tot += 1; probe_far += D >= a.probe_thr ? 1 : 0; return; }
         const uint32_t oi = (uint32_t)line + (uint32_t)p * ls;
         if constexpr (STAGE == 2) {
-            if (a.out_i32) { (a.out_i32 + base)[oi] = filled ? -D : D; return; }
+            if (a.out_i32 && i32) { (a.out_i32 + base)[oi] = filled ? -D : D; return; }
             (reinterpret_cast<int16_t*>(a.out) + base)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
             if (side) (a.side_out + base)[oi] = filled ? -D : D;
         } else {
@@ -552,13 +557,15 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
 // raised by a marching sweep that hits its scan bound), [8 + 2 stage] guard word of the marching sweep, [12] / [13] the
 // probe's counters.  The marching sweep runs iff the general pipeline is needed at all and the probe found the axis
 // near-field; otherwise the envelope flag is raised and the (flag-guarded) envelope kernel does the sweep.
-__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den) {
+__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff) {
     const bool active = dense_tried ? small[3] != 0u : true;
     const uint32_t far_n = small[12], tot = small[13];
     // far when more than num / den of the sampled voxels need a long scan (64-bit: counts are < 2^24, factors small)
-    const bool far = force >= 0 ? force != 0 : (uint64_t)far_n * (uint64_t)den > (uint64_t)tot * (uint64_t)num;
+    bool far = force >= 0 ? force != 0 : (uint64_t)far_n * (uint64_t)den > (uint64_t)tot * (uint64_t)num;
+    if (stage == 1 && small[7] != 0u) far = true;               // the y probe chose the far-field pair with int32 hand-off
     small[8 + 2 * stage] = (active && !far) ? 1u : 0u;
     if (active && far) small[4 + stage] = 1u;
+    if (stage == 0 && active && far && handoff) small[7] = 1u;
     small[12] = 0u;
     small[13] = 0u;
     small[14 + stage] = tot ? (far_n * 1000u) / tot : 0u;         // per-mille of far voxels in the sample (diagnostics)

@@ -175,15 +175,18 @@ def test_divide_and_conquer_envelope_kernel_is_exact(gpu, shape):
         for name, m in scenes_.items():
             for vb in (False, True):
                 ex, ex_ext, _ = O.exact_sdf(m, 0.05, vb)
-                for dc in (1, 0):
+                # (dc, hand-off): the y sweep hands the x sweep an int32 plane field (default) or p16 + side table
+                for dc, ho in ((1, 1), (1, 0), (0, 1)):
                     gpu.set_option("envelope_dc", dc)
+                    gpu.set_option("i32_handoff", ho)
                     gpu.set_option("envelope_mode", 1)
                     sdf, ext = gpu.build(m, 0.05, vb)
                     bad = np.argwhere(sdf.view(np.uint32) != ex.view(np.uint32))
-                    assert len(bad) == 0, "%s vb=%s dc=%d: %d voxels differ, first %s got %r want %r" % (
-                        name, vb, dc, len(bad), bad[0].tolist(), sdf[tuple(bad[0])], ex[tuple(bad[0])])
-                    assert ext == ex_ext, (name, vb, dc, ext, ex_ext)
+                    assert len(bad) == 0, "%s vb=%s dc=%d handoff=%d: %d voxels differ, first %s got %r want %r" % (
+                        name, vb, dc, ho, len(bad), bad[0].tolist(), sdf[tuple(bad[0])], ex[tuple(bad[0])])
+                    assert ext == ex_ext, (name, vb, dc, ho, ext, ex_ext)
     finally:
         gpu.set_option("envelope_dc", 1)
+        gpu.set_option("i32_handoff", 1)
         gpu.set_option("envelope_mode", 0)
         gpu.set_option("dense", 1)
