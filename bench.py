@@ -47,7 +47,7 @@ B_ALG = {"pack_bits": 1, "dense_ball": 16, "sweep_z": 3, "sweep_y": 6, "sweep_zy
          "envelope_y": 6, "envelope_x": 8}
 B_ALG_TOTAL = 17
 B_COMPULSORY_TOTAL = 5          # mask in + fp32 out
-KERNEL_NAMES = {"envelope_y": "k_envelope_dc<2> / k_envelope<2>", "envelope_x": "k_envelope_dc<3> / k_envelope<3>",
+KERNEL_NAMES = {"envelope_y": "k_envelope_dc<2, 256> / k_envelope<2>", "envelope_x": "k_envelope_dc<3, 256> / k_envelope<3>",
                 "pack_bits": "k_pack_bits_mask", "dense_ball": "k_ball_dense", "sweep_z": "k_sweep_z_vec16",
                 "sweep_y": "k_sweep_march<2,...>", "sweep_zy": "k_sweep_zy_fused",
                 "sweep_x": "k_sweep_march<3,...> / k_sweep_x16"}
@@ -151,8 +151,10 @@ def stage_table(ctx, ms_sum, builds, n_total):
     return info, avg, stage_ms
 
 
-def roofline_of(stage, ms, n_total, plane16, traffic_table=None):
+def roofline_of(stage, ms, n_total, plane16, traffic_table=None, info=None):
     bk = (B_KERNEL16 if plane16 else B_KERNEL32)[stage]
+    if info and info.get("far_y") and info.get("far_x") and stage.startswith("envelope"):
+        bk = B_KERNEL32[stage]      # far-field pair: exact int32 plane field between the two sweeps (4 B/voxel)
     achieved = n_total * bk / (ms * 1e-3) / 1e9
     tr = (traffic_table or {}).get(stage) if n_total == 512 ** 3 else None
     r = {"bound": "hbm", "kernel": KERNEL_NAMES[stage], "stage": stage,
@@ -222,7 +224,7 @@ def run_leg(torch, capi, dev, shape, res, masks, opts, steps, warmup, label):
            "kernels": info, "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "extrema": list(ctx.get_extrema())}
     if stage_ms:
         dom = max(stage_ms, key=stage_ms.get)
-        leg["roofline"] = roofline_of(dom, stage_ms[dom], n_total, info["plane16"], load_traffic())
+        leg["roofline"] = roofline_of(dom, stage_ms[dom], n_total, info["plane16"], load_traffic(), info)
     ctx.close()
     return leg
 
@@ -267,7 +269,7 @@ def streaming_leg(torch, dev, n, res, frames):
            "kernels": info, "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "extrema": list(st.extrema())}
     if stage_ms:
         dom = max(stage_ms, key=stage_ms.get)
-        leg["roofline"] = roofline_of(dom, stage_ms[dom], n ** 3, info["plane16"], load_traffic())
+        leg["roofline"] = roofline_of(dom, stage_ms[dom], n ** 3, info["plane16"], load_traffic(), info)
     st.ctx.close()
     return leg
 
@@ -445,7 +447,7 @@ def main():
             if info["dense_certified"]:
                 result["config"]["guarded_general_pipeline_ms"] = round(sum(avg[2:]), 4)
             dom = max(stage_ms, key=stage_ms.get)
-            r = roofline_of(dom, stage_ms[dom], n_total, info["plane16"], load_traffic())
+            r = roofline_of(dom, stage_ms[dom], n_total, info["plane16"], load_traffic(), info)
             r["stages_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
             r["note"] = ("frac = compulsory bytes of this kernel (bytes_per_voxel x voxels) / HIP-event duration / peak; "
                          "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json)")

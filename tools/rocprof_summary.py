@@ -22,7 +22,7 @@ def find(dirname, pattern):
 
 
 def short(name):
-    for key, label in (("k_envelope_dc<2>", "envelope_y"), ("k_envelope_dc<3>", "envelope_x"),
+    for key, label in (("k_envelope_dc<2", "envelope_y"), ("k_envelope_dc<3", "envelope_x"),
                        ("k_envelope_dcILi2", "envelope_y"), ("k_envelope_dcILi3", "envelope_x"),
                        ("k_envelope<2>", "envelope_y_gen1"), ("k_envelope<3>", "envelope_x_gen1"),
                        ("k_pack_bits", "pack_bits"), ("k_ball_dense", "dense_ball"), ("k_sweep_zy_fused", "sweep_zy"),
