@@ -478,7 +478,8 @@ int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, b
 // K0 + KD: pack to bits, then the bit-parallel ball kernel (sdfgpu_dense.hpp)
 bool dense_eligible(const sdfgpu_context* h, int64_t nz, int vb) {
     const int64_t nzw = nz / 32;
-    return h->dense_on && !vb && (nz % 32) == 0 && nzw >= 1 && nzw <= 64 && (nzw & (nzw - 1)) == 0;
+    (void)vb;                                     // (the tuned ball kernel folds the virtual border itself)
+    return h->dense_on && (nz % 32) == 0 && nzw >= 1 && nzw <= 64 && (nzw & (nzw - 1)) == 0;
 }
 
 int launch_pack_bits(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, size_t stride, size_t off, int unknown,
@@ -517,9 +518,10 @@ int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s, uint32_t* res
 
 int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int64_t rows_x, int64_t out_lo, int64_t out_hi,
                       int64_t ny, int64_t nz, double resolution, uint32_t* d_maxdsq, uint32_t* d_uncert, hipStream_t s,
-                      uint32_t* d_fix_needed = nullptr, bool early_out = false) {
+                      uint32_t* d_fix_needed = nullptr, bool early_out = false, int vb = 0, int64_t nx_glob = 0) {
     DenseArgs a{};
     a.early_out = early_out ? 1 : 0;
+    a.vb = vb; a.nx_glob = (int)nx_glob;
     a.bits = d_bits; a.out = d_out;
     a.nzw = (int)(nz / 32);
     a.log2_nzw = 0;
@@ -767,9 +769,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         HIP_TRY(h, mark(1));
         // fix-up mode (policy): undecided voxels go to the fix-up kernel, which raises `uncertified` only for what it
         // cannot decide either; otherwise the ball kernel raises it directly and nothing extra is launched
-        const bool fix = h->fixup_on && h->fix_mode;
+        // (with a virtual border the fix-up kernel stays out: a voxel it would finish may still be bound by b >= 3)
+        const bool fix = h->fixup_on && h->fix_mode && !vb;
         if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
-                                       h->d_small + 3, s, fix ? h->d_small + 6 : nullptr, true)) return rc;
+                                       h->d_small + 3, s, fix ? h->d_small + 6 : nullptr, true, vb, nx)) return rc;
         launched_since_mark = true;
         h->guard = h->d_small + 3;
         cur_fix_mode = fix;

@@ -107,6 +107,10 @@ struct DenseArgs {
     // early out (whole-build launches only): once `uncertified` is up the general sweeps will redo the whole grid, so
     // workgroups that start later return at once -- a far-field scene then costs one wave of workgroups, not the kernel
     int early_out;
+    // virtual border (sdf_generation.hpp:287-419, net effect D <- min(D, b^2), b = axis distance to the padded layer over the
+    // axes with more than one cell): inside the ball only b = 1 and b = 2 can bind, folded into levels 0 and 3
+    int vb;
+    int nx_glob;            // x extent of the whole grid (buffer plane 0 = grid plane 0 in this mode)
     int checked;            // debugging: take the bounds-checked expansion even for interior tiles
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
 };
@@ -252,6 +256,18 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
         });
     }
 
+    if (a.vb) {                                               // (block-uniform)
+        int bxy = 1 << 20;
+        const int gx = x0 + tx_, gy = y0 + ty_;
+        if (a.nx_glob > 1) bxy = min(bxy, min(gx + 1, a.nx_glob - gx));
+        if (a.ny > 1) bxy = min(bxy, min(gy + 1, a.ny - gy));
+        uint32_t b1 = bxy == 1 ? ~0u : 0u, b2 = bxy <= 2 ? ~0u : 0u;
+        // (nz = 32 nzw >= 32: the first / last voxel of the row are bit 0 of word 0 / bit 31 of the last word)
+        if (w == 0) { b1 |= 1u; b2 |= 3u; }
+        if (w == nzw - 1) { b1 |= 0x80000000u; b2 |= 0xC0000000u; }
+        acc[0] |= b1; acc[1] |= b1; acc[2] |= b1;
+        acc[3] |= b2; acc[4] |= b2; acc[5] |= b2; acc[6] |= b2;
+    }
     // extrema (max d^2 per class) and certification, per word
     int mxF = 0, mxQ = 0;
     {

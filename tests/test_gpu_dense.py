@@ -115,9 +115,10 @@ def test_collision_cells_take_the_dense_path(gpu):
         assert np.array_equal(got, want) and ext == want_ext
 
 
-def test_virtual_border_takes_the_generic_dense_kernel(gpu):
-    """add_virtual_border (sdf_generation.hpp:287-419) folds into the ball: b^2 = 1 and 4 are levels 0 and 3."""
-    for shape in ((8, 8, 32), (64, 64, 64), (20, 17, 45), (1, 30, 70)):
+def test_virtual_border_folds_into_the_dense_tier(gpu):
+    """add_virtual_border (sdf_generation.hpp:287-419) folds into the ball: b^2 = 1 and 4 are levels 0 and 3.  Shapes
+    with nz = 32 * 2^k take the tuned kernel (thin grids: an axis of one cell has no border), the others the generic one."""
+    for shape in ((8, 8, 32), (64, 64, 64), (2, 5, 64), (1, 9, 32), (3, 1, 128), (40, 33, 256), (20, 17, 45), (1, 30, 70)):
         m = synth.bernoulli_mask(shape, 0.5, 1)
         sdf, ext = gpu.build(m, 1.0, True)
         assert gpu.last_build_info()["dense"] and gpu.last_dense_certified()
@@ -125,6 +126,13 @@ def test_virtual_border_takes_the_generic_dense_kernel(gpu):
         assert np.array_equal(sdf, ex) and ext == ex_ext
         ref, ref_ext = O.reference_sdf(m, 1.0, True)       # the reference's pad-twice-and-combine, bit for bit
         assert np.array_equal(sdf, ref) and ext == ref_ext
+    # almost dense + virtual border, repeated builds (the fix-up kernel stays out of virtual-border builds), then sparse
+    for p in (0.1, 0.03):
+        m = synth.bernoulli_mask((48, 40, 64), p, 7)
+        ex, ex_ext, _ = O.exact_sdf(m, 0.5, True)
+        for _ in range(3):
+            sdf, ext = gpu.build(m, 0.5, True)
+            assert np.array_equal(sdf, ex) and ext == ex_ext, p
     # one class only + virtual border: voxels deeper than 2 layers are not decided by the ball -> general pipeline
     for fill in (0, 1):
         m = np.full((12, 10, 40), fill, np.uint8)
