@@ -44,7 +44,7 @@ protected:
 
     std::pair<SignedDistanceField, std::pair<double, double>> BuildWithFilter(
         const float oob_value, const int object_mode, const std::vector<uint32_t>& ids, const bool unknown_is_filled,
-        const bool add_virtual_border) const {
+        const bool add_virtual_border, const bool cells_on_device = false) const {
         const Eigen::Vector3d cell_sizes = GetCellSizes();
         if ((cell_sizes.x() != cell_sizes.y()) || (cell_sizes.x() != cell_sizes.z()))
             throw std::invalid_argument("Grid must have uniform resolution");
@@ -53,7 +53,7 @@ protected:
         double max_distance = 0.0, min_distance = 0.0;
         sdfgpu_handle h = sdf_generation::GpuContext::Get();
         sdf_generation::ThrowOnStatus(
-            h, sdfgpu_build_tagged_cells(h, data_.data(), sizeof(TAGGED_OBJECT_COLLISION_CELL),
+            h, sdfgpu_build_tagged_cells(h, cells_on_device ? nullptr : data_.data(), sizeof(TAGGED_OBJECT_COLLISION_CELL),
                                          offsetof(TAGGED_OBJECT_COLLISION_CELL, occupancy),
                                          offsetof(TAGGED_OBJECT_COLLISION_CELL, object_id), object_mode,
                                          ids.empty() ? nullptr : ids.data(), (int64_t)ids.size(), unknown_is_filled ? 1 : 0,
@@ -105,7 +105,8 @@ public:
     std::pair<SignedDistanceField, std::pair<double, double>> ExtractFreeAndNamedObjectsSignedDistanceField(
         const float oob_value, const bool unknown_is_filled) const {
         const auto free_sdf_result = BuildWithFilter(oob_value, 0, {}, unknown_is_filled, false);
-        const auto named_objects_sdf_result = BuildWithFilter(oob_value, 1, {}, unknown_is_filled, false);
+        // (same records as the call above: they are still on the device)
+        const auto named_objects_sdf_result = BuildWithFilter(oob_value, 1, {}, unknown_is_filled, false, true);
         SignedDistanceField combined_sdf = free_sdf_result.first;
         const std::vector<float>& fr = free_sdf_result.first.GetImmutableRawData();
         const std::vector<float>& nm = named_objects_sdf_result.first.GetImmutableRawData();
@@ -122,10 +123,13 @@ public:
     std::map<uint32_t, SignedDistanceField> MakeObjectSDFs(const std::vector<uint32_t>& object_ids, const bool unknown_is_filled,
                                                            const bool add_virtual_border) const {
         std::map<uint32_t, SignedDistanceField> per_object_sdfs;
-        for (const uint32_t object_id : object_ids)
-            per_object_sdfs[object_id] = ExtractSignedDistanceField(std::numeric_limits<float>::infinity(),
-                                                                    std::vector<uint32_t>{object_id}, unknown_is_filled,
-                                                                    add_virtual_border).first;
+        bool uploaded = false;                  // the cell records travel once; every further object re-uses the device copy
+        for (const uint32_t object_id : object_ids) {
+            per_object_sdfs[object_id] = BuildWithFilter(std::numeric_limits<float>::infinity(), 2,
+                                                         std::vector<uint32_t>{object_id}, unknown_is_filled,
+                                                         add_virtual_border, uploaded).first;
+            uploaded = true;
+        }
         return per_object_sdfs;
     }
 

@@ -101,7 +101,11 @@ int sdfgpu_build_cells(sdfgpu_handle h, const void* cells,
  *   object_mode 2: object_id in object_ids[0..n) (ExtractSignedDistanceField(objects_to_use) :817-827;
  *                                                 n == 0 means any object, like :826)
  * object_ids may hold any number of ids in any order (a sorted copy is searched on the device).
- * Classified on the device, then the same build as sdfgpu_build. */
+ * Classified on the device, then the same build as sdfgpu_build.
+ * cells may be NULL: the records uploaded by the previous sdfgpu_build_tagged_cells call on this handle are used again
+ * (same nx * ny * nz * cell_stride, no other host-buffer entry point on the handle in between; INVALID_ARGUMENT
+ * otherwise).  A caller that builds one field per object (MakeObjectSDFs :875-891, one call per id) then sends the
+ * 16 B/voxel records over PCIe once instead of once per object. */
 int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells,
                               size_t cell_stride, size_t occupancy_offset, size_t object_id_offset,
                               int object_mode, const uint32_t* object_ids, int64_t n_object_ids,

@@ -169,16 +169,19 @@ class SdfGpu:
 
     def build_tagged_cells(self, cells, shape, object_mode=0, object_ids=(), unknown_is_filled=False, resolution=1.0,
                            add_virtual_border=False, cell_stride=16, occupancy_offset=0, object_id_offset=8):
-        """cells: raw TAGGED_OBJECT_COLLISION_CELL records; object_mode 0 any / 1 named (id > 0) / 2 id list."""
-        c = np.ascontiguousarray(cells)
+        """cells: raw TAGGED_OBJECT_COLLISION_CELL records; object_mode 0 any / 1 named (id > 0) / 2 id list.
+        cells=None re-uses the records the previous call on this context uploaded (one field per object: upload once)."""
         nx, ny, nz = (int(s) for s in shape)
-        if c.nbytes != nx * ny * nz * cell_stride:
-            raise ValueError("cells buffer size does not match shape * cell_stride")
+        c = None
+        if cells is not None:
+            c = np.ascontiguousarray(cells)
+            if c.nbytes != nx * ny * nz * cell_stride:
+                raise ValueError("cells buffer size does not match shape * cell_stride")
         ids = np.ascontiguousarray(np.asarray(object_ids, dtype=np.uint32))
         out = np.empty((nx, ny, nz), dtype=np.float32)
         ext = (ctypes.c_double * 2)()
         self._check(self._lib.sdfgpu_build_tagged_cells(
-            self._h, c.ctypes.data, cell_stride, occupancy_offset, object_id_offset, int(object_mode),
+            self._h, c.ctypes.data if c is not None else None, cell_stride, occupancy_offset, object_id_offset, int(object_mode),
             ids.ctypes.data if ids.size else None, int(ids.size), int(bool(unknown_is_filled)), nx, ny, nz,
             float(resolution), int(bool(add_virtual_border)), out.ctypes.data, ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
         return out, (float(ext[0]), float(ext[1]))

@@ -56,6 +56,7 @@ struct sdfgpu_context {
     DeviceBuffer tagids;     // uint32 object id filter
     DeviceBuffer stage_in;   // host-API staging: mask / cells
     DeviceBuffer stage_out;  // host-API staging: sdf
+    size_t tag_cached_bytes = 0;            // stage_in holds the tagged cell records of the last sdfgpu_build_tagged_cells call
     void* pin[2] = {nullptr, nullptr};      // pinned host staging of copy_to_host (two chunks in flight)
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] uncertified, [4] far_y, [5] far_x
@@ -1033,6 +1034,7 @@ int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, s
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nx * ny * nz;
     const size_t in_bytes = cells ? (size_t)n * stride : (size_t)n;
+    h->tag_cached_bytes = 0;                        // (stage_in is about to be overwritten)
     if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
     if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
     const bool timing = getenv("SDFGPU_HOST_TIMING") != nullptr;
@@ -1401,7 +1403,7 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
                               int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
                               int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
-    if (!cells || !out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
+    if (!out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
     if (cell_stride < 8 || (cell_stride % 4) || (occupancy_offset % 4) || (object_id_offset % 4) ||
         occupancy_offset + 4 > cell_stride || object_id_offset + 4 > cell_stride)
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell layout must be 4-byte aligned and in range");
@@ -1412,11 +1414,20 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
     if (int rc = check_dims(h, nx, ny, nz)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nx * ny * nz;
-    if (int rc = ensure(h, h->stage_in, (size_t)n * cell_stride)) return rc;
+    if (!cells) {                                  // the records of the previous call on this handle, still on the device
+        if (h->tag_cached_bytes == 0 || h->tag_cached_bytes != (size_t)n * cell_stride)
+            return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cells is null and the handle holds no cell records of this size");
+    } else {
+        h->tag_cached_bytes = 0;
+        if (int rc = ensure(h, h->stage_in, (size_t)n * cell_stride)) return rc;
+    }
     if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
     if (int rc = ensure(h, h->tagmask, (size_t)n)) return rc;
     if (int rc = ensure(h, h->tagids, (size_t)std::max<int64_t>(n_object_ids, 1) * 4)) return rc;
-    if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells, (size_t)n * cell_stride)) return rc0;
+    if (cells) {
+        if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells, (size_t)n * cell_stride)) return rc0;
+        h->tag_cached_bytes = (size_t)n * cell_stride;
+    }
     if (n_object_ids > 0) {                        // sorted copy: the classify kernel binary-searches it
         std::vector<uint32_t> sorted_ids(object_ids, object_ids + n_object_ids);
         std::sort(sorted_ids.begin(), sorted_ids.end());
@@ -1515,6 +1526,7 @@ int sdfgpu_gradient(sdfgpu_handle h, const float* sdf, int64_t nx, int64_t ny, i
     const int64_t plane = ny * nz;
     const int64_t max_rows = std::max<int64_t>(1, ((int64_t)1 << 26) / std::max<int64_t>(plane, 1));   // <= 64 Mi voxels per chunk
     const int64_t rows = std::min<int64_t>(nx, max_rows);
+    h->tag_cached_bytes = 0;
     if (int rc = ensure(h, h->stage_in, (size_t)(rows + 2) * plane * 4)) return rc;
     if (int rc = ensure(h, h->stage_out, (size_t)(rows + 2) * plane * 3 * esz)) return rc;
     (void)n;

@@ -117,6 +117,19 @@ def test_tagged_object_cells_match_oracle_per_filter():
                 want, want_ext, _ = O.exact_sdf(mask.astype(np.uint8), 0.25, vb)
                 np.testing.assert_array_equal(got, want)
                 assert ext == tuple(float(v) for v in want_ext)
+                # cells = NULL: the records of the call above are still on the device (MakeObjectSDFs uploads once)
+                again, ext2 = g.build_tagged_cells(None, shape, object_mode=mode, object_ids=ids, unknown_is_filled=unknown,
+                                                   resolution=0.25, add_virtual_border=vb)
+                np.testing.assert_array_equal(again, want)
+                assert ext2 == ext
+    # no records of that size on the handle: refused, and the handle stays usable
+    with pytest.raises(capi.SdfGpuError):
+        g.build_tagged_cells(None, (8, 8, 8))
+    g.build(np.zeros((8, 8, 32), np.uint8))                   # another host-buffer entry point takes the staging buffer
+    with pytest.raises(capi.SdfGpuError):
+        g.build_tagged_cells(None, shape)
+    got, _ = g.build_tagged_cells(cells, shape, object_mode=1)
+    np.testing.assert_array_equal(got, O.exact_sdf(((cells["occupancy"] > 0.5) & (cells["object_id"] > 0)).astype(np.uint8), 1.0)[0])
 
 
 def test_cell_predicate_overload_matches_oracle():
