@@ -51,6 +51,14 @@ while time.time() - t0 < budget:
         ctx.set_option(k, v)
     if rng.random() < 0.3:
         ctx.set_option("fixup_mode", 1)                 # force the fix-up kernel behind the dense ball kernel
+    # tier selection: fresh decisions, forced far-field sweeps, both hand-off forms, low thresholds (far-field kernel on
+    # scenes the marching kernels would normally take)
+    if rng.random() < 0.5:
+        ctx.set_option("policy_reset", 1)
+    ctx.set_option("i32_handoff", int(rng.integers(0, 2)))
+    ctx.set_option("envelope_mode", 1 if rng.random() < 0.2 else 0)
+    ctx.set_option("far_threshold_y", int(rng.choice([1, 4, 64])))
+    ctx.set_option("far_threshold_x", int(rng.choice([1, 9, 25])))
     got, ext = ctx.build(m, res, vb)
     want, want_ext, _ = O.exact_sdf(m, res, vb)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
