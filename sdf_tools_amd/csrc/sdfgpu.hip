@@ -1501,11 +1501,15 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
     sc.inv2f = (float)sc.inv2;
     if (out_is_f64)
         hipLaunchKernelGGL(k_gradient<double>, grid, block, 0, s, d_sdf, (double*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
-    else if ((nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_sdf) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out_grad) % 16) == 0) {
+    else if ((nz % 4) == 0 && ny * (nz / 4) < ((int64_t)1 << 31) - kBlock &&
+             (reinterpret_cast<uintptr_t>(d_sdf) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_out_grad) % 16) == 0) {
         const bool f32scale = (double)sc.inv2f == sc.inv2 && std::isfinite(sc.inv2) && std::fabs(sc.inv2) < 1e30 && std::fabs(sc.inv2) > 1e-30;
-        const dim3 g4((unsigned)((n / 4 + kBlock - 1) / kBlock));
-        if (f32scale) hipLaunchKernelGGL(k_gradient_f32x4<true>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
-        else hipLaunchKernelGGL(k_gradient_f32x4<false>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
+        const int64_t per_plane = ny * (nz / 4);                                  // groups of 4 voxels per x plane
+        const dim3 g4((unsigned)((per_plane + kBlock - 1) / kBlock), (unsigned)std::min<int64_t>(nx, 65535));
+        int gshift = -1;                                                           // log2(nz / 4) when that is a power of two
+        for (int b = 0; b < 31; ++b) if (((int64_t)1 << b) == nz / 4) gshift = b;
+        if (f32scale) hipLaunchKernelGGL(k_gradient_f32x4<true>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients, gshift);
+        else hipLaunchKernelGGL(k_gradient_f32x4<false>, g4, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients, gshift);
     } else
         hipLaunchKernelGGL(k_gradient<float>, grid, block, 0, s, d_sdf, (float*)d_out_grad, nx, ny, nz, sc, enable_edge_gradients);
     HIP_TRY(h, hipGetLastError());

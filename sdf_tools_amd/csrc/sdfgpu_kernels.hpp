@@ -741,20 +741,27 @@ __global__ __launch_bounds__(kBlock) void k_gradient(const float* __restrict__ f
 // instructions (no conversions, no fp64 multiply).
 template <bool F32SCALE>
 __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restrict__ f, float* __restrict__ g,
-                                                          int64_t nx, int64_t ny, int64_t nz, const GradScale sc, int edge) {
+                                                          int64_t nx, int64_t ny, int64_t nz, const GradScale sc, int edge,
+                                                          int gshift) {
     // A lane's 4 voxels give 12 consecutive floats (48 B).  Written straight from the lane, every store instruction
     // would touch 64 x 16 B at a 48 B stride (24 cache lines instead of 8); the wave's 3 KiB are therefore transposed
     // through LDS so that each of the 3 store instructions writes one contiguous 1 KiB.
     __shared__ __attribute__((aligned(16))) float stage[(kBlock / 64) * 64 * 12];
-    const int64_t n4 = nx * ny * nz / 4;
     // (tried in round 2, no gain at 512^3: an XCD-contiguous workgroup order and non-temporal stores)
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    // Grid: blockIdx.y walks the x planes, blockIdx.x the groups of 4 voxels inside a plane -- one 32-bit division (a shift
+    // when nz / 4 is a power of two) per lane instead of three 64-bit ones, which were ~250 of the kernel's ~350
+    // instructions per lane and kept it off the memory roofline (0.49 -> 0.43 ms at 512^3).
+    const uint32_t G = (uint32_t)(nz >> 2);                      // groups per z row
+    const uint32_t P = (uint32_t)ny * G;                         // groups per x plane (the launcher checks the range)
     const int lane = threadIdx.x & 63;
     float* st = stage + (threadIdx.x >> 6) * (64 * 12);
-    if (q < n4) {
-        const int64_t i = 4 * q;
-        const int64_t z = i % nz, y = (i / nz) % ny, x = i / (nz * ny);
+    for (int64_t x = blockIdx.y; x < nx; x += gridDim.y) {       // (more than one pass only when nx > 65535)
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;        // group inside the plane
+    if (r < P) {
+        const uint32_t yy = gshift >= 0 ? r >> gshift : r / G;
+        const int64_t y = yy, z = (int64_t)(r - yy * G) * 4;
         const int64_t sx = ny * nz, sy = nz;
+        const int64_t i = x * sx + (int64_t)r * 4;
         float o[12];
         if (x > 0 && x < nx - 1 && y > 0 && y < ny - 1) {
             // x and y interior.  A group on a z face (z == 0 or z + 4 == nz: one lane of EVERY wave at nz = 512) still takes
@@ -800,12 +807,36 @@ __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restri
                     o[11] = edge ? (float)(((double)c.w - (double)c.z) * sc.inv_w1) : (float)nan;
                 }
             }
-        } else {                                  // rows on an x or y face of the grid: four independent per-voxel chains
+        } else if (!edge) {                       // rows on an x or y face: boundary shell, no edge gradients (:464)
+            const float nanf = (float)__builtin_nan("");
+#pragma unroll
+            for (int k = 0; k < 12; ++k) o[k] = nanf;
+        } else {
+            // rows on an x or y face of the grid: every voxel of the group is on the boundary shell (:464-512) -- clamped
+            // neighbour indices, double subtraction, interval of 1 or 2 cells per axis (0: singleton axis, gradient 0).
+            // Same five 16-byte row loads as the interior path with the out-of-grid neighbour replaced by the row itself:
+            // whole waves take this path (a row is 128 lanes at nz = 512), and the per-voxel form (gradient_one: six scalar
+            // loads per voxel behind index arithmetic) made the 0.8 % of waves on the faces cost 15 % of the kernel.
+            const int64_t dxl = x > 0 ? sx : 0, dxh = x < nx - 1 ? sx : 0;
+            const int64_t dyl = y > 0 ? sy : 0, dyh = y < ny - 1 ? sy : 0;
+            const int wx = (x > 0 ? 1 : 0) + (x < nx - 1 ? 1 : 0), wy = (y > 0 ? 1 : 0) + (y < ny - 1 ? 1 : 0);
+            const double kx = wx == 2 ? sc.inv_w2 : (wx == 1 ? sc.inv_w1 : 0.0);
+            const double ky = wy == 2 ? sc.inv_w2 : (wy == 1 ? sc.inv_w1 : 0.0);
+            const float4 c = *reinterpret_cast<const float4*>(f + i);
+            const float4 xp = *reinterpret_cast<const float4*>(f + i + dxh), xm = *reinterpret_cast<const float4*>(f + i - dxl);
+            const float4 yp = *reinterpret_cast<const float4*>(f + i + dyh), ym = *reinterpret_cast<const float4*>(f + i - dyl);
+            const float zm = z > 0 ? f[i - 1] : c.x, zp = z + 4 < nz ? f[i + 4] : c.w;
+            const float cz[6] = {zm, c.x, c.y, c.z, c.w, zp};
+            const float xpv[4] = {xp.x, xp.y, xp.z, xp.w}, xmv[4] = {xm.x, xm.y, xm.z, xm.w};
+            const float ypv[4] = {yp.x, yp.y, yp.z, yp.w}, ymv[4] = {ym.x, ym.y, ym.z, ym.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                double v[3];
-                gradient_one(f, i + k, x, y, z + k, nx, ny, nz, sc, edge, v);
-                o[3 * k] = (float)v[0]; o[3 * k + 1] = (float)v[1]; o[3 * k + 2] = (float)v[2];
+                const bool lo = z + k > 0, hi = z + k < nz - 1;
+                const double kz = (lo && hi) ? sc.inv_w2 : ((lo || hi) ? sc.inv_w1 : 0.0);
+                const float zl = lo ? cz[k] : cz[k + 1], zh = hi ? cz[k + 2] : cz[k + 1];
+                o[3 * k + 0] = wx ? (float)(((double)xpv[k] - (double)xmv[k]) * kx) : 0.0f;     // (inf - inf on a singleton axis)
+                o[3 * k + 1] = wy ? (float)(((double)ypv[k] - (double)ymv[k]) * ky) : 0.0f;
+                o[3 * k + 2] = (float)(((double)zh - (double)zl) * kz);
             }
         }
         float4* d = reinterpret_cast<float4*>(st + lane * 12);
@@ -814,15 +845,17 @@ __global__ __launch_bounds__(kBlock) void k_gradient_f32x4(const float* __restri
         d[2] = make_float4(o[8], o[9], o[10], o[11]);
     }
     __syncthreads();
-    const int64_t q0 = q - lane;                                     // first group of this wave
-    if (q0 < n4) {
-        const int valid = (int)min((int64_t)64, n4 - q0) * 12;       // floats this wave produced (multiple of 4)
-        float* dst = g + 12 * q0;
+    const uint32_t r0 = r - (uint32_t)lane;                          // first group of this wave
+    if (r0 < P) {
+        const int valid = (int)min(64u, P - r0) * 12;                // floats this wave produced (multiple of 4)
+        float* dst = g + 3 * (x * ny * nz + (int64_t)r0 * 4);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int idx = k * 256 + lane * 4;
             if (idx < valid) *reinterpret_cast<float4*>(dst + idx) = *reinterpret_cast<const float4*>(st + idx);
         }
+    }
+    __syncthreads();                                                 // (the staging area is reused by the next plane)
     }
 }
 

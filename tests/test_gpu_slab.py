@@ -260,8 +260,10 @@ def test_gradient_matches_reference_definition(gpu):
     assert np.all(np.isnan(got2[0])) and np.all(np.isnan(got2[:, :, -1]))
     # fp32 output (vectorised kernel when nz % 4 == 0) == fp64 output narrowed once
     # (res = 0.25, 0.01: 1 / (2 res) is an fp32 number -> the kernel scales in fp32; 0.03, 0.007: fp64 scale)
-    for shp in ((10, 9, 16), (3, 5, 8), (12, 9, 10), (1, 7, 12), (40, 33, 64)):
+    for shp in ((10, 9, 16), (3, 5, 8), (12, 9, 10), (1, 7, 12), (40, 33, 64), (1, 6, 8), (2, 1, 16), (5, 2, 4)):
         mm = synth.bernoulli_mask(shp, 0.3, 4)
+        if shp == (1, 6, 8):
+            mm[:] = 0                              # all free: +inf everywhere (inf - inf = NaN, but 0 on the singleton axis)
         for r2 in (res, 0.01, 0.03, 0.007):
             ss, _ = gpu.build(mm, r2)
             ft = torch.from_numpy(ss).cuda()
