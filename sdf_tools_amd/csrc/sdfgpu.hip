@@ -418,8 +418,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         EnvDcArgs a{};
         a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
         int64_t ntiles;
-        if (stage == 2) { ntiles = nx * (nz / kDcLines); a.tiles_per_outer = nz / kDcLines; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
-        else { ntiles = ny * nz / kDcLines; a.tiles_per_outer = ntiles; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
+        constexpr int NL = kDcLines;                            // lines per tile
+        if (stage == 2) { ntiles = nx * (nz / NL); a.tiles_per_outer = nz / NL; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
+        else { ntiles = ny * nz / NL; a.tiles_per_outer = ntiles; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
         a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = g.Kp;
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
         a.y_off = 0; a.ny_glob = ny;
@@ -435,20 +436,22 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.probe_out = probe_out;
             ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
             // the sampled tile index b * stride + (7 b mod stride) must stay inside the grid: drop the last block if needed
-            const int64_t all = stage == 2 ? nx * (nz / kDcLines) : ny * nz / kDcLines;
+            const int64_t all = stage == 2 ? nx * (nz / NL) : ny * nz / NL;
             while (ntiles > 0 && (ntiles - 1) * a.probe_stride + ((ntiles - 1) * 7) % a.probe_stride >= all) --ntiles;
             if (ntiles == 0) return SDFGPU_OK;
         }
-        const size_t lds = envelope_dc_lds_bytes(a.L, a.pitch);
-        // (workgroups of 512 lanes at the same LDS footprint would double the waves per SIMD, but the kernel needs ~120 VGPRs:
-        //  at the 64 that leaves it spills and runs 1.2 - 2.3x slower, measured)
-        const void* fn = stage == 2 ? (const void*)k_envelope_dc<2, 256> : (const void*)k_envelope_dc<3, 256>;
+        const size_t lds = envelope_dc_lds_bytes(a.L, a.pitch, NL);
+        // Measured alternatives to 16 lines x 256 lanes (4 workgroups = 16 waves per CU, ~120 VGPRs, 38 KB of LDS):
+        //   512 lanes on 16 lines (8 waves per SIMD): needs <= 64 VGPRs, spills, 1.2 - 2.3x slower;
+        //   8 lines x 128 lanes (7 workgroups per CU, the same waves per SIMD, more independent chains): 7 - 18 % slower --
+        //   the per-tile work of the levels is amortised over fewer voxels and the row segments halve (16 / 32 B).
+        const void* fn = stage == 2 ? (const void*)k_envelope_dc<2, kDcLines> : (const void*)k_envelope_dc<3, kDcLines>;
         if (lds > 64 * 1024 && !h->dc_lds_attr[stage - 2]) {
             HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             h->dc_lds_attr[stage - 2] = true;
         }
-        if (stage == 2) hipLaunchKernelGGL((k_envelope_dc<2, 256>), dim3((unsigned)ntiles), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((k_envelope_dc<3, 256>), dim3((unsigned)ntiles), dim3(256), lds, s, a);
+        if (stage == 2) hipLaunchKernelGGL((k_envelope_dc<2, kDcLines>), dim3((unsigned)ntiles), dim3(16 * kDcLines), lds, s, a);
+        else hipLaunchKernelGGL((k_envelope_dc<3, kDcLines>), dim3((unsigned)ntiles), dim3(16 * kDcLines), lds, s, a);
         HIP_TRY(h, hipGetLastError());
         return SDFGPU_OK;
     }

@@ -99,15 +99,17 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
     return __builtin_fma(d1, h1, s2);
 }
 
-inline size_t envelope_dc_lds_bytes(int L, int pitch) {
+inline size_t envelope_dc_lds_bytes(int L, int pitch, int lines = kDcLines) {
     const int SW = (L + 31) / 32, M = (L + kDcChunk - 1) / kDcChunk;
-    return ((size_t)kDcLines * pitch + (size_t)kDcLines * SW + 64 + kDcLocalFilled) * 4 + (size_t)kDcLines * (M + 2) * 2;
+    return ((size_t)lines * pitch + (size_t)lines * SW + 64 + kDcLocalFilled) * 4 + (size_t)lines * (M + 2) * 2;
 }
 
-template <int STAGE, int NT>
-__global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) {
-    constexpr int PS = NT / 4;          // positions staged per pass of the workgroup (4 lanes per position)
-    constexpr int NS = NT / 16;         // (line, slot) mapping: slots per line
+template <int STAGE, int NL>          // NL lines per tile (16 or 8), 16 lanes per line
+__global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
+    constexpr int NT = 16 * NL;
+    constexpr int LSUB = NL / 4;        // staging: lanes per position (4 lines each)
+    constexpr int PS = NT / LSUB;       // positions staged per pass of the workgroup (= 64)
+    constexpr int NS = 16;              // (line, slot) mapping: slots per line
     extern __shared__ __attribute__((aligned(16))) uint32_t dc_smem[];
     if (a.guard) {
         const uint32_t gv = *a.guard;
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
     const int SW = (L + 31) >> 5, AP = M + 2;
     const uint32_t mask = (1u << B) - 1u, finf = a.finf;
     uint32_t* keys = dc_smem;                                   // [16][pitch]
-    uint32_t* sgn = keys + kDcLines * pitch;                    // [16][SW]   bit p: voxel p of the line is filled
-    uint32_t* span = sgn + kDcLines * SW;                       // [16][2]    first / last site of the line
+    uint32_t* sgn = keys + NL * pitch;                    // [16][SW]   bit p: voxel p of the line is filled
+    uint32_t* span = sgn + NL * SW;                       // [16][2]    first / last site of the line
     uint32_t* flg = span + 32;                                  // [16] line holds a filled voxel, [16] = tile does
     uint32_t* flist = flg + 32;                                 // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
     uint16_t* args = reinterpret_cast<uint16_t*>(flist + kDcLocalFilled);   // [16][AP]   argmin of coarse position i' (1-based)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
         tile = ((int64_t)(seq >> 2) * 8 + xcd) * 4 + (seq & 3u);
     }
     const int64_t o = tile / a.tiles_per_outer;
-    const int64_t c0 = (tile - o * a.tiles_per_outer) * kDcLines;
+    const int64_t c0 = (tile - o * a.tiles_per_outer) * NL;
     const int64_t base = o * a.outer_stride + c0;               // element index of (line 0, position 0)
     const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
     const int16_t* const in16 = a.in16 + base;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
         }
         return (int)b;
     };
-    const int byz = byz_of(t & 15);             // the lane's own line in the chunk phase
+    const int byz = byz_of(t & (NL - 1));             // the lane's own line in the chunk phase
 
     // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
     auto raw_signed = [&](int line, int q) -> int {
@@ -229,11 +231,11 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
         // in-row squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can
         // only matter while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises flg[17] for the rest.
         if (cls == 1 && flg[17] == 0u) break;   // (block-uniform)
-        if (cls == 0) for (int i = t; i < kDcLines * SW; i += NT) sgn[i] = 0u;
-        if (t < 16) { span[2 * t] = 0xFFFFFFFFu; span[2 * t + 1] = 0u; }
+        if (cls == 0) for (int i = t; i < NL * SW; i += NT) sgn[i] = 0u;
+        if (t < NL) { span[2 * t] = 0xFFFFFFFFu; span[2 * t + 1] = 0u; }
         __syncthreads();
         {
-            const int sub = t & 3, r = t >> 2;
+            const int sub = t & (LSUB - 1), r = t / LSUB;
             uint32_t seen[4] = {0u, 0u, 0u, 0u};            // bit it: iteration `it` of this lane found a site on line 4 sub + k
             uint32_t* const kbase = keys + (4 * sub) * pitch + r;
             for (int pb = 0, itb = 0; pb < L; pb += PS * kDcBatch, itb += kDcBatch) {
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
                     atomicMax(&span[2 * (4 * sub + k) + 1], (uint32_t)(r + PS * (31 - __clz((int)seen[k]))));
                 }
             }
-            if (t < 16) keys[t * pitch + L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);   // sentinel
+            if (t < NL) keys[t * pitch + L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);   // sentinel
         }
         __syncthreads();
 
@@ -358,15 +360,15 @@ __global__ __launch_bounds__(NT, NT / 64) void k_envelope_dc(const EnvDcArgs a) 
         // (min-reduced with shuffles); levels with many positions switch to lane = (line, slot): the 16 lanes of a row then
         // work on the SAME position of 16 neighbouring lines, whose ranges are alike (the scene is coherent across
         // lines), so the per-lane loops of a row have nearly the same trip count.
-        const int lineT = t & 15, slotT = t >> 4;
+        const int lineT = t & (NL - 1), slotT = t / NL;
         const uint32_t qmnT = span[2 * lineT], qmxT = span[2 * lineT + 1];
         const bool actT = qmnT <= qmxT;
         {
-            const int lineU = (t >> 4) & 15, g = t & 15;      // (lanes beyond 256 idle through the first levels)
+            const int lineU = t >> 4, g = t & 15;
             const uint32_t* klU = keys + lineU * pitch;
             uint16_t* aU = args + lineU * AP;
             const uint32_t qmn = span[2 * lineU], qmx = span[2 * lineU + 1];
-            const bool actU = qmn <= qmx && t < 256;
+            const bool actU = qmn <= qmx;
             const uint32_t* klT = keys + lineT * pitch;
             uint16_t* aT = args + lineT * AP;
             for (int l = 0; l < ((a.dbg & 1) ? 0 : Kp); ++l) {
