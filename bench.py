@@ -47,7 +47,7 @@ B_ALG = {"pack_bits": 1, "dense_ball": 16, "sweep_z": 3, "sweep_y": 6, "sweep_zy
          "envelope_y": 6, "envelope_x": 8}
 B_ALG_TOTAL = 17
 B_COMPULSORY_TOTAL = 5          # mask in + fp32 out
-KERNEL_NAMES = {"envelope_y": "k_envelope_dc<2, 256> / k_envelope<2>", "envelope_x": "k_envelope_dc<3, 256> / k_envelope<3>",
+KERNEL_NAMES = {"envelope_y": "k_envelope_dc<2, 16> / k_envelope<2>", "envelope_x": "k_envelope_dc<3, 16> / k_envelope<3>",
                 "pack_bits": "k_pack_bits_mask", "dense_ball": "k_ball_dense", "sweep_z": "k_sweep_z_vec16",
                 "sweep_y": "k_sweep_march<2,...>", "sweep_zy": "k_sweep_zy_fused",
                 "sweep_x": "k_sweep_march<3,...> / k_sweep_x16"}
