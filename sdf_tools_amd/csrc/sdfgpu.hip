@@ -444,7 +444,8 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         // Measured alternatives to 16 lines x 256 lanes (4 workgroups = 16 waves per CU, ~120 VGPRs, 38 KB of LDS):
         //   512 lanes on 16 lines (8 waves per SIMD): needs <= 64 VGPRs, spills, 1.2 - 2.3x slower;
         //   8 lines x 128 lanes (7 workgroups per CU, the same waves per SIMD, more independent chains): 7 - 18 % slower --
-        //   the per-tile work of the levels is amortised over fewer voxels and the row segments halve (16 / 32 B).
+        //   the per-tile work of the levels is amortised over fewer voxels and the row segments halve (16 / 32 B);
+        //   32 lines x 512 lanes (2 workgroups per CU, full 128-B row segments, no spills): 3 - 8 % slower.
         const void* fn = stage == 2 ? (const void*)k_envelope_dc<2, kDcLines> : (const void*)k_envelope_dc<3, kDcLines>;
         if (lds > 64 * 1024 && !h->dc_lds_attr[stage - 2]) {
             HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

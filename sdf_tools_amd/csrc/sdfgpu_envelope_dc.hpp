@@ -101,7 +101,7 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
 
 inline size_t envelope_dc_lds_bytes(int L, int pitch, int lines = kDcLines) {
     const int SW = (L + 31) / 32, M = (L + kDcChunk - 1) / kDcChunk;
-    return ((size_t)lines * pitch + (size_t)lines * SW + 64 + kDcLocalFilled) * 4 + (size_t)lines * (M + 2) * 2;
+    return ((size_t)lines * pitch + (size_t)lines * SW + 2 * (size_t)lines + 32 + kDcLocalFilled) * 4 + (size_t)lines * (M + 2) * 2;
 }
 
 template <int STAGE, int NL>          // NL lines per tile (16 or 8), 16 lanes per line
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
     uint32_t* keys = dc_smem;                                   // [16][pitch]
     uint32_t* sgn = keys + NL * pitch;                    // [16][SW]   bit p: voxel p of the line is filled
     uint32_t* span = sgn + NL * SW;                       // [16][2]    first / last site of the line
-    uint32_t* flg = span + 32;                                  // [16] line holds a filled voxel, [16] = tile does
+    uint32_t* flg = span + 2 * NL;                                  // [16] line holds a filled voxel, [16] = tile does
     uint32_t* flist = flg + 32;                                 // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
     uint16_t* args = reinterpret_cast<uint16_t*>(flist + kDcLocalFilled);   // [16][AP]   argmin of coarse position i' (1-based)
     const int t = threadIdx.x;
