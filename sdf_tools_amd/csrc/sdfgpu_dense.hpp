@@ -428,7 +428,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
     const uint32_t flags = a.tileflag[tile_id];               // wave-uniform
     if (flags == 0u) return;
-    if (*a.uncertified != 0u) {                               // the general sweeps will redo the grid anyway
+    if (__hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {   // the general sweeps will redo the grid anyway
         if (threadIdx.x == 0) a.tileflag[tile_id] = 0u;       // (the flag words stay zero between builds)
         return;
     }
