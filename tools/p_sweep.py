@@ -13,6 +13,7 @@ rows = []
 for p in [0.5, 0.2, 0.1, 0.05, 0.03, 0.02, 0.01, 0.003, 0.001, 0.0001]:
     masks = [synth.bernoulli_mask_torch(shape, p, 1 + k, device=dev) for k in range(2)]
     ctx = capi.SdfGpu(0)
+    torch.cuda.synchronize()                      # (the mask generators above are asynchronous)
     t0 = time.perf_counter(); ctx.build_device(masks[0].data_ptr(), shape, out.data_ptr(), 0.01, False, s); torch.cuda.synchronize()
     first = (time.perf_counter() - t0) * 1e3
     for i in range(30):
