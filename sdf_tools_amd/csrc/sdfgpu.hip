@@ -119,6 +119,7 @@ struct sdfgpu_context {
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
+    int wide_y_from = 16;            // policy: radius-8 y windows when the largest squared distance exceeds this
     bool wide_y = false, wide_x = false;   // policy: radius-8 windows for the next build's y / x marching sweep
     bool last_plane16 = false;
     int profiling = 0;            // 0 off, 1 an event behind every stage, 2 events around the dense ball kernel only,
@@ -681,7 +682,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         //   p = 0.03 has 28 and gets slower, p = 0.02 has 37 and gets faster)
         if (general_ran) {
             const uint32_t md = std::max(h->h_flags[0], h->h_flags[1]);
-            h->wide_y = md > 16u && md <= 100u;           // (beyond ~100 the scans past a radius-8 window dominate again:
+            h->wide_y = md > (uint32_t)h->wide_y_from && md <= 100u;           // (beyond ~100 the scans past a radius-8 window dominate again:
             h->wide_x = md >= 32u && md <= 160u;          //  p = 0.003 has 130: x sweep 1.7 -> 1.2 ms; p = 0.001 has 270 and
                                                           //  its x sweep took 5.0 instead of 2.4 ms)
         } else {
@@ -1670,6 +1671,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;
+    else if (n == "wide_y_from") h->wide_y_from = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return SDFGPU_OK;
 }
