@@ -328,7 +328,8 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * default 16, 0 = always try), "fixup" (the fix-up kernel behind the dense ball kernel for almost-dense
  * scenes, default 1), "fixup_mode" (force the policy state that launches it with the next build),
  * "march_window" / "x16_window" = 8 (force the radius-8 register windows of the y / x marching sweeps,
- * which the policy otherwise selects for mid-sparse scenes), "dense_generic" (1 = shapes the tuned dense kernels do not take -- nz not 32 * 2^k, virtual border -- use their
+ * which the policy otherwise selects for mid-sparse scenes; "wide_y_from": the largest squared distance of the previous
+ * build above which it does so for the y sweep, default 16), "dense_generic" (1 = shapes the tuned dense kernels do not take -- nz not 32 * 2^k, virtual border -- use their
  * generic forms, default; 0 = such shapes skip the dense tier), "envelope_dc" (1 = divide-and-conquer envelope kernel
  * where the shape allows, default; 0 = first-generation stack kernel), "tier_select" (1 = choose marching vs
  * envelope sweep per axis on the device inside each build from a probe of the sweep's input, default; 0 = learn
