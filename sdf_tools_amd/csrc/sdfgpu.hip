@@ -119,6 +119,7 @@ struct sdfgpu_context {
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
+    int wide_x_from = 32;            // ... and radius-8 x windows from this one
     int wide_y_from = 16;            // policy: radius-8 y windows when the largest squared distance exceeds this
     bool wide_y = false, wide_x = false;   // policy: radius-8 windows for the next build's y / x marching sweep
     bool last_plane16 = false;
@@ -683,7 +684,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         if (general_ran) {
             const uint32_t md = std::max(h->h_flags[0], h->h_flags[1]);
             h->wide_y = md > (uint32_t)h->wide_y_from && md <= 100u;           // (beyond ~100 the scans past a radius-8 window dominate again:
-            h->wide_x = md >= 32u && md <= 160u;          //  p = 0.003 has 130: x sweep 1.7 -> 1.2 ms; p = 0.001 has 270 and
+            h->wide_x = md >= (uint32_t)h->wide_x_from && md <= 160u;          //  p = 0.003 has 130: x sweep 1.7 -> 1.2 ms; p = 0.001 has 270 and
                                                           //  its x sweep took 5.0 instead of 2.4 ms)
         } else {
             h->wide_y = h->wide_x = false;
@@ -716,6 +717,11 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
     const bool select = dev_select && !fused;
+    // With the tier chosen on the device, the far-field kernel takes the x axis from the point where the radius-3 window
+    // stops deciding nearly every voxel (0.55 ms flat at 512^3); the radius-8 x window (0.64 ms flat, it spills) can only
+    // lose against both from there on -- measured: p = 0.04 0.64 vs 0.36 ms with the radius-3 window.  It stays for shapes
+    // the far-field kernel does not take.
+    if (select) h->wide_x = false;
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
@@ -1672,6 +1678,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "x16_window") h->x16_h = value;
     else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;
     else if (n == "wide_y_from") h->wide_y_from = value;
+    else if (n == "wide_x_from") h->wide_x_from = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return SDFGPU_OK;
 }
