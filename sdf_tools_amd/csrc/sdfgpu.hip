@@ -119,6 +119,7 @@ struct sdfgpu_context {
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
+    int mid_thr_y = 16, mid_den_y = 24;   // y probe: radius-8 marching window when more than 1 / den of the voxels have d^2 >= thr
     int wide_x_from = 32;            // ... and radius-8 x windows from this one
     int wide_y_from = 16;            // policy: radius-8 y windows when the largest squared distance exceeds this
     bool wide_y = false, wide_x = false;   // policy: radius-8 windows for the next build's y / x marching sweep
@@ -226,7 +227,7 @@ int pick_T(int user, int span) {
 }
 
 template <int STAGE, bool VB>
-int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s) {
+int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s, int force_window = 0) {
     const int span = a.out_hi - a.out_lo;
     const int nchunks = (span + a.T - 1) / a.T;
     const int64_t nbx = (a.ncols + kBlock - 1) / kBlock;
@@ -234,7 +235,7 @@ int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s) {
     dim3 grid((unsigned)nbx, (unsigned)nchunks), block(kBlock);
     bool wide = false;
     if constexpr (STAGE == 2 && !VB) {                       // radius-8 window: y sweep only
-        if (vec4 && (h->march_h == 8 || h->wide_y)) {
+        if (vec4 && force_window != 3 && (force_window == 8 || h->march_h == 8 || h->wide_y)) {
             hipLaunchKernelGGL((k_sweep_march<2, 4, 8, false>), grid, block, 0, s, a);
             wide = true;
         }
@@ -250,7 +251,7 @@ int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s) {
 // (d_side != nullptr: write the int16 plane field to d_out and exact saturated groups to d_side;
 //  requires the vec4 path)
 int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, void* d_out, int32_t* d_side, int64_t nx, int64_t ny,
-                   int64_t nz, hipStream_t s) {
+                   int64_t nz, hipStream_t s, int force_window = 0) {
     const bool vec4 = (nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_in) % 8) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_out) % 16) == 0;
     if (d_side && !vec4) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "16-bit plane output needs nz % 4 == 0");
@@ -266,7 +267,7 @@ int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, void* d_out, int32_t* d
     a.line_stride = nz;
     a.L = (int)ny; a.out_lo = 0; a.out_hi = (int)ny;
     a.T = pick_T(h->tune_ty, (int)ny);
-    return launch_march<2, false>(h, a, vec4, s);
+    return launch_march<2, false>(h, a, vec4, s, force_window);
 }
 
 // K12 launch: mask -> int32 in-plane signed d^2 in one kernel (nz = 512 or 1024, 16-B aligned mask)
@@ -435,6 +436,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         if (probe_out) {                                        // sample ~256 tiles spread over the grid, store nothing
             a.probe_stride = (int)std::max<int64_t>(1, std::min<int64_t>(64, ntiles / 256));
             a.probe_thr = h->far_thr[stage - 2];
+            a.probe_thr2 = stage == 2 ? h->mid_thr_y : 0;
             a.probe_out = probe_out;
             ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
             // the sampled tile index b * stride + (7 b mod stride) must stay inside the grid: drop the last block if needed
@@ -475,9 +477,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
     return SDFGPU_OK;
 }
 
-int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff = false) {
+int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff = false, bool window_choice = false) {
     hipLaunchKernelGGL(k_decide_tier, dim3(1), dim3(1), 0, s, h->d_small, stage, dense_tried ? 1 : 0, h->force_env,
-                       1, h->far_den[stage], handoff ? 1 : 0);
+                       1, h->far_den[stage], handoff ? 1 : 0, (stage == 0 && window_choice) ? h->mid_den_y : 0);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -811,14 +813,21 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     DcExtra hand2{}, hand3{};
     hand2.out_i32 = (int32_t*)h->yzfield.ptr; hand2.i32_flag = h->d_small + 7;
     hand3.in_i32 = (const int32_t*)h->yzfield.ptr; hand3.i32_flag = h->d_small + 7;
-    auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff); };   // probe counters -> guard words
+    // (the radius-8 y window exists for 4-voxel lanes only; a forced window leaves nothing to choose)
+    const bool window_choice = select && (nz % 4) == 0 && h->march_h != 8 && h->mid_den_y > 0;
+    auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff, window_choice); };   // probe counters -> guard words
     if (select) {
         if (h->force_env < 0)
             if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
                                          nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12)) return rc;
         if (int rc = decide(0)) return rc;
-        h->guard = h->d_small + 8;                              // marching y sweep: general pipeline needed AND near-field
-        if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s)) return rc;
+        // marching y sweep: general pipeline needed AND near-field; the probe also picks the window (radius 3 / radius 8)
+        h->guard = h->d_small + 8;
+        if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s, window_choice ? 3 : 0)) return rc;
+        if (window_choice) {
+            h->guard = h->d_small + 9;
+            if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s, 8)) return rc;
+        }
         h->guard = general_guard;
         launched_since_mark = true;
     } else if (fused) {
@@ -1679,6 +1688,8 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;
     else if (n == "wide_y_from") h->wide_y_from = value;
     else if (n == "wide_x_from") h->wide_x_from = value;
+    else if (n == "mid_threshold_y") h->mid_thr_y = value;
+    else if (n == "mid_fraction_den_y") h->mid_den_y = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return SDFGPU_OK;
 }

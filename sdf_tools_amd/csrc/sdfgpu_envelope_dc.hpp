@@ -74,6 +74,7 @@ struct EnvDcArgs {
     // pass counts the voxels it produced ([1]) and those whose squared distance is >= probe_thr ([0]) into probe_out
     int probe_stride;
     int probe_thr;
+    int probe_thr2;           // second, lower threshold (y probe: radius-8 vs radius-3 marching window), counted into probe_out[-1]
     uint32_t* probe_out;
     // both axes far-field: when *i32_flag != 0 the y sweep hands its result to the x sweep as an exact int32 plane field
     // (out_i32 / in_i32, the side-table buffer used whole) instead of p16 + side table; nullptr = the pointers alone decide
@@ -197,9 +198,9 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
     };
     // finish one voxel: STAGE 2 plane field (+ side table on request), STAGE 3 the reference's merge arithmetic
-    int probe_far = 0, probe_tot = 0;
+    int probe_far = 0, probe_tot = 0, probe_mid = 0;
     auto emit = [&](int line, int p, int D, bool filled, bool side, int b_yz) {
-        if (probe) { probe_tot += 1; probe_far += D >= a.probe_thr ? 1 : 0; return; }
+        if (probe) { probe_tot += 1; probe_far += D >= a.probe_thr ? 1 : 0; probe_mid += D >= a.probe_thr2 ? 1 : 0; return; }
         const uint32_t oi = (uint32_t)line + (uint32_t)p * ls;
         if constexpr (STAGE == 2) {
             if (a.out_i32 && i32) { (a.out_i32 + base)[oi] = filled ? -D : D; return; }
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
 
 #pragma unroll 1
     for (int cls = 0; cls < 2; ++cls) {         // 0: sites of "distance to filled" (for free voxels); 1: the reverse
-        if (cls == 0 && t == 0) { flg[16] = 0u; flg[17] = 0u; flg[18] = 0u; flg[19] = 0u; }   // (ordered before their users by the barriers of pass 0)
+        if (cls == 0 && t == 0) { flg[16] = 0u; flg[17] = 0u; flg[18] = 0u; flg[19] = 0u; flg[20] = 0u; }   // (ordered before their users by the barriers of pass 0)
         // ---- stage the tile: rows -> keys, one pass ----------------------------------------------------------------------
         // A lane reads 4 lines x 1 position (8 B; STAGE 3 adds the 16-B side-table group where the 16-bit value is
         // saturated, or reads 16 B of an int32 plane field), kDcBatch independent row loads in flight, and writes the four
@@ -537,11 +538,12 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
         for (int off = 32; off >= 1; off >>= 1) {
             probe_far += __shfl_xor(probe_far, off);
             probe_tot += __shfl_xor(probe_tot, off);
+            probe_mid += __shfl_xor(probe_mid, off);
         }
         // one pair of global atomics per workgroup (same-address atomics serialise at ~12 ns each)
-        if ((t & 63) == 0) { atomicAdd(&flg[18], (uint32_t)probe_far); atomicAdd(&flg[19], (uint32_t)probe_tot); }
+        if ((t & 63) == 0) { atomicAdd(&flg[18], (uint32_t)probe_far); atomicAdd(&flg[19], (uint32_t)probe_tot); atomicAdd(&flg[20], (uint32_t)probe_mid); }
         __syncthreads();
-        if (t == 0) { atomicAdd(a.probe_out, flg[18]); atomicAdd(a.probe_out + 1, flg[19]); }
+        if (t == 0) { atomicAdd(a.probe_out, flg[18]); atomicAdd(a.probe_out + 1, flg[19]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, flg[20]); }
         return;
     }
     if constexpr (STAGE == 3) {
@@ -559,15 +561,20 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
 // raised by a marching sweep that hits its scan bound), [8 + 2 stage] guard word of the marching sweep, [12] / [13] the
 // probe's counters.  The marching sweep runs iff the general pipeline is needed at all and the probe found the axis
 // near-field; otherwise the envelope flag is raised and the (flag-guarded) envelope kernel does the sweep.
-__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff) {
+__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff,
+                              int mid_den) {
     const bool active = dense_tried ? small[3] != 0u : true;
-    const uint32_t far_n = small[12], tot = small[13];
+    const uint32_t far_n = small[12], tot = small[13], mid_n = small[11];
     // far when more than num / den of the sampled voxels need a long scan (64-bit: counts are < 2^24, factors small)
     bool far = force >= 0 ? force != 0 : (uint64_t)far_n * (uint64_t)den > (uint64_t)tot * (uint64_t)num;
     if (stage == 1 && small[7] != 0u) far = true;               // the y probe chose the far-field pair with int32 hand-off
-    small[8 + 2 * stage] = (active && !far) ? 1u : 0u;
+    // y sweep, near-field: radius-8 register windows when more than 1 / mid_den of the voxels are beyond the radius-3 one
+    const bool wide = stage == 0 && mid_den > 0 && (uint64_t)mid_n * (uint64_t)mid_den > (uint64_t)tot;
+    small[8 + 2 * stage] = (active && !far && !wide) ? 1u : 0u;
+    if (stage == 0) small[9] = (active && !far && wide) ? 1u : 0u;
     if (active && far) small[4 + stage] = 1u;
     if (stage == 0 && active && far && handoff) small[7] = 1u;
+    small[11] = 0u;
     small[12] = 0u;
     small[13] = 0u;
     small[14 + stage] = tot ? (far_n * 1000u) / tot : 0u;         // per-mille of far voxels in the sample (diagnostics)
