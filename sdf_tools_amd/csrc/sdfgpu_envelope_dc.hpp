@@ -158,10 +158,17 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
         uint32_t R = (__umul24(p, p) << B) - __umul24(c, (uint32_t)q);
         const uint32_t dR = __umul24(c, (uint32_t)(2 * G));
         uint32_t best = 0xFFFFFFFFu;
-        for (; q <= hi; q += 2 * G) {
+        const int step = 2 * G;
+        for (; q + step <= hi; q += 2 * step) {                 // two pairs per trip: half the loop overhead
+            const uint32_t k0 = kl[q], k1 = kl[q + 1], k2 = kl[q + step], k3 = kl[q + step + 1];
+            const uint32_t R2 = R - dR;
+            best = min(best, min(k0 + R, k1 + R - c));
+            best = min(best, min(k2 + R2, k3 + R2 - c));
+            R = R2 - dR;
+        }
+        if (q <= hi) {
             const uint32_t k0 = kl[q], k1 = kl[q + 1];
             best = min(best, min(k0 + R, k1 + R - c));
-            R -= dR;
         }
         return best;
     };
