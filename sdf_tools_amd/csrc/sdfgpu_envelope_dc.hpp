@@ -23,8 +23,8 @@
 //   upper levels  positions p = 0, 8, 16, ... (coarse grid) by binary subdivision; 16 lanes per line: the first
 //                 levels split one position's candidate range over 16 / 8 / 4 / 2 lanes and min-reduce, later levels
 //                 give every lane its own positions.  Argmins go to a small LDS array.
-//   chunk phase   lane = (line, chunk of 8 positions): the 7 interior positions by the same subdivision with the
-//                 bounds held in registers, results converted and stored straight from the lane (16 lines x 2 / 4 B
+//   chunk phase   lane = (line, chunk of 8 positions): all 8 positions against every candidate between the argmins of the
+//                 chunk's two coarse neighbours, results converted and stored straight from the lane (16 lines x 2 / 4 B
 //                 contiguous per position).
 // Both classes of the signed field take one pass each (sites of "distance to filled" evaluated on free voxels,
 // then the reverse); a tile without filled voxels skips the second pass, and in it free voxels are sites only
@@ -41,7 +41,6 @@ namespace sdfgpu {
 constexpr int kDcLines = 16;          // lines per tile
 constexpr int kDcChunk = 8;           // positions per lane in the chunk phase
 constexpr int kDcBatch = 2;           // staging: row loads in flight per lane (register budget: 128 VGPRs at 4 waves per SIMD)
-constexpr int kDcBrute = 24;          // chunk phase: candidate ranges below this are searched exhaustively
 constexpr int kDcLocalMax = 64;       // pass 0 finishes filled voxels whose in-row squared distance is at most this ...
 constexpr int kDcLocalFilled = 448;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second
                                       // pass costs as much as the first: at 224 a 3 %-occupied scene -- 245 per tile --
@@ -442,11 +441,13 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
                 for (int k = 0; k < kDcChunk; ++k) D[k] = kInf32;
                 const int a0 = (live && act && !(a.dbg & 2)) ? (int)al[i + 1] : 0;
                 const int a8 = (live && act && !(a.dbg & 2)) ? ((i + 2 <= M) ? (int)al[i + 2] : (int)qmx) : -1;
-                if (live && act && a8 - a0 < kDcBrute) {
-                    // few candidates (the common case: the argmin moves ~ half a site per position): all 8 positions against
-                    // every candidate of [a0, a8], branch-free, two candidates per step; 2 VALU per evaluation, no per-position
-                    // set-up.  With p_k = p0 + k: R_k(q) = (p_k^2 << B) - ((2 p_k) << B) q, R_k(a0) - R_{k-1}(a0) =
-                    // ((2 (p0 - a0) + 2k - 1) << B).
+                if (live && act) {
+                    // all 8 positions against every candidate of [a0, a8] (usually a few: the argmin moves ~ half a site per
+                    // position), branch-free, two candidates per step; 2 VALU per evaluation, no per-position set-up.  Long ranges
+                    // take the same loop: a per-lane divide-and-conquer over the chunk's positions (3 R instead of 8 R evaluations
+                    // for a range of R) was kept for ranges >= 24 at first -- it ran the whole wave through both code paths and lost
+                    // everywhere (KE3 0.82 -> 0.75 ms on the streaming scene, KE2 0.80 -> 0.63 ms at Bernoulli p = 0.003).
+                    // With p_k = p0 + k: R_k(q) = (p_k^2 << B) - ((2 p_k) << B) q, R_k(a0) - R_{k-1}(a0) = ((2 (p0 - a0) + 2k - 1) << B).
                     uint32_t R[kDcChunk], nc[kDcChunk], best[kDcChunk];
                     const uint32_t W = (uint32_t)(2 * (p0 - a0)) << B;
                     R[0] = (__umul24((uint32_t)p0, (uint32_t)p0) << B) - __umul24(((uint32_t)(2 * p0)) << B, (uint32_t)a0);
@@ -471,25 +472,6 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
                         const uint32_t d = best[k] >> B;
                         D[k] = d >= finf ? kInf32 : (int)d;
                     }
-                } else if (live && act && !(a.dbg & 2)) {
-                    // position p0 + k over [lo, hi]: distance to D[k], argmin returned (positions beyond the line end
-                    // only pass the upper bound on)
-                    auto pos = [&](auto kc, int lo, int hi) -> int {
-                        constexpr int k = decltype(kc)::value;
-                        if (p0 + k >= L) return hi;
-                        const uint32_t best = scan(kl, (uint32_t)(p0 + k), lo, hi, 0, 1);
-                        const uint32_t d = best >> B;
-                        D[k] = d >= finf ? kInf32 : (int)d;
-                        return (int)(best & mask);
-                    };
-                    pos(std::integral_constant<int, 0>{}, a0, a0);
-                    const int a4 = pos(std::integral_constant<int, 4>{}, a0, a8);
-                    const int a2 = pos(std::integral_constant<int, 2>{}, a0, a4);
-                    const int a6 = pos(std::integral_constant<int, 6>{}, a4, a8);
-                    pos(std::integral_constant<int, 1>{}, a0, a2);
-                    pos(std::integral_constant<int, 3>{}, a2, a4);
-                    pos(std::integral_constant<int, 5>{}, a4, a6);
-                    pos(std::integral_constant<int, 7>{}, a6, a8);
                 }
                 uint32_t cm = 0u;                               // bit k: voxel p0 + k of this line is filled
                 if (live) cm = (sgn[line * SW + (p0 >> 5)] >> (p0 & 31)) & 0xFFu;
