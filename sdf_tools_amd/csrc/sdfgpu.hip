@@ -88,11 +88,12 @@ struct sdfgpu_context {
     bool tier_select = true;         // pick marching vs envelope sweep per axis on the device, inside the build (probe + decide)
     int force_env = -1;              // -1 automatic, 1 = envelope kernels only (option "envelope_mode")
     // an axis is far-field when more than 1 / den of the probed voxels have d^2 >= thr.  Per axis, from the measured
-    // break-even of the two sweeps at 512^3 (tools/p_sweep.py): the y marching sweep (2 B rows, radius-8 windows) holds up to
-    // in-plane d^2 ~ 64 on an eighth of the voxels; the x marching sweep falls behind the far-field kernel as soon as its
+    // break-even of the two sweeps at 512^3 (tools/p_sweep.py, tools/ythr_probe.py): the y marching sweep (2 B rows, radius-8
+    // windows) against the far-field PAIR (int32 hand-off, no x probe) breaks even at in-plane d^2 ~ 36 on an eighth of the
+    // voxels (Bernoulli p = 0.02: 1.31 vs 1.29 ms; p = 0.015: 1.54 vs 1.29 ms; p = 0.025: 1.21 vs 1.28 ms); the x marching sweep falls behind the far-field kernel as soon as its
     // radius-3 window stops deciding nearly every voxel (Bernoulli p = 0.03: 0.65 ms against 0.55; p = 0.04 and denser:
     // marching wins), so its threshold is d^2 >= 9 on 1 / 24 of the voxels (p = 0.03: 6 %, p = 0.04: 2.4 %)
-    int far_thr[2] = {64, 9};
+    int far_thr[2] = {36, 9};
     int far_den[2] = {8, 24};
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
