@@ -68,29 +68,11 @@ def dc_line(F, FINF):
         a0 = a[i + 1]
         a8 = a[i + 2] if i + 2 <= M else qmax
 
-        def pos(p, lo, hi):
-            if p >= L:
-                return hi
-            assert lo <= hi
-            k = scan(p, lo, hi)
-            D[p] = k >> B
-            assert lo <= (k & mask) <= hi
-            return k & mask
-
-        if a8 - a0 < 24:            # few candidates: every position of the chunk against all of [a0, a8] (pairs: a8 + 1 may be read)
-            for k in range(8):
-                if p0 + k < L:
-                    best = min(scan(p0 + k, a0, a8), 0xFFFFFFFF)
-                    D[p0 + k] = best >> B
-            continue
-        pos(p0, a0, a0)
-        a4 = pos(p0 + 4, a0, a8)
-        a2 = pos(p0 + 2, a0, a4)
-        a6 = pos(p0 + 6, a4, a8)
-        pos(p0 + 1, a0, a2)
-        pos(p0 + 3, a2, a4)
-        pos(p0 + 5, a4, a6)
-        pos(p0 + 7, a6, a8)
+        # every position of the chunk against all of [a0, a8] (pairs: a8 + 1 may be read); the kernel has no other path
+        for k in range(8):
+            if p0 + k < L:
+                best = min(scan(p0 + k, a0, a8), 0xFFFFFFFF)
+                D[p0 + k] = best >> B
     return [d if d < FINF else INF for d in D], evals[0]
 
 
