@@ -85,3 +85,34 @@ def test_multi_gpu_library_exports_every_declared_symbol_and_refuses_without_gpu
         with pytest.raises(capi.SdfGpuError) as ei:
             capi.MultiSdfGpu(2)
         assert ei.value.code == -4 and "no CPU fallback" in str(ei.value)
+
+
+def test_far_field_schedule_model_is_exact():
+    """tools/envelope_dc_model.py restates k_envelope_dc's schedule (32-bit keys, levels, pair-wise scans that may read one
+    candidate past the range, distance-bound clipping, exhaustive chunk phase) line by line on the CPU; it must equal a
+    brute-force min-plus evaluation on random lines incl. ties, runs, lengths that are not multiples of 8 and empty lines."""
+    import importlib.util
+    import random
+    spec = importlib.util.spec_from_file_location(
+        "envelope_dc_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "envelope_dc_model.py"))
+    model = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(model)
+    rng = random.Random(7)
+    for trial in range(400):
+        L = rng.choice([1, 2, 7, 8, 9, 17, 40, 64, 100, 127, 128, 257, 512])
+        dens = rng.choice([0.0, 0.01, 0.05, 0.3, 1.0])
+        kind = rng.choice(["rand", "ties", "runs", "smooth"])
+        c, hh = rng.randrange(-50, L + 50), rng.randrange(0, 300)
+        F = []
+        for q in range(L):
+            if kind == "smooth":
+                F.append(hh * hh + (q - c) ** 2 if rng.random() < max(dens, 0.3) else model.INF)
+            elif kind == "ties":
+                F.append(rng.choice([0, 1, 4]) if rng.random() < dens else model.INF)
+            elif kind == "runs":
+                F.append(0 if (q // 7) % 3 == 0 and dens > 0 else model.INF)
+            else:
+                F.append(rng.randrange(0, 200001) if rng.random() < dens else model.INF)
+        finf = max([v for v in F if v < model.INF] + [0]) + (L - 1) ** 2 + 1
+        got, _ = model.dc_line(F, finf)
+        assert got == model.brute(F), (trial, L, kind)
