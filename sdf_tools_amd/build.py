@@ -41,7 +41,7 @@ def build_libsdfgpu(force=False, verbose=False):
     if not force and not _newer(LIB, srcs):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I", INCLUDE, srcs[0], "-o", LIB]
+           "-I", INCLUDE, srcs[0], "-o", LIB] + os.environ.get("SDFGPU_EXTRA_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -7,6 +7,7 @@
 #include "sdfgpu_dense.hpp"
 #include "sdfgpu_envelope.hpp"
 #include "sdfgpu_envelope_dc.hpp"
+#include "sdfgpu_envelope_v3.hpp"
 
 #include <sys/mman.h>
 
@@ -97,6 +98,9 @@ struct sdfgpu_context {
     int far_den[2] = {8, 24};
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
+    int dc_version = 3;              // far-field kernel generation: 3 = k_envelope_v3, 2 = k_envelope_dc (kept for A/B runs)
+    bool v3_lds_attr[4] = {false, false, false, false};
+    unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
@@ -409,12 +413,86 @@ DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, 
     return g;
 }
 
+// Third generation (sdfgpu_envelope_v3.hpp): any line count, keys must fit 32 bits: finf + (L + 2)^2 < 2^(32 - B).
+DcGeometry envelope_v3_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz, int64_t ny_full = -1) {
+    DcGeometry g{};
+    if (ny_full < 0) ny_full = ny;
+    const int64_t L = stage == 2 ? ny : nx;
+    if (!h->envelope_dc || L < 1 || L > 2048 || nx * ny * nz >= (1ll << 31)) return g;
+    int B = 1;
+    while ((1ll << B) < L) ++B;
+    const int64_t finf = (nx - 1) * (nx - 1) + (ny_full - 1) * (ny_full - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2
+    if (finf + (L + 2) * (L + 2) >= (1ll << (32 - B))) return g;
+    if ((L + 2) * (2ll << B) >= (1ll << 23)) return g;            // 24-bit multiplier operands
+    if (envelope_v3_lds_bytes((int)L) > 160 * 1024) return g;
+    g.ok = true; g.B = B; g.finf = (uint32_t)finf;
+    g.pitch = envelope_v3_pitch((int)L);
+    g.M = (int)((L + 7) / 8);
+    g.Kp = 0;
+    return g;
+}
+
+bool far_geometry_ok(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz, int64_t ny_full = -1) {
+    return (h->dc_version >= 3 && envelope_v3_geometry(h, stage, nx, ny, nz, ny_full).ok) ||
+           envelope_dc_geometry(h, stage, nx, ny, nz, ny_full).ok;
+}
+
 // KE2 / KE3: exact far-field sweeps.  guard: run iff (*guard != 0) != guard_invert (nullptr: always).
 int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int32_t* d_side_in, void* d_out,
                     int32_t* d_side_out, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
                     uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s, int guard_invert = 0,
                     uint32_t* probe_out = nullptr, const DcExtra* ex = nullptr) {
     (void)d_maxdsq;
+    const DcGeometry g3 = h->dc_version >= 3 ? envelope_v3_geometry(h, stage, nx, ny, nz, ex ? ex->ny_glob : -1) : DcGeometry{};
+    if (g3.ok) {
+        EnvDcArgs a{};
+        a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
+        int64_t ntiles;
+        constexpr int NL = kV3Lines;
+        if (stage == 2) { a.group_lines = nz; a.tiles_per_outer = (nz + NL - 1) / NL; ntiles = nx * a.tiles_per_outer; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
+        else { a.group_lines = ny * nz; a.tiles_per_outer = (ny * nz + NL - 1) / NL; ntiles = a.tiles_per_outer; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
+        a.B = g3.B; a.finf = g3.finf; a.pitch = g3.pitch; a.M = g3.M; a.Kp = 0; a.h = (a.L + 1) / 2;
+        a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
+        a.y_off = 0; a.ny_glob = ny;
+        if (ex) {
+            a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
+            if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
+        }
+        a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
+#ifdef SDFGPU_PHASE_CLOCKS
+        if (!h->d_clocks) { HIP_TRY(h, hipMalloc((void**)&h->d_clocks, 16 * 8)); HIP_TRY(h, hipMemset(h->d_clocks, 0, 16 * 8)); }
+        a.clocks = h->d_clocks;
+#endif
+        if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
+        const int64_t all = ntiles;
+        if (probe_out) {                                        // sample ~256 tiles spread over the grid, store nothing
+            a.probe_stride = (int)std::max<int64_t>(1, std::min<int64_t>(64, ntiles / 256));
+            a.probe_thr = h->far_thr[stage - 2];
+            a.probe_thr2 = stage == 2 ? h->mid_thr_y : 0;
+            a.probe_out = probe_out;
+            ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
+            while (ntiles > 0 && (ntiles - 1) * a.probe_stride + ((ntiles - 1) * 7) % a.probe_stride >= all) --ntiles;
+            if (ntiles == 0) return SDFGPU_OK;
+        }
+        // vector loads: 4 consecutive lines per load, whole tiles, aligned rows
+        auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) % n) == 0; };
+        const bool vec = (nz % 4) == 0 && (a.group_lines % NL) == 0 && al(d_in16, 8) && al(d_side_in, 16) && al(a.in_i32, 16);
+        const size_t lds = envelope_v3_lds_bytes(a.L);
+        const void* fn = stage == 2 ? (vec ? (const void*)k_envelope_v3<2, true> : (const void*)k_envelope_v3<2, false>)
+                                    : (vec ? (const void*)k_envelope_v3<3, true> : (const void*)k_envelope_v3<3, false>);
+        const int fi = (stage - 2) * 2 + (vec ? 1 : 0);
+        if (lds > 64 * 1024 && !h->v3_lds_attr[fi]) {
+            HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            h->v3_lds_attr[fi] = true;
+        }
+        const dim3 grid((unsigned)ntiles), block(256);
+        if (stage == 2 && vec) hipLaunchKernelGGL((k_envelope_v3<2, true>), grid, block, lds, s, a);
+        else if (stage == 2) hipLaunchKernelGGL((k_envelope_v3<2, false>), grid, block, lds, s, a);
+        else if (vec) hipLaunchKernelGGL((k_envelope_v3<3, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_envelope_v3<3, false>), grid, block, lds, s, a);
+        HIP_TRY(h, hipGetLastError());
+        return SDFGPU_OK;
+    }
     const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz, ex ? ex->ny_glob : -1);
     if (ex && !g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "int32 plane fields need the divide-and-conquer envelope kernel");
     if (probe_out && !g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "probe needs the divide-and-conquer envelope kernel");
@@ -712,7 +790,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // reference's API is one-shot: collision_map.hpp:680-712 builds and returns) never runs a sweep that is thrown away.
     // Other shapes keep the host policy below (choice learned from the previous build on the handle).
     const bool dev_select = envelope && h->tier_select &&
-                            envelope_dc_geometry(h, 2, nx, ny, nz).ok && envelope_dc_geometry(h, 3, nx, ny, nz).ok;
+                            far_geometry_ok(h, 2, nx, ny, nz) && far_geometry_ok(h, 3, nx, ny, nz);
     const bool env_y = envelope && !dev_select && h->env_mode_y, env_x = envelope && !dev_select && h->env_mode_x;
     // K12 (fused z+y) only as the guarded stand-by behind a dense build that is expected to be certified
     // again; everywhere else K1 + K2 (rows from the int16 z field) scan much faster than the fused kernel
@@ -1233,7 +1311,7 @@ int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int6
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nxs * ny * nz;
     hipStream_t s = (hipStream_t)stream;
-    const bool tiered = h->envelope_on && h->tier_select && envelope_dc_geometry(h, 2, nxs, ny, nz).ok &&
+    const bool tiered = h->envelope_on && h->tier_select && far_geometry_ok(h, 2, nxs, ny, nz) &&
                         (nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
     if (!tiered) {
         if (fused_zy_eligible(h, d_filled, d_plane_dsq, nz)) return launch_sweep_zy_fused(h, d_filled, d_plane_dsq, nullptr, nxs, ny, nz, s);
@@ -1284,7 +1362,7 @@ int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int
     hipStream_t s = (hipStream_t)stream;
     h->guard = nullptr;
     h->far_y = nullptr;
-    const bool tiered = h->envelope_on && h->tier_select && envelope_dc_geometry(h, 3, nx, nys, nz, ny_global).ok &&
+    const bool tiered = h->envelope_on && h->tier_select && far_geometry_ok(h, 3, nx, nys, nz, ny_global) &&
                         (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
     if (!tiered) {
         if (int rc = launch_sweep_x(h, d_plane_dsq, d_out_sdf, 0, nx, 0, nys, nz, 0, 0, 0, nx, resolution, add_virtual_border,
@@ -1654,6 +1732,19 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
     return SDFGPU_OK;
 }
 
+#ifdef SDFGPU_PHASE_CLOCKS
+// profiling builds only: read (and clear) the phase clocks of the far-field kernels, [2][8] shader-clock sums over waves
+extern "C" int sdfgpu_debug_read_clocks(sdfgpu_handle h, unsigned long long* out16) {
+    if (!h || !out16) return SDFGPU_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    if (!h->d_clocks) return SDFGPU_OK;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(out16, h->d_clocks, 16 * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemset(h->d_clocks, 0, 16 * 8));
+    return SDFGPU_OK;
+}
+#endif
+
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     if (!h || !name) return SDFGPU_ERR_INVALID_ARGUMENT;
     const std::string n(name);
@@ -1668,6 +1759,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "envelope") h->envelope_on = value != 0;
     else if (n == "envelope_dc") h->envelope_dc = value != 0;
     else if (n == "dc_debug") h->dc_debug = value;
+    else if (n == "dc_version") h->dc_version = value;
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;

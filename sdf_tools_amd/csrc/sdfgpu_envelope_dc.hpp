@@ -78,6 +78,9 @@ struct EnvDcArgs {
     // both axes far-field: when *i32_flag != 0 the y sweep hands its result to the x sweep as an exact int32 plane field
     // (out_i32 / in_i32, the side-table buffer used whole) instead of p16 + side table; nullptr = the pointers alone decide
     const uint32_t* i32_flag;
+    int h;                    // third generation: centre of the key coordinates, ceil(L / 2)
+    int64_t group_lines;      // third generation: lines per outer unit (tiles that stick out replicate the last line)
+    unsigned long long* clocks;   // SDFGPU_PHASE_CLOCKS builds only: per-phase shader-clock sums over waves ([stage - 2][8])
     int dbg;                  // profiling aid (wrong results!): bit0 skip upper levels, bit1 skip chunk search, bit2 skip stores,
                               // bit3 skip the second class, bit4 skip key conversion
 };

@@ -1,0 +1,558 @@
+// sdfgpu_envelope_v3.hpp -- KE2 / KE3, third generation: the far-field y / x sweep as a three-level, 8-ary exact
+// min-plus search built from ONE inner loop.
+//
+// Along one line the sweep computes D(p) = min_q F(q) + (p - q)^2 (F = squared distance inside the rows already
+// swept, "no site" = +inf).  c(p, q) = F(q) + (p - q)^2 is a Monge array, so for any argmin a(p1) at p1 < p2 there is
+// an argmin a(p2) >= a(p1): once the argmins of two positions are known, every position between them only needs the
+// candidates between those argmins (sdfgpu_envelope_dc.hpp, the second generation, has the derivation).
+//
+// What changed against the second generation (binary subdivision, one position per lane per level, ~10 barriers per
+// tile, 2.5 wave-level VALU instructions per voxel of which the levels above the chunk phase were 40 %; the kernel
+// is VALU-bound -- 90 % of the SIMD issue slots -- so instructions are what counts):
+//   * ONE primitive does the searching: a lane holds 8 positions with a common stride and streams a candidate range
+//     past them, two candidates per LDS read (ds_read_b64), 3 VALU per position and candidate pair:
+//         v0 = key[q] - c_k * q',  v1 = key[q+1] - c_k * (q'+1)      (v_mad_i32_i24 x 2)
+//         best_k = min(best_k, v0, v1)                               (v_min3_u32)
+//     Level B runs it with stride 8 inside each interval of level A, level C with stride 1 inside each interval of
+//     level B (the "chunk phase").  Level A (positions 64 i) scans one position per lane over a range clipped by a
+//     distance bound (below); 5 barriers per tile and pass, no per-position set-up code in the loops.
+//   * Centred coordinates.  With h = ceil(L / 2), q' = q - h, p' = p - h and
+//         key[q] = ((F(q) + q'^2 + h^2) << B) | q
+//     the candidate value key[q] - ((2 p') << B) * q' equals ((F(q) + (p - q)^2 + (h^2 - p'^2)) << B) | q, which is
+//     non-negative and below 2^32 whenever finf + (L + 2)^2 < 2^(32 - B): the multiply-add form needs no more key
+//     bits than the running-sum form of the second generation did, and no per-position term inside the loop.
+//   * Distance-bound clipping with the tile's smallest site value m: any candidate's value v bounds the optimum of a
+//     position p, and a candidate farther than sqrt(v - m) from p costs more than v.  The scenes this kernel serves
+//     have lines far from every object, where F is large but nearly flat: v - m is then small although v is not.
+//   * Staging writes each key with one clamp + one shift-add; which voxels are filled is not kept anywhere: in the
+//     pass that serves free voxels a voxel is filled iff its result is 0 (only a filled voxel is a site with F = 0),
+//     and the other way round in the second pass.
+//   * The site span (first / last candidate) is kept per TILE (wave ballots in the staging loop); the tile's 16 lines
+//     see nearly the same sites (in the first pass exactly the same: a row / plane either holds a filled voxel or not).
+//   * Any line count: tiles that stick out of their line group replicate the last line on load and mask the stores;
+//     shapes without 4-element alignment use scalar loads (template parameter VEC).
+// Exactness: integer arithmetic throughout; the finish is the reference's (sqrt and multiply in fp64, one cast,
+// sdf_generation.hpp:254-265).
+#pragma once
+#include "sdfgpu_envelope_dc.hpp"
+
+namespace sdfgpu {
+
+constexpr int kV3Lines = 16;
+constexpr int kV3Batch = 8;          // staging: row loads in flight per lane (a 512-line is staged from ONE round of loads)
+
+inline int envelope_v3_pitch(int L) { return ((L + 63) / 64) * 64 + 2; }        // >= L + 2, == 2 mod 64, even (8-byte pairs)
+inline size_t envelope_v3_lds_bytes(int L) {
+    const int M = (L + 7) / 8;
+    return ((size_t)kV3Lines * envelope_v3_pitch(L) + (size_t)(M + 2) * kV3Lines + 32 + kDcLocalFilled) * 4;
+}
+
+// a * b + c on the low 24 bits of a and b (signed), low 32 bits of the result: one full-rate instruction.  (Written as
+// __mul24(a, b) + c the compiler keeps explicit sign extensions of the operands inside the loop.)
+__device__ __forceinline__ uint32_t mad_i24(int a, int b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (HIP's overloaded min() picks the double version for some unsigned argument pairs: v_cvt_f64_u32 + v_min_f64 + v_cvt_u32_f64)
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// Profiling builds (-DSDFGPU_PHASE_CLOCKS, never the shipped library): shader-clock time per phase, summed over waves.
+#ifdef SDFGPU_PHASE_CLOCKS
+#define V3_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk[k] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define V3_STAMP(k) do {} while (0)
+#endif
+
+template <int STAGE, bool VEC>
+__global__ __launch_bounds__(256, 4) void k_envelope_v3(const EnvDcArgs a) {
+    constexpr int NL = kV3Lines, NT = 256;
+    extern __shared__ __attribute__((aligned(16))) uint32_t v3_smem[];
+    if (a.guard) {
+        const uint32_t gv = *a.guard;
+        if ((gv != 0u) == (a.guard_invert != 0)) return;
+    }
+    const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
+    if (a.probe_stride > 0 && a.i32_flag && i32) return;       // the x tier is already decided: no probe
+    const int L = a.L, B = a.B, pitch = a.pitch, M = a.M, h = a.h;
+    const int MA = (L + 63) >> 6;
+    const uint32_t mask = (1u << B) - 1u, finf = a.finf;
+    // position multipliers -(2 p') << B (|.| < 2^23: 24-bit multiplies), as shifts of h - p
+    auto ncof = [&](int p) -> int { return (int)((uint32_t)(h - p) << (B + 1)); };
+    uint32_t* const keys = v3_smem;                             // [16][pitch]
+    uint32_t* const args = keys + NL * pitch;                   // [M + 2][16]  best value (distance << B | argmin) of coarse position 8 i
+    uint32_t* const misc = args + (M + 2) * NL;                 // [0..3] span lo per wave, [4..7] span hi, [8..11] smallest site value, [16] filled voxels listed, [17] second pass wanted, [18..20] probe
+    uint32_t* const flist = misc + 32;                          // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
+    const int t = threadIdx.x;
+#ifdef SDFGPU_PHASE_CLOCKS
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
+
+    // tile of this workgroup (XCD-aware order: see the second generation)
+    int64_t tile = blockIdx.x;
+    const bool probe = a.probe_stride > 0;
+    if (probe) {
+        tile = (int64_t)blockIdx.x * a.probe_stride + (blockIdx.x * 7u) % (uint32_t)a.probe_stride;
+    } else if ((gridDim.x & 31u) == 0u) {
+        const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+        tile = ((int64_t)(seq >> 2) * 8 + xcd) * 4 + (seq & 3u);
+    }
+    const int64_t o = tile / a.tiles_per_outer;
+    const int64_t c0 = (tile - o * a.tiles_per_outer) * NL;
+    const int nvalid = (int)min((int64_t)NL, a.group_lines - c0);     // lines of this tile that exist
+    const int64_t base = o * a.outer_stride + c0;               // element index of (line 0, position 0)
+    const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
+    const int16_t* const in16 = a.in16 + base;
+    const int32_t* const side_in = STAGE == 3 ? a.side_in + base : nullptr;
+    const int32_t* const in32 = (STAGE == 3 && a.in_i32 && i32) ? a.in_i32 + base : nullptr;
+    const bool out32 = STAGE == 2 && a.out_i32 && i32;
+
+    int mxF = 0, mxQ = 0;
+    auto byz_of = [&](int line) -> int {        // virtual-border distance of a line to the padded layer over y and z
+        int64_t b = kInf32;
+        if constexpr (STAGE == 3) {
+            if (a.vb) {
+                const int64_t c = c0 + line;
+                const int64_t vyl = c / a.nz, vz = c - vyl * a.nz;
+                const int64_t vy = vyl + a.y_off;
+                if (a.ny_glob > 1) b = min(b, min(vy + 1, a.ny_glob - vy));
+                if (a.nz > 1) b = min(b, min(vz + 1, a.nz - vz));
+            }
+        }
+        return (int)b;
+    };
+    const int lineT = t & (NL - 1), slotT = t >> 4;             // (line, slot) mapping of levels B and C
+    const bool lineT_ok = lineT < nvalid;
+    const int byz = byz_of(lineT);
+
+    // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
+    auto raw_signed = [&](int line, int q) -> int {
+        const uint32_t idx = (uint32_t)line + (uint32_t)q * ls;
+        if (STAGE == 3 && in32) return in32[idx];
+        int v = in16[idx];
+        if constexpr (STAGE == 2) {
+            const int g = abs(v);
+            const int sq = g >= kInf16 ? kInf32 : g * g;
+            return v < 0 ? -sq : sq;
+        } else {
+            if (abs(v) >= kSat16) v = side_in[idx];
+            return v;
+        }
+    };
+    // finish one FILLED voxel of pass 0's local search (rare path; the chunk phase has its own, vectorised finish)
+    auto emit_filled = [&](uint32_t oi, int p, int D, int b_yz) {
+        if constexpr (STAGE == 2) {
+            if (out32) { (a.out_i32 + base)[oi] = -D; return; }
+            (reinterpret_cast<int16_t*>(a.out) + base)[oi] = (int16_t)(-imin(D, kSat16));
+            (a.side_out + base)[oi] = -D;
+        } else {
+            if (a.vb) {
+                int b = b_yz;
+                if (a.nx > 1) b = imin(b, (int)min((int64_t)p + 1, a.nx - p));
+                if (b < 32768) D = imin(D, (int)__umul24((uint32_t)b, (uint32_t)b));
+            }
+            mxQ = imax(mxQ, D);
+            const float f = (D >= kInf32) ? __builtin_inff() : (float)(sqrt_exact_pos((double)D) * a.resolution);
+            (reinterpret_cast<float*>(a.out) + base)[oi] = -f;
+        }
+    };
+    int probe_far = 0, probe_tot = 0, probe_mid = 0;
+
+    // THE inner loop: 8 positions (multipliers nc[k] = -((2 p'_k) << B)) against the candidates qs, qs + step, ... <= qe
+    // taken in aligned pairs (qs even).  Candidates outside the caller's range that ride along in a pair are harmless:
+    // any candidate's value is an upper bound of the optimum, and whatever wins is a true argmin of the position.
+    auto scan8 = [&](const uint32_t* kl, int qs, int qe, int step, const int (&nc)[8], uint32_t (&best)[8]) {
+        int qc = qs - h;
+        const uint32_t* kp = kl + qs;
+        for (int q = qs; q <= qe; q += step) {
+            const uint2 kk = *reinterpret_cast<const uint2*>(kp);
+            const int qc1 = qc + 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) best[k] = umin(best[k], umin(mad_i24(qc, nc[k], kk.x), mad_i24(qc1, nc[k], kk.y)));
+            kp += step;
+            qc += step;
+        }
+    };
+
+    // one pass over the tile.  CLS 0: sites of "distance to filled" (results for free voxels); 1: the reverse, on the
+    // negated field.
+    auto run_pass = [&](auto cls_tag) {
+        constexpr int cls = decltype(cls_tag)::value;
+        for (int i = t; i < (M + 2) * NL; i += NT) args[i] = 0xFFFFFFFFu;
+        if (cls == 0 && t < 32) misc[t] = 0u;
+
+        // ---- stage the tile: rows -> keys ------------------------------------------------------------------------------------
+        // A lane reads 4 lines x 1 position per load (VEC: one 8 / 16-byte load), kV3Batch loads in flight, and writes the
+        // four keys.
+        const int sub = t & 3, r = t >> 2;
+        uint32_t* const kb = keys + (4 * sub) * pitch + r;
+        int lsel[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lsel[k] = imin(4 * sub + k, nvalid - 1);
+        const uint32_t off_r = (uint32_t)r * ls + 4u * sub, off_last = (uint32_t)(L - 1) * ls + 4u * sub;
+        int lo_w = 0x7fffffff, hi_w = -1;                       // span seen by this wave (uniform)
+        uint32_t mt = 0xFFFFFFFFu;                              // smallest site value seen by this lane
+        for (int pb = 0; pb < L; pb += 64 * kV3Batch) {
+            int sv[kV3Batch][4];
+#pragma unroll
+            for (int it = 0; it < kV3Batch; ++it) {
+                // (rows past the end of the line re-read the last row; their keys are not written)
+                const uint32_t off = (pb + 64 * it + r < L) ? off_r + (uint32_t)(pb + 64 * it) * ls : off_last;
+                if constexpr (VEC) {
+                    if (STAGE == 3 && in32) {
+                        const int4 e = *reinterpret_cast<const int4*>(in32 + off);
+                        sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
+                    } else {
+                        const uint2 raw = *reinterpret_cast<const uint2*>(in16 + off);
+                        sv[it][0] = (int)(short)(raw.x & 0xffffu); sv[it][1] = (int)raw.x >> 16;
+                        sv[it][2] = (int)(short)(raw.y & 0xffffu); sv[it][3] = (int)raw.y >> 16;
+                        if constexpr (STAGE == 3) {
+                            // a 16-bit lane is saturated iff it holds +-32767 (-32768 is never stored): |v| + 1 has bit 15 set
+                            const uint32_t n0 = (raw.x >> 15) & 0x00010001u, n1 = (raw.y >> 15) & 0x00010001u;
+                            const uint32_t m0 = (raw.x ^ (n0 * 0xFFFFu)) + 0x00010001u + n0;
+                            const uint32_t m1 = (raw.y ^ (n1 * 0xFFFFu)) + 0x00010001u + n1;
+                            if (((m0 | m1) & 0x80008000u) != 0u) {
+                                const int4 e = *reinterpret_cast<const int4*>(side_in + off);
+                                sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t idx = off - 4u * sub + (uint32_t)lsel[k];
+                        int v;
+                        if (STAGE == 3 && in32) v = in32[idx];
+                        else {
+                            v = in16[idx];
+                            if constexpr (STAGE == 3) if (abs(v) >= kSat16) v = side_in[idx];
+                        }
+                        sv[it][k] = v;
+                    }
+                }
+            }
+            if (pb == 0) __syncthreads();                       // args / misc initialised (the loads above are in flight meanwhile)
+#pragma unroll
+            for (int it = 0; it < kV3Batch; ++it) {
+                const int p = pb + 64 * it + r;
+                const bool inl = p < L;
+                const int pc = p - h;
+                const uint32_t cpos = (mad_i24(pc, pc, (uint32_t)(h * h)) << B) | (uint32_t)p;
+                uint32_t F[4];
+                int neg = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int s1 = cls == 0 ? sv[it][k] : -sv[it][k];
+                    if constexpr (STAGE == 2) {
+                        const uint32_t m = (uint32_t)imax(s1, 0);
+                        F[k] = umin(__umul24(m, m), finf);
+                    } else {
+                        F[k] = (uint32_t)imin(imax(s1, 0), (int)finf);
+                    }
+                    neg |= s1;
+                }
+                if (inl) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) kb[k * pitch + (pb + 64 * it)] = (F[k] << B) + cpos;
+                }
+                const uint32_t fmin4 = inl ? umin(umin(F[0], F[1]), umin(F[2], F[3])) : finf;
+                mt = umin(mt, fmin4);
+                const uint64_t bal = __ballot(fmin4 < finf);
+                if (bal) {                                      // (wave-uniform: scalar code)
+                    const int pw = pb + 64 * it + ((t >> 6) << 4);
+                    lo_w = imin(lo_w, pw + ((__ffsll((unsigned long long)bal) - 1) >> 2));
+                    hi_w = imax(hi_w, pw + ((63 - __clzll((long long)bal)) >> 2));
+                }
+                if (cls == 0 && neg < 0 && inl) {               // filled voxels (rare in the scenes this kernel serves): list them
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int s1 = sv[it][k];
+                        if (s1 < 0 && 4 * sub + k < nvalid) {
+                            uint32_t S = (uint32_t)(-s1);       // squared distance to the nearest free voxel so far
+                            if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
+                            const uint32_t e = atomicAdd(&misc[16], 1u);
+                            if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | umin(S, 255u);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mt = umin(mt, (uint32_t)__shfl_xor((int)mt, off));
+        if ((t & 63) == 0) { misc[t >> 6] = (uint32_t)lo_w; misc[4 + (t >> 6)] = (uint32_t)hi_w; misc[8 + (t >> 6)] = mt; }
+        if (t < 2 * NL) {                                       // two sentinels behind every line (pairs are read 8-byte aligned)
+            const int line = t >> 1, q = L + (t & 1), qc = q - h;
+            keys[line * pitch + q] = ((finf + (uint32_t)(qc * qc) + (uint32_t)(h * h)) << B) | ((uint32_t)q & mask);
+        }
+        __syncthreads();
+        V3_STAMP(0);
+        const int lo_t = imin(imin((int)misc[0], (int)misc[1]), imin((int)misc[2], (int)misc[3]));
+        const int hi_t = imax(imax((int)misc[4], (int)misc[5]), imax((int)misc[6], (int)misc[7]));
+        const uint32_t mt_t = umin(umin(misc[8], misc[9]), umin(misc[10], misc[11]));
+        const bool act = lo_t <= hi_t;                          // the tile holds a site (block-uniform)
+
+        if (act) {
+            // ---- level A: positions 64 i ---------------------------------------------------------------------------------------
+            // Two forms, chosen per line (= per 16-lane row): (a) one position per lane group over a range clipped by the
+            // distance bound -- a few candidates per position wherever the line runs near sites or far from ALL of them;
+            // (b) when the clipped ranges stay long (objects at different distances: the bound v - m is then large), the 16
+            // lanes split the span and every lane takes its share of the candidates for 8 positions at once.
+            {
+                const int lineA = t >> 4, u = t & 15;
+                const uint32_t* klA = keys + lineA * pitch;
+                const int span_pairs = (hi_t - (lo_t & ~1)) / 2 + 1;
+                int G = 1;                                      // form (a): lanes per position
+                while (2 * G * MA <= 16) G *= 2;
+                const int v = u & (G - 1), i1 = u / G;
+                int lo = lo_t, hi = hi_t, nc1 = 0;
+                bool clip = false;
+                if (MA <= 16) {
+                    int prs = 0;
+                    if (i1 < MA) {
+                        const int p = 64 * i1;
+                        nc1 = ncof(p);
+                        // any candidate bounds the optimum: try the candidate next to p and the two ends of the span
+                        const int pcl = imin(imax(p, lo_t), hi_t);
+                        const uint32_t ub = umin(mad_i24(pcl - h, nc1, klA[pcl]), umin(mad_i24(lo_t - h, nc1, klA[lo_t]), mad_i24(hi_t - h, nc1, klA[hi_t])));
+                        const uint32_t dub = (ub >> B) - __umul24((uint32_t)p, (uint32_t)(2 * h - p));
+                        if (dub < finf) {
+                            const int w = (int)__builtin_sqrtf((float)(dub - umin(mt_t, dub))) + 2;
+                            lo = imax(lo, p - w);
+                            hi = imin(hi, p + w);
+                        }
+                        prs = (hi - (lo & ~1)) / 2 + 1;
+                    }
+                    int rmax = prs;                             // longest clipped range of the line (row maximum)
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x128, 0xF, 0xF, true));      // row_ror:8
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x124, 0xF, 0xF, true));      // row_ror:4
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x122, 0xF, 0xF, true));      // row_ror:2
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x121, 0xF, 0xF, true));      // row_ror:1
+                    // cost per lane: (a) ceil(rmax / G) trips of ~8 instructions, (b) ceil(span_pairs / 16) trips of ~29 per 8 positions
+                    clip = ((rmax + G - 1) / G) * 8 <= ((span_pairs + 15) / 16) * 29 * ((MA + 7) / 8);
+                }
+                if (clip) {
+                    if (i1 < MA) {
+                        uint32_t best = 0xFFFFFFFFu;
+                        int q = (lo & ~1) + 2 * v, qc = q - h;
+                        const uint32_t* kp = klA + q;
+                        for (; q <= hi; q += 2 * G) {
+                            const uint2 kk = *reinterpret_cast<const uint2*>(kp);
+                            best = umin(best, umin(mad_i24(qc, nc1, kk.x), mad_i24(qc + 1, nc1, kk.y)));
+                            kp += 2 * G;
+                            qc += 2 * G;
+                        }
+                        atomicMin(&args[(8 * i1) * NL + lineA], best);
+                    }
+                } else {
+                    for (int g = 0; g < MA; g += 8) {
+                        int nc[8];
+                        uint32_t best[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            nc[k] = ncof(64 * imin(g + k, MA - 1));
+                            best[k] = 0xFFFFFFFFu;
+                        }
+                        scan8(klA, (lo_t & ~1) + 2 * u, hi_t, 32, nc, best);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (g + k < MA) atomicMin(&args[(8 * (g + k)) * NL + lineA], best[k]);
+                    }
+                }
+            }
+            __syncthreads();
+            V3_STAMP(1);
+            // ---- level B: positions 64 i + 8 k inside interval i; lane = (line, interval[, share of the candidates]) ------------
+            {
+                int Hs = 1;                                     // lanes per interval (16 slots per line)
+                while (2 * Hs * MA <= 16) Hs *= 2;
+                const uint32_t* kl = keys + lineT * pitch;
+                for (int i = slotT / Hs; i < MA; i += 16 / Hs) {
+                    const int u = slotT % Hs;
+                    const int lo = (int)(args[(8 * i) * NL + lineT] & mask);
+                    const int hi = (i + 1 < MA) ? (int)(args[(8 * (i + 1)) * NL + lineT] & mask) : hi_t;
+                    int nc[8];
+                    uint32_t best[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        nc[k] = ncof(64 * i + 8 * k);
+                        best[k] = 0xFFFFFFFFu;
+                    }
+                    scan8(kl, (lo & ~1) + 2 * u, hi, 2 * Hs, nc, best);
+#pragma unroll
+                    for (int k = 1; k < 8; ++k)
+                        if (8 * i + k < M) atomicMin(&args[(8 * i + k) * NL + lineT], best[k]);
+                }
+            }
+            __syncthreads();
+            V3_STAMP(2);
+        }
+
+        // ---- level C: lane = (line, chunk of 8 positions); finish and store ---------------------------------------------------
+        {
+            const uint32_t* kl = keys + lineT * pitch;
+            for (int i0 = 0; i0 < M; i0 += 16) {
+                const int i = i0 + slotT;
+                if (i >= M || !lineT_ok) continue;
+                const int p0 = 8 * i;
+                int D[8];
+                if (act) {
+                    const int a0 = (int)(args[i * NL + lineT] & mask);
+                    const int a8 = (i + 1 < M) ? (int)(args[(i + 1) * NL + lineT] & mask) : hi_t;
+                    int nc[8];
+                    uint32_t best[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        nc[k] = ncof(p0 + k);
+                        best[k] = 0xFFFFFFFFu;
+                    }
+                    V3_STAMP(4);
+                    scan8(kl, a0 & ~1, a8, 2, nc, best);
+                    V3_STAMP(3);
+                    // D = (best >> B) - (h^2 - p'^2), h^2 - p'^2 = p (2 h - p): a running value, + (2 h - 2 p - 1) per position
+                    uint32_t hp = __umul24((uint32_t)p0, (uint32_t)(2 * h - p0));
+                    const uint32_t c1 = (uint32_t)(2 * h - 2 * p0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t d = (best[k] >> B) - hp;
+                        D[k] = d >= finf ? kInf32 : (int)d;
+                        hp += c1 - (uint32_t)(2 * k + 1);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) D[k] = kInf32;
+                }
+                // positions past the end of the line count as "not mine" (D = 0).  Pass 0: a voxel is filled iff its distance
+                // to the nearest filled voxel is 0; pass 1: free iff its distance to the nearest free voxel is 0 -- so in
+                // both passes the voxels this pass must write are exactly those with D != 0.
+                if (p0 + 8 > L) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (p0 + k >= L) D[k] = 0;
+                }
+                const uint32_t ob = (uint32_t)lineT + (uint32_t)p0 * ls;      // element offset of the chunk's first voxel
+                if (probe) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        probe_tot += D[k] != 0 ? 1 : 0;
+                        probe_far += D[k] >= a.probe_thr ? 1 : 0;
+                        probe_mid += D[k] >= a.probe_thr2 ? 1 : 0;
+                    }
+                    continue;
+                }
+                if constexpr (STAGE == 2) {
+                    if (out32) {
+                        char* const op = reinterpret_cast<char*>(a.out_i32 + base);      // (uniform base + 32-bit byte offset)
+                        uint32_t bo = ob * 4u;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            if (D[k] != 0) *reinterpret_cast<int32_t*>(op + bo) = cls == 1 ? -D[k] : D[k];
+                            bo += 4u * ls;
+                        }
+                    } else {
+                        // side-table convention (sdfgpu_sweep_x16.hpp): if ANY voxel of a group of 4 is saturated, the exact
+                        // values of the whole group must be in the side table.  A pass only knows its own class, so a voxel
+                        // also writes its exact value when its group holds a voxel of the other class.
+                        int16_t* const op = reinterpret_cast<int16_t*>(a.out) + base;
+                        int32_t* const sp = a.side_out + base;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const bool inl = p0 + k < L, mine = D[k] != 0;
+                            const int need = mine ? (D[k] >= kSat16 ? 1 : 0) : (inl ? 1 : 0);
+                            int any = need | __builtin_amdgcn_mov_dpp(need, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                            any |= __builtin_amdgcn_mov_dpp(any, 0x4E, 0xF, 0xF, true);                  // quad_perm [2,3,0,1]
+                            if (mine) {
+                                const uint32_t oi = ob + (uint32_t)k * ls;
+                                const int Ds = imin(D[k], kSat16);
+                                op[oi] = (int16_t)(cls == 1 ? -Ds : Ds);
+                                if (cls == 1 || any) sp[oi] = cls == 1 ? -D[k] : D[k];
+                            }
+                        }
+                    }
+                } else {
+                    if (a.vb) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            int b = byz;
+                            if (a.nx > 1) b = imin(b, (int)min((int64_t)(p0 + k) + 1, a.nx - (p0 + k)));
+                            if (b < 32768) D[k] = imin(D[k], (int)__umul24((uint32_t)b, (uint32_t)b));      // (b >= 1: a voxel of the other class stays 0)
+                        }
+                    }
+                    char* const op = reinterpret_cast<char*>(reinterpret_cast<float*>(a.out) + base);     // (uniform base + 32-bit byte offset)
+                    uint32_t bo = ob * 4u;
+                    int mx = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        mx = imax(mx, D[k]);
+                        float f = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);                 // (D = 0: not stored)
+                        f = D[k] >= kInf32 ? __builtin_inff() : f;
+                        if (D[k] != 0) *reinterpret_cast<float*>(op + bo) = cls == 1 ? -f : f;
+                        bo += 4u * ls;
+                    }
+                    if (cls == 1) mxQ = imax(mxQ, mx); else mxF = imax(mxF, mx);
+                }
+            }
+            V3_STAMP(4);
+            // Pass 0 finishes the tile's filled voxels itself when they are few and shallow (thin surfaces): one lane per
+            // listed voxel, exact local search along its line.  Deep or numerous filled voxels raise misc[17] and the second
+            // pass does the class properly.
+            if (cls == 0 && !probe) {
+                const uint32_t nf = misc[16];
+                if (nf > (uint32_t)kDcLocalFilled) {
+                    if (t == 0) misc[17] = 1u;
+                } else {
+                    for (uint32_t e = (uint32_t)t; e < nf; e += (uint32_t)NT) {
+                        const uint32_t ent = flist[e];
+                        const int fl = (int)(ent >> 24), p = (int)((ent >> 8) & 0xffffu);
+                        int D1 = (int)(ent & 0xffu);
+                        if (D1 > kDcLocalMax) { misc[17] = 1u; continue; }
+                        for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
+                            if (p - d >= 0) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p - d), 0));
+                            if (p + d < L) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p + d), 0));
+                        }
+                        emit_filled((uint32_t)fl + (uint32_t)p * ls, p, D1, byz_of(fl));
+                    }
+                }
+            }
+        }
+        V3_STAMP(5);
+        __syncthreads();                        // keys / args are rebuilt by the next class; misc[17] is complete
+        V3_STAMP(6);
+    };
+
+    run_pass(std::integral_constant<int, 0>{});
+    // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose in-row
+    // squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can only matter
+    // while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises misc[17] for the rest.
+    if (!probe && misc[17] != 0u) run_pass(std::integral_constant<int, 1>{});      // (block-uniform)
+
+#ifdef SDFGPU_PHASE_CLOCKS
+    if (a.clocks && (t & 63) == 0 && !probe && (blockIdx.x & 31u) == 5u) {     // a sample: same-address atomics serialise
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(a.clocks + (STAGE - 2) * 8 + k, clk[k]);
+    }
+#endif
+    if (probe) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            probe_far += __shfl_xor(probe_far, off);
+            probe_tot += __shfl_xor(probe_tot, off);
+            probe_mid += __shfl_xor(probe_mid, off);
+        }
+        if ((t & 63) == 0) { atomicAdd(&misc[18], (uint32_t)probe_far); atomicAdd(&misc[19], (uint32_t)probe_tot); atomicAdd(&misc[20], (uint32_t)probe_mid); }
+        __syncthreads();
+        if (t == 0) { atomicAdd(a.probe_out, misc[18]); atomicAdd(a.probe_out + 1, misc[19]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, misc[20]); }
+        return;
+    }
+    if constexpr (STAGE == 3) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            mxF = imax(mxF, __shfl_xor(mxF, off));
+            mxQ = imax(mxQ, __shfl_xor(mxQ, off));
+        }
+        if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * (NT / 64) + (t >> 6), mxF, mxQ);
+    }
+}
+
+}  // namespace sdfgpu
