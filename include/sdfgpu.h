@@ -330,8 +330,8 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * "march_window" / "x16_window" = 8 (force the radius-8 register windows of the y / x marching sweeps,
  * which the policy otherwise selects for mid-sparse scenes; "wide_y_from": the largest squared distance of the previous
  * build above which it does so for the y sweep, default 16), "dense_generic" (1 = shapes the tuned dense kernels do not take -- nz not 32 * 2^k, virtual border -- use their
- * generic forms, default; 0 = such shapes skip the dense tier), "envelope_dc" (1 = divide-and-conquer envelope kernel
- * where the shape allows, default; 0 = first-generation stack kernel), "tier_select" (1 = choose marching vs
+ * generic forms, default; 0 = such shapes skip the dense tier), "envelope_dc" (1 = the far-field kernel k_envelope_dc
+ * redoes sweeps whose bounded scans did not decide every voxel, default; 0 = never: the marching scans stay unbounded), "tier_select" (1 = choose marching vs
  * envelope sweep per axis on the device inside each build from a probe of the sweep's input, default; 0 = learn
  * it from the previous build on the handle), "far_threshold_y" / "far_fraction_den_y" and "..._x" (an axis counts as
  * far-field when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 36, 8 for the
@@ -339,8 +339,9 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * windows when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 24; den 0 = leave
  * the window to the host policy), "i32_handoff" (1 = when the y probe finds the scene far-field, the x sweep is the
  * far-field kernel too and takes an exact int32 plane field from the y sweep, default; 0 = 16-bit plane field + side
- * table between them and a probe of its own for the x axis), "dc_debug" (profiling aid of the far-field kernel: skips
- * phases, results are then wrong). */
+ * table between them and a probe of its own for the x axis).  Every option leaves the results exact: switches that
+ * skip work for profiling ("dc_debug", "ball_variant") exist only in libraries built with -DSDFGPU_DEBUG_HOOKS and are
+ * rejected with SDFGPU_ERR_INVALID_ARGUMENT by the shipped one. */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),

@@ -5,9 +5,7 @@
 #include "sdfgpu_sweep_x16.hpp"
 #include "sdfgpu_fused_zy.hpp"
 #include "sdfgpu_dense.hpp"
-#include "sdfgpu_envelope.hpp"
 #include "sdfgpu_envelope_dc.hpp"
-#include "sdfgpu_envelope_v3.hpp"
 
 #include <sys/mman.h>
 
@@ -49,7 +47,6 @@ struct sdfgpu_context {
     DeviceBuffer yzfield;    // int32 [N]   K2 output (32-bit pipeline) / side table (16-bit pipeline)
     DeviceBuffer plane16;    // int16 [N]   plane field of the 16-bit pipeline
     DeviceBuffer bits;       // uint32 [N/32] packed occupancy of the dense path
-    DeviceBuffer env;        // int2 [N] per-line stacks of the envelope kernels (far-field scenes)
     DeviceBuffer unc;        // uint32 [N/32] undecided bits handed from the dense ball kernel to its fix-up kernel
     DeviceBuffer tileflag;   // uint32 [tiles] which waves of a tile wrote unc words (kept zero between builds)
     DeviceBuffer fix_order;  // uint32 [kFixRows] (dx, dy) rows of the fix-up kernel sorted by dx^2 + dy^2
@@ -98,11 +95,9 @@ struct sdfgpu_context {
     int far_den[2] = {8, 24};
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
-    int dc_version = 3;              // far-field kernel generation: 3 = k_envelope_v3, 2 = k_envelope_dc (kept for A/B runs)
-    bool v3_lds_attr[4] = {false, false, false, false};
+    bool dc_lds_attr[4] = {false, false, false, false};
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
-    bool dc_lds_attr[2] = {false, false};   // large dynamic LDS enabled for k_envelope_dc<2> / <3>
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
     int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // outward-scan bounds of the marching kernels
     bool env_mode_y = false, env_mode_x = false;               // policy: run the envelope kernel alone on that axis
@@ -385,36 +380,16 @@ int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t h
     return vb ? launch_march<3, true>(h, a, vec4, s) : launch_march<3, false>(h, a, vec4, s);
 }
 
-// Shapes the divide-and-conquer envelope kernel takes: tiles of 16 memory-adjacent lines, keys that fit 32 bits.
+// Shapes the far-field kernel takes (any line count; keys must fit 32 bits: finf + (L + 2)^2 < 2^(32 - B)).
 struct DcGeometry { bool ok; int B; uint32_t finf; int pitch; int M, Kp; };
-struct DcExtra {                 // slab pipelines: int32 plane fields instead of p16 + side table, y-slab geometry
+struct DcExtra {                 // int32 plane fields instead of p16 + side table, y-slab geometry
     const int32_t* in_i32 = nullptr;
     int32_t* out_i32 = nullptr;
     int64_t y_off = 0, ny_glob = -1;
     const uint32_t* i32_flag = nullptr;     // device word: use the int32 fields only when it is non-zero (nullptr: always)
 };
-DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz,
-                                int64_t ny_full = -1) {
-    DcGeometry g{};
-    if (ny_full < 0) ny_full = ny;                            // (a y slab of a larger grid holds distances of the whole grid)
-    const int64_t L = stage == 2 ? ny : nx;
-    const int64_t group = stage == 2 ? nz : ny * nz;          // lines that are contiguous in memory
-    if (!h->envelope_dc || L < 1 || L > 1024 || (group % kDcLines) != 0 || (nz % 4) != 0 ||
-        nx * ny * nz >= (1ll << 31)) return g;                  // (the kernel uses 32-bit element offsets inside a tile's lines)
-    int B = 1;
-    while ((1ll << B) < L) ++B;
-    const int64_t finf = (nx - 1) * (nx - 1) + (ny_full - 1) * (ny_full - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2
-    if (finf + L * L >= (1ll << (32 - B))) return g;
-    g.ok = true; g.B = B; g.finf = (uint32_t)finf;
-    g.pitch = (int)(((L + 2 + 31) / 32) * 32 + 1);
-    g.M = (int)((L + kDcChunk - 1) / kDcChunk);
-    g.Kp = 0;
-    while ((1 << g.Kp) <= g.M) ++g.Kp;
-    return g;
-}
-
-// Third generation (sdfgpu_envelope_v3.hpp): any line count, keys must fit 32 bits: finf + (L + 2)^2 < 2^(32 - B).
-DcGeometry envelope_v3_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz, int64_t ny_full = -1) {
+// Longer lines, larger grids (L > 2048, finf + (L + 2)^2 >= 2^(32 - B), 2^31 voxels or more): the marching sweeps with unbounded scans.
+DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz, int64_t ny_full = -1) {
     DcGeometry g{};
     if (ny_full < 0) ny_full = ny;
     const int64_t L = stage == 2 ? ny : nx;
@@ -424,17 +399,16 @@ DcGeometry envelope_v3_geometry(const sdfgpu_context* h, int stage, int64_t nx, 
     const int64_t finf = (nx - 1) * (nx - 1) + (ny_full - 1) * (ny_full - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2
     if (finf + (L + 2) * (L + 2) >= (1ll << (32 - B))) return g;
     if ((L + 2) * (2ll << B) >= (1ll << 23)) return g;            // 24-bit multiplier operands
-    if (envelope_v3_lds_bytes((int)L) > 160 * 1024) return g;
+    if (envelope_dc_lds_bytes((int)L) > 160 * 1024) return g;
     g.ok = true; g.B = B; g.finf = (uint32_t)finf;
-    g.pitch = envelope_v3_pitch((int)L);
+    g.pitch = envelope_dc_pitch((int)L);
     g.M = (int)((L + 7) / 8);
     g.Kp = 0;
     return g;
 }
 
 bool far_geometry_ok(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz, int64_t ny_full = -1) {
-    return (h->dc_version >= 3 && envelope_v3_geometry(h, stage, nx, ny, nz, ny_full).ok) ||
-           envelope_dc_geometry(h, stage, nx, ny, nz, ny_full).ok;
+    return envelope_dc_geometry(h, stage, nx, ny, nz, ny_full).ok;
 }
 
 // KE2 / KE3: exact far-field sweeps.  guard: run iff (*guard != 0) != guard_invert (nullptr: always).
@@ -443,15 +417,16 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
                     uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s, int guard_invert = 0,
                     uint32_t* probe_out = nullptr, const DcExtra* ex = nullptr) {
     (void)d_maxdsq;
-    const DcGeometry g3 = h->dc_version >= 3 ? envelope_v3_geometry(h, stage, nx, ny, nz, ex ? ex->ny_glob : -1) : DcGeometry{};
-    if (g3.ok) {
+    const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz, ex ? ex->ny_glob : -1);
+    if (!g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "shape not taken by the far-field kernel (internal: callers check the geometry first)");
+    {
         EnvDcArgs a{};
         a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
         int64_t ntiles;
-        constexpr int NL = kV3Lines;
+        constexpr int NL = kDcLines;
         if (stage == 2) { a.group_lines = nz; a.tiles_per_outer = (nz + NL - 1) / NL; ntiles = nx * a.tiles_per_outer; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
         else { a.group_lines = ny * nz; a.tiles_per_outer = (ny * nz + NL - 1) / NL; ntiles = a.tiles_per_outer; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
-        a.B = g3.B; a.finf = g3.finf; a.pitch = g3.pitch; a.M = g3.M; a.Kp = 0; a.h = (a.L + 1) / 2;
+        a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = 0; a.h = (a.L + 1) / 2;
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
         a.y_off = 0; a.ny_glob = ny;
         if (ex) {
@@ -459,6 +434,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
         }
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
+#ifdef SDFGPU_DEBUG_HOOKS
+        a.dbg = h->dc_debug;
+#endif
 #ifdef SDFGPU_PHASE_CLOCKS
         if (!h->d_clocks) { HIP_TRY(h, hipMalloc((void**)&h->d_clocks, 16 * 8)); HIP_TRY(h, hipMemset(h->d_clocks, 0, 16 * 8)); }
         a.clocks = h->d_clocks;
@@ -477,83 +455,22 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         // vector loads: 4 consecutive lines per load, whole tiles, aligned rows
         auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) % n) == 0; };
         const bool vec = (nz % 4) == 0 && (a.group_lines % NL) == 0 && al(d_in16, 8) && al(d_side_in, 16) && al(a.in_i32, 16);
-        const size_t lds = envelope_v3_lds_bytes(a.L);
-        const void* fn = stage == 2 ? (vec ? (const void*)k_envelope_v3<2, true> : (const void*)k_envelope_v3<2, false>)
-                                    : (vec ? (const void*)k_envelope_v3<3, true> : (const void*)k_envelope_v3<3, false>);
+        const size_t lds = envelope_dc_lds_bytes(a.L);
+        const void* fn = stage == 2 ? (vec ? (const void*)k_envelope_dc<2, true> : (const void*)k_envelope_dc<2, false>)
+                                    : (vec ? (const void*)k_envelope_dc<3, true> : (const void*)k_envelope_dc<3, false>);
         const int fi = (stage - 2) * 2 + (vec ? 1 : 0);
-        if (lds > 64 * 1024 && !h->v3_lds_attr[fi]) {
+        if (lds > 64 * 1024 && !h->dc_lds_attr[fi]) {
             HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            h->v3_lds_attr[fi] = true;
+            h->dc_lds_attr[fi] = true;
         }
         const dim3 grid((unsigned)ntiles), block(256);
-        if (stage == 2 && vec) hipLaunchKernelGGL((k_envelope_v3<2, true>), grid, block, lds, s, a);
-        else if (stage == 2) hipLaunchKernelGGL((k_envelope_v3<2, false>), grid, block, lds, s, a);
-        else if (vec) hipLaunchKernelGGL((k_envelope_v3<3, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((k_envelope_v3<3, false>), grid, block, lds, s, a);
+        if (stage == 2 && vec) hipLaunchKernelGGL((k_envelope_dc<2, true>), grid, block, lds, s, a);
+        else if (stage == 2) hipLaunchKernelGGL((k_envelope_dc<2, false>), grid, block, lds, s, a);
+        else if (vec) hipLaunchKernelGGL((k_envelope_dc<3, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((k_envelope_dc<3, false>), grid, block, lds, s, a);
         HIP_TRY(h, hipGetLastError());
         return SDFGPU_OK;
     }
-    const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz, ex ? ex->ny_glob : -1);
-    if (ex && !g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "int32 plane fields need the divide-and-conquer envelope kernel");
-    if (probe_out && !g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "probe needs the divide-and-conquer envelope kernel");
-    if (g.ok) {
-        EnvDcArgs a{};
-        a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
-        int64_t ntiles;
-        constexpr int NL = kDcLines;                            // lines per tile
-        if (stage == 2) { ntiles = nx * (nz / NL); a.tiles_per_outer = nz / NL; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
-        else { ntiles = ny * nz / NL; a.tiles_per_outer = ntiles; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
-        a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = g.Kp;
-        a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
-        a.y_off = 0; a.ny_glob = ny;
-        if (ex) {
-            a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
-            if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
-        }
-        a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert; a.dbg = h->dc_debug;
-        if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
-        if (probe_out) {                                        // sample ~256 tiles spread over the grid, store nothing
-            a.probe_stride = (int)std::max<int64_t>(1, std::min<int64_t>(64, ntiles / 256));
-            a.probe_thr = h->far_thr[stage - 2];
-            a.probe_thr2 = stage == 2 ? h->mid_thr_y : 0;
-            a.probe_out = probe_out;
-            ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
-            // the sampled tile index b * stride + (7 b mod stride) must stay inside the grid: drop the last block if needed
-            const int64_t all = stage == 2 ? nx * (nz / NL) : ny * nz / NL;
-            while (ntiles > 0 && (ntiles - 1) * a.probe_stride + ((ntiles - 1) * 7) % a.probe_stride >= all) --ntiles;
-            if (ntiles == 0) return SDFGPU_OK;
-        }
-        const size_t lds = envelope_dc_lds_bytes(a.L, a.pitch, NL);
-        // Measured alternatives to 16 lines x 256 lanes (4 workgroups = 16 waves per CU, ~120 VGPRs, 38 KB of LDS):
-        //   512 lanes on 16 lines (8 waves per SIMD): needs <= 64 VGPRs, spills, 1.2 - 2.3x slower;
-        //   8 lines x 128 lanes (7 workgroups per CU, the same waves per SIMD, more independent chains): 7 - 18 % slower --
-        //   the per-tile work of the levels is amortised over fewer voxels and the row segments halve (16 / 32 B);
-        //   32 lines x 512 lanes (2 workgroups per CU, full 128-B row segments, no spills): 3 - 8 % slower.
-        const void* fn = stage == 2 ? (const void*)k_envelope_dc<2, kDcLines> : (const void*)k_envelope_dc<3, kDcLines>;
-        if (lds > 64 * 1024 && !h->dc_lds_attr[stage - 2]) {
-            HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            h->dc_lds_attr[stage - 2] = true;
-        }
-        if (stage == 2) hipLaunchKernelGGL((k_envelope_dc<2, kDcLines>), dim3((unsigned)ntiles), dim3(16 * kDcLines), lds, s, a);
-        else hipLaunchKernelGGL((k_envelope_dc<3, kDcLines>), dim3((unsigned)ntiles), dim3(16 * kDcLines), lds, s, a);
-        HIP_TRY(h, hipGetLastError());
-        return SDFGPU_OK;
-    }
-    if (guard_invert) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "inverted guard needs the divide-and-conquer envelope kernel");
-    // first-generation kernel (one lane per line, stacks in a global scratch array of 8 B/voxel, allocated only here)
-    if (int rc = ensure(h, h->env, (size_t)(nx * ny * nz) * 8)) return rc;
-    EnvArgs a{};
-    a.in16 = d_in16; a.side_in = d_side_in; a.out = d_out; a.side_out = d_side_out;
-    a.scratch = (int2*)h->env.ptr;
-    if (stage == 2) { a.nlines = nx * nz; a.cpl = nz; a.outer_stride = ny * nz; a.line_stride = nz; a.L = (int)ny; }
-    else { a.nlines = ny * nz; a.cpl = a.nlines; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
-    a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
-    a.maxdsq = h->d_slots; a.guard = guard;
-    dim3 grid((unsigned)((a.nlines + kBlock - 1) / kBlock)), block(kBlock);
-    if (stage == 2) hipLaunchKernelGGL(k_envelope<2>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(k_envelope<3>, grid, block, 0, s, a);
-    HIP_TRY(h, hipGetLastError());
-    return SDFGPU_OK;
 }
 
 int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff = false, bool window_choice = false) {
@@ -784,13 +701,16 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         }
     }
     if (dense && h->dense_skip > 0) { --h->dense_skip; dense = false; }
-    const bool envelope = p16 && h->envelope_on && !(h->expect_dense && dense);
+    // bounded marching scans + the far-field kernel behind them, on every shape that kernel takes; other shapes (lines beyond
+    // 2048, keys beyond 32 bits) keep unbounded marching scans.  Shapes without the 16-bit plane field (nz % 4 != 0) hand
+    // exact int32 plane values from the y to the x sweep.
+    const bool envelope = h->envelope_on && !(h->expect_dense && dense) &&
+                          far_geometry_ok(h, 2, nx, ny, nz) && far_geometry_ok(h, 3, nx, ny, nz);
     // Device-side tier selection (needs the divide-and-conquer envelope kernel on both axes): the marching-vs-envelope
     // choice of each axis is made INSIDE this build from a probe of the sweep's own input, so a fresh context (the
     // reference's API is one-shot: collision_map.hpp:680-712 builds and returns) never runs a sweep that is thrown away.
     // Other shapes keep the host policy below (choice learned from the previous build on the handle).
-    const bool dev_select = envelope && h->tier_select &&
-                            far_geometry_ok(h, 2, nx, ny, nz) && far_geometry_ok(h, 3, nx, ny, nz);
+    const bool dev_select = envelope && p16 && h->tier_select;
     const bool env_y = envelope && !dev_select && h->env_mode_y, env_x = envelope && !dev_select && h->env_mode_x;
     // K12 (fused z+y) only as the guarded stand-by behind a dense build that is expected to be certified
     // again; everywhere else K1 + K2 (rows from the int16 z field) scan much faster than the fused kernel
@@ -917,10 +837,13 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(4));
+    DcExtra plain2{}, plain3{};                                 // shapes without the 16-bit plane field: int32 in / out, unconditionally
+    plain2.out_i32 = (int32_t*)h->yzfield.ptr;
+    plain3.in_i32 = (const int32_t*)h->yzfield.ptr;
     if (envelope && !fused) {
-        if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
+        if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, p16 ? h->plane16.ptr : nullptr, p16 ? (int32_t*)h->yzfield.ptr : nullptr,
                                      nx, ny, nz, resolution, vb, h->d_small, env_y ? h->guard : h->d_small + 4, s, 0, nullptr,
-                                     handoff ? &hand2 : nullptr)) return rc;
+                                     !p16 ? &plain2 : handoff ? &hand2 : nullptr)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(5));
@@ -944,16 +867,17 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                           0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
             launched_since_mark = true;
         }
-    } else {
+    } else if (!env_x) {
         if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
-                                    resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+                                    resolution, vb, h->d_small, h->d_small + 2, s, 0, -1,
+                                    h->far_y ? h->scan_x : 0, h->far_y ? h->far_y + 1 : nullptr)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(6));
     if (envelope && !fused) {
-        if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
+        if (int rc = launch_envelope(h, 3, p16 ? (const int16_t*)h->plane16.ptr : nullptr, p16 ? (const int32_t*)h->yzfield.ptr : nullptr, d_out, nullptr,
                                      nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s, 0, nullptr,
-                                     handoff ? &hand3 : nullptr)) return rc;
+                                     !p16 ? &plain3 : handoff ? &hand3 : nullptr)) return rc;
         launched_since_mark = true;
     }
     // one kernel folds the maxima, publishes the status block (device copy for get_extrema, pinned host copy for the
@@ -963,7 +887,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // enqueues builds back to back without ever synchronising keeps feeding the policy (a few builds late), and the
     // builds in between skip the host write.  What the reported build was (dense? fix-up? envelope mode?) is
     // remembered with the report -- not with whatever build happens to be the latest when it is read.
-    const bool report = p16 && h->envelope_on && h->h_flags_dev && !h->flags_pending;
+    const bool report = h->envelope_on && h->h_flags_dev && !h->flags_pending;
     if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : nullptr)) return rc;
     h->small_clean = true;
     h->guard = nullptr;
@@ -1211,7 +1135,7 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
 int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
-    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->env, &h->unc, &h->tileflag, &h->fix_order, &h->tagmask, &h->tagids, &h->stage_in,
+    for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->unc, &h->tileflag, &h->fix_order, &h->tagmask, &h->tagids, &h->stage_in,
                             &h->stage_out})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
@@ -1758,14 +1682,15 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense_generic") h->dense_generic_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;
     else if (n == "envelope_dc") h->envelope_dc = value != 0;
-    else if (n == "dc_debug") h->dc_debug = value;
-    else if (n == "dc_version") h->dc_version = value;
+#ifdef SDFGPU_DEBUG_HOOKS
+    else if (n == "dc_debug") h->dc_debug = value;              // profiling builds only: these skip work, results are then wrong
+    else if (n == "ball_variant") h->ball_variant = value;
+#endif
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
-    else if (n == "ball_variant") h->ball_variant = value;
     else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; h->dense_backoff = 0; h->fix_mode = false; h->wide_y = h->wide_x = false; }
     else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; }
     else if (n == "fixup_mode") h->fix_mode = value != 0;

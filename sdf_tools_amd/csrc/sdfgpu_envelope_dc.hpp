@@ -1,51 +1,62 @@
-// sdfgpu_envelope_dc.hpp -- KE2 / KE3, second generation: the far-field y / x sweep as a PARALLEL exact
-// min-plus search instead of a per-lane parabola stack.
+// sdfgpu_envelope_dc.hpp -- KE2 / KE3 (third generation of the far-field kernel): the far-field y / x sweep as a three-level, 8-ary exact
+// min-plus search built from ONE inner loop.
 //
 // Along one line the sweep computes D(p) = min_q F(q) + (p - q)^2 (F = squared distance inside the rows already
-// swept, "no site" = +inf).  The cost c(p, q) = F(q) + (p - q)^2 is a Monge array: c(p,q) + c(p',q') <=
-// c(p,q') + c(p',q) for p < p', q < q' (the F terms cancel, the rest is 2 (p'-p)(q-q') <= 0).  Hence for any
-// argmin a(p1) at p1 < p2 there is an argmin a(p2) >= a(p1) (and symmetrically from the right): once the argmin of
-// a middle position is known, the positions left of it only need the candidates up to it and the positions right
-// of it only the candidates from it on.  Recursing on halves gives ~ (log2 L + 1) x L candidate evaluations per
-// line (9.8 per position at L = 512, fewer when the sites cover only part of the line) -- about the instruction
-// count of the stack algorithm -- but every evaluation is independent of every other one in its level: no
-// push / pop chain, no per-line stack in memory (the first-generation kernel k_envelope spilled 8 B/voxel of stack
-// to a global scratch array and ran one lane per line, 16 waves per CU, at ~10 % of the HBM roofline).
-// tools/envelope_dc_model.py is an executable model of exactly this schedule, checked against brute force.
+// swept, "no site" = +inf).  c(p, q) = F(q) + (p - q)^2 is a Monge array, so for any argmin a(p1) at p1 < p2 there is
+// an argmin a(p2) >= a(p1): once the argmins of two positions are known, every position between them only needs the
+// candidates between those argmins (the F terms cancel in the quadrangle inequality c(p,q) + c(p',q') <= c(p,q') + c(p',q) for p < p', q < q': what is left is 2 (p'-p)(q-q') <= 0).
 //
-// Work decomposition.  A workgroup (256 lanes) owns a tile of 16 neighbouring lines (z-adjacent, so every global
-// row access is a contiguous 32 / 64-byte segment) and stages the whole tile in LDS as 32-bit KEYS
-//     key[q] = ((F(q) + q^2) << B) | q          B = bits of a position, "no site" uses F = finf
-// so that for a position p
-//     key[q] + (p^2 << B) - ((2p << B) * q)  =  ((F(q) + (p - q)^2) << B) | q       (mod 2^32, exact: < 2^32)
-// One unsigned min over such values yields the distance AND an argmin; walking q upward the linear term is
-// updated by one add, so a candidate costs ~2 VALU instructions + half an LDS read (keys are read in pairs).
-//   upper levels  positions p = 0, 8, 16, ... (coarse grid) by binary subdivision; 16 lanes per line: the first
-//                 levels split one position's candidate range over 16 / 8 / 4 / 2 lanes and min-reduce, later levels
-//                 give every lane its own positions.  Argmins go to a small LDS array.
-//   chunk phase   lane = (line, chunk of 8 positions): all 8 positions against every candidate between the argmins of the
-//                 chunk's two coarse neighbours, results converted and stored straight from the lane (16 lines x 2 / 4 B
-//                 contiguous per position).
-// Both classes of the signed field take one pass each (sites of "distance to filled" evaluated on free voxels,
-// then the reverse); a tile without filled voxels skips the second pass, and in it free voxels are sites only
-// next to a filled voxel of their line (only the ends of a run can be nearest to anything outside it).
+// What changed against the second generation (binary subdivision, one position per lane per level, ~10 barriers per
+// tile, 2.5 wave-level VALU instructions per voxel of which the levels above the chunk phase were 40 %; the kernel
+// is VALU-bound -- 90 % of the SIMD issue slots -- so instructions are what counts):
+//   * ONE primitive does the searching: a lane holds 8 positions with a common stride and streams a candidate range
+//     past them, two candidates per LDS read (ds_read_b64), 3 VALU per position and candidate pair:
+//         v0 = key[q] - c_k * q',  v1 = key[q+1] - c_k * (q'+1)      (v_mad_i32_i24 x 2)
+//         best_k = min(best_k, v0, v1)                               (v_min3_u32)
+//     Level B runs it with stride 8 inside each interval of level A, level C with stride 1 inside each interval of
+//     level B (the "chunk phase").  Level A (positions 64 i) scans one position per lane over a range clipped by a
+//     distance bound (below); 5 barriers per tile and pass, no per-position set-up code in the loops.
+//   * Centred coordinates.  With h = ceil(L / 2), q' = q - h, p' = p - h and
+//         key[q] = ((F(q) + q'^2 + h^2) << B) | q
+//     the candidate value key[q] - ((2 p') << B) * q' equals ((F(q) + (p - q)^2 + (h^2 - p'^2)) << B) | q, which is
+//     non-negative and below 2^32 whenever finf + (L + 2)^2 < 2^(32 - B): the multiply-add form needs no more key
+//     bits than the running-sum form of the second generation did, and no per-position term inside the loop.
+//   * Distance-bound clipping with the tile's smallest site value m: any candidate's value v bounds the optimum of a
+//     position p, and a candidate farther than sqrt(v - m) from p costs more than v.  The scenes this kernel serves
+//     have lines far from every object, where F is large but nearly flat: v - m is then small although v is not.
+//   * Staging writes each key with one clamp + one shift-add; which voxels are filled is not kept anywhere: in the
+//     pass that serves free voxels a voxel is filled iff its result is 0 (only a filled voxel is a site with F = 0),
+//     and the other way round in the second pass.
+//   * The site span (first / last candidate) is kept per TILE (wave ballots in the staging loop); the tile's 16 lines
+//     see nearly the same sites (in the first pass exactly the same: a row / plane either holds a filled voxel or not).
+//   * Any line count: tiles that stick out of their line group replicate the last line on load and mask the stores;
+//     shapes without 4-element alignment use scalar loads (template parameter VEC).
+// Measured and not kept (512^3, two-box scene and Bernoulli 1 % .. 0.01 %; tools/ff_check.sh, profiling builds with
+// -DSDFGPU_DEBUG_HOOKS / -DSDFGPU_PHASE_CLOCKS):
+//   * 512 lanes per tile inside 64 VGPRs (8 waves per SIMD): +-5 % either way -- not latency-bound;
+//   * 32-line tiles (128-byte row segments, 512 lanes): +-3 %, and twice the filled voxels per tile push Bernoulli 3 % into the
+//     second pass; the bare memory pattern (tools/probe/tile_copy_probe.hip) is 0.27 ms with 16-line and 0.22 ms with 32-line
+//     tiles against 0.17 ms for a linear copy of the same 8 B/voxel;
+//   * a persistent grid whose workgroups request the rows of their next tile before searching the current one: 10 - 25 %
+//     SLOWER on every scene (120 VGPRs, static tile assignment);
+//   * an LDS table of the finished values of small squared distances instead of the fp64 finish: no change -- removing the
+//     fp64 finish altogether does not change the time either (it overlaps with the integer pipe);
+//   * ablation of the x sweep on the two-box scene: no search 0.37 ms (of 0.55), no search and no stores 0.19 ms.
 // Exactness: integer arithmetic throughout; the finish is the reference's (sqrt and multiply in fp64, one cast,
-// sdf_generation.hpp:254-265).  Shapes whose keys do not fit 32 bits (finf + L^2 >= 2^(32-B)), L > 1024 or
-// line counts that are not multiples of 16 fall back to k_envelope (sdfgpu_envelope.hpp).
+// sdf_generation.hpp:254-265).
 #pragma once
 #include "sdfgpu_kernels.hpp"
 #include "sdfgpu_sweep_x16.hpp"
 
 namespace sdfgpu {
 
-constexpr int kDcLines = 16;          // lines per tile
-constexpr int kDcChunk = 8;           // positions per lane in the chunk phase
-constexpr int kDcBatch = 2;           // staging: row loads in flight per lane (register budget: 128 VGPRs at 4 waves per SIMD)
+// Rows the marching kernels scan outward before handing the sweep to the far-field kernel.  Long enough that mid-sparse
+// scenes (p = 0.01: distances up to ~30) never pay for a far-field pass they do not need.
+constexpr int kScanExpectNear = 40;
+
 constexpr int kDcLocalMax = 64;       // pass 0 finishes filled voxels whose in-row squared distance is at most this ...
-constexpr int kDcLocalFilled = 448;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second
-                                      // pass costs as much as the first: at 224 a 3 %-occupied scene -- 245 per tile --
-                                      // ran it everywhere, 1.9 instead of 0.57 ms; one packed word per entry keeps 448
-                                      // of them inside the LDS budget of 4 workgroups per CU)
+constexpr int kDcLocalFilled = 448;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second pass costs as much
+                                      // as the first: a 3 %-occupied 512^3 scene has 245 per tile and must stay below)
 
 struct EnvDcArgs {
     const int16_t* in16;      // STAGE 2: z field (+-g, 32767 = none); STAGE 3: plane field p16
@@ -61,8 +72,8 @@ struct EnvDcArgs {
     int L;                    // positions per line
     int B;                    // bits of the position field of a key
     uint32_t finf;            // "no site": larger than every real squared distance of this grid
-    int pitch;                // LDS words per line of keys (>= L + 2, == 1 mod 32)
-    int M, Kp;                // coarse positions ceil(L / 8) and levels (bit length of M)
+    int pitch;                // LDS words per line of keys (>= L + 2, == 2 mod 64)
+    int M, Kp;                // coarse positions ceil(L / 8); Kp unused
     double resolution;        // STAGE 3
     int vb;
     int64_t nx, ny, nz;       // full extents (virtual border)
@@ -78,11 +89,10 @@ struct EnvDcArgs {
     // both axes far-field: when *i32_flag != 0 the y sweep hands its result to the x sweep as an exact int32 plane field
     // (out_i32 / in_i32, the side-table buffer used whole) instead of p16 + side table; nullptr = the pointers alone decide
     const uint32_t* i32_flag;
-    int h;                    // third generation: centre of the key coordinates, ceil(L / 2)
-    int64_t group_lines;      // third generation: lines per outer unit (tiles that stick out replicate the last line)
+    int h;                    // centre of the key coordinates, ceil(L / 2)
+    int64_t group_lines;      // lines per outer unit (tiles that stick out replicate the last line)
     unsigned long long* clocks;   // SDFGPU_PHASE_CLOCKS builds only: per-phase shader-clock sums over waves ([stage - 2][8])
-    int dbg;                  // profiling aid (wrong results!): bit0 skip upper levels, bit1 skip chunk search, bit2 skip stores,
-                              // bit3 skip the second class, bit4 skip key conversion
+    int dbg;                  // SDFGPU_DEBUG_HOOKS builds only (wrong results): bit0 no search, bit1 no fp64 finish, bit2 no stores
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -102,17 +112,39 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
     return __builtin_fma(d1, h1, s2);
 }
 
-inline size_t envelope_dc_lds_bytes(int L, int pitch, int lines = kDcLines) {
-    const int SW = (L + 31) / 32, M = (L + kDcChunk - 1) / kDcChunk;
-    return ((size_t)lines * pitch + (size_t)lines * SW + 2 * (size_t)lines + 32 + kDcLocalFilled) * 4 + (size_t)lines * (M + 2) * 2;
+
+constexpr int kDcLines = 16;
+constexpr int kDcBatch = 8;          // staging: row loads in flight per lane (a 512-line is staged from ONE round of loads)
+
+inline int envelope_dc_pitch(int L) { return ((L + 63) / 64) * 64 + 2; }        // >= L + 2, == 2 mod 64, even (8-byte pairs)
+inline size_t envelope_dc_lds_bytes(int L) {
+    const int M = (L + 7) / 8;
+    return ((size_t)kDcLines * envelope_dc_pitch(L) + (size_t)(M + 2) * kDcLines + 32 + kDcLocalFilled) * 4;
 }
 
-template <int STAGE, int NL>          // NL lines per tile (16 or 8), 16 lanes per line
-__global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
-    constexpr int NT = 16 * NL;
-    constexpr int LSUB = NL / 4;        // staging: lanes per position (4 lines each)
-    constexpr int PS = NT / LSUB;       // positions staged per pass of the workgroup (= 64)
-    constexpr int NS = 16;              // (line, slot) mapping: slots per line
+// a * b + c on the low 24 bits of a and b (signed), low 32 bits of the result: one full-rate instruction.  (Written as
+// __mul24(a, b) + c the compiler keeps explicit sign extensions of the operands inside the loop.)
+__device__ __forceinline__ uint32_t mad_i24(int a, int b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (HIP's overloaded min() picks the double version for some unsigned argument pairs: v_cvt_f64_u32 + v_min_f64 + v_cvt_u32_f64)
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// Profiling builds (-DSDFGPU_PHASE_CLOCKS, never the shipped library): shader-clock time per phase, summed over waves.
+#ifdef SDFGPU_PHASE_CLOCKS
+#define DC_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk[k] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define DC_STAMP(k) do {} while (0)
+#endif
+
+template <int STAGE, bool VEC>
+__global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
+    constexpr int NL = kDcLines, NT = 256;
     extern __shared__ __attribute__((aligned(16))) uint32_t dc_smem[];
     if (a.guard) {
         const uint32_t gv = *a.guard;
@@ -120,24 +152,26 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
     }
     const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
     if (a.probe_stride > 0 && a.i32_flag && i32) return;       // the x tier is already decided: no probe
-    const int L = a.L, B = a.B, pitch = a.pitch, M = a.M, Kp = a.Kp;
-    const int SW = (L + 31) >> 5, AP = M + 2;
+    const int L = a.L, B = a.B, pitch = a.pitch, M = a.M, h = a.h;
+    const int MA = (L + 63) >> 6;
     const uint32_t mask = (1u << B) - 1u, finf = a.finf;
-    uint32_t* keys = dc_smem;                                   // [16][pitch]
-    uint32_t* sgn = keys + NL * pitch;                    // [16][SW]   bit p: voxel p of the line is filled
-    uint32_t* span = sgn + NL * SW;                       // [16][2]    first / last site of the line
-    uint32_t* flg = span + 2 * NL;                                  // [16] line holds a filled voxel, [16] = tile does
-    uint32_t* flist = flg + 32;                                 // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
-    uint16_t* args = reinterpret_cast<uint16_t*>(flist + kDcLocalFilled);   // [16][AP]   argmin of coarse position i' (1-based)
+    // position multipliers -(2 p') << B (|.| < 2^23: 24-bit multiplies), as shifts of h - p
+    auto ncof = [&](int p) -> int { return (int)((uint32_t)(h - p) << (B + 1)); };
+    uint32_t* const keys = dc_smem;                             // [16][pitch]
+    uint32_t* const args = keys + NL * pitch;                   // [M + 2][16]  best value (distance << B | argmin) of coarse position 8 i
+    uint32_t* const misc = args + (M + 2) * NL;                 // [0..3] span lo per wave, [4..7] span hi, [8..11] smallest site value, [16] filled voxels listed, [17] second pass wanted, [18..20] probe
+    uint32_t* const flist = misc + 32;                          // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
     const int t = threadIdx.x;
+#ifdef SDFGPU_PHASE_CLOCKS
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
 
     // tile of this workgroup.  Four consecutive tiles share cache lines (16 lines x 2 B = 32 B of a 128-B line), so an XCD
     // (workgroups are dealt to the 8 XCDs round-robin, each with its own L2) gets runs of 4 consecutive tiles; the runs
-    // themselves are dealt round-robin, so that every XCD sees every part of the grid (work is not uniform in space:
-    // a tile far from every object is trivial)
+    // themselves are dealt round-robin, so that every XCD sees every part of the grid (work is not uniform in space)
     int64_t tile = blockIdx.x;
     const bool probe = a.probe_stride > 0;
-    if (probe) {                                                // a sample spread over the whole grid
+    if (probe) {
         tile = (int64_t)blockIdx.x * a.probe_stride + (blockIdx.x * 7u) % (uint32_t)a.probe_stride;
     } else if ((gridDim.x & 31u) == 0u) {
         const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
@@ -145,39 +179,16 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
     }
     const int64_t o = tile / a.tiles_per_outer;
     const int64_t c0 = (tile - o * a.tiles_per_outer) * NL;
+    const int nvalid = (int)min((int64_t)NL, a.group_lines - c0);     // lines of this tile that exist
     const int64_t base = o * a.outer_stride + c0;               // element index of (line 0, position 0)
     const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
     const int16_t* const in16 = a.in16 + base;
     const int32_t* const side_in = STAGE == 3 ? a.side_in + base : nullptr;
     const int32_t* const in32 = (STAGE == 3 && a.in_i32 && i32) ? a.in_i32 + base : nullptr;
-
-    // one candidate range for one position: lanes u = 0 .. G-1 of a group take the pairs lo + 2u, lo + 2u + 2G, ...
-    // (the second key of the last pair may be candidate hi + 1: it can tie but never beat the range's minimum, and on a
-    // tie the smaller position wins the unsigned min, so the argmin stays inside [lo, hi])
-    auto scan = [&](const uint32_t* kl, uint32_t p, int lo, int hi, int u, int G) -> uint32_t {
-        const uint32_t c = (2u * p) << B;                       // < 2^22: 24-bit multiplies are exact mod 2^32
-        int q = lo + 2 * u;
-        uint32_t R = (__umul24(p, p) << B) - __umul24(c, (uint32_t)q);
-        const uint32_t dR = __umul24(c, (uint32_t)(2 * G));
-        uint32_t best = 0xFFFFFFFFu;
-        const int step = 2 * G;
-        for (; q + step <= hi; q += 2 * step) {                 // two pairs per trip: half the loop overhead
-            const uint32_t k0 = kl[q], k1 = kl[q + 1], k2 = kl[q + step], k3 = kl[q + step + 1];
-            const uint32_t R2 = R - dR;
-            best = min(best, min(k0 + R, k1 + R - c));
-            best = min(best, min(k2 + R2, k3 + R2 - c));
-            R = R2 - dR;
-        }
-        if (q <= hi) {
-            const uint32_t k0 = kl[q], k1 = kl[q + 1];
-            best = min(best, min(k0 + R, k1 + R - c));
-        }
-        return best;
-    };
+    const bool out32 = STAGE == 2 && a.out_i32 && i32;
 
     int mxF = 0, mxQ = 0;
-    // virtual-border distance of a line to the padded layer over y and z (STAGE 3: line = (y, z))
-    auto byz_of = [&](int line) -> int {
+    auto byz_of = [&](int line) -> int {        // virtual-border distance of a line to the padded layer over y and z
         int64_t b = kInf32;
         if constexpr (STAGE == 3) {
             if (a.vb) {
@@ -190,7 +201,9 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
         return (int)b;
     };
-    const int byz = byz_of(t & (NL - 1));             // the lane's own line in the chunk phase
+    const int lineT = t & (NL - 1), slotT = t >> 4;             // (line, slot) mapping of levels B and C
+    const bool lineT_ok = lineT < nvalid;
+    const int byz = byz_of(lineT);
 
     // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
     auto raw_signed = [&](int line, int q) -> int {
@@ -206,325 +219,415 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
             return v;
         }
     };
-    // finish one voxel: STAGE 2 plane field (+ side table on request), STAGE 3 the reference's merge arithmetic
-    int probe_far = 0, probe_tot = 0, probe_mid = 0;
-    auto emit = [&](int line, int p, int D, bool filled, bool side, int b_yz) {
-        if (probe) { probe_tot += 1; probe_far += D >= a.probe_thr ? 1 : 0; probe_mid += D >= a.probe_thr2 ? 1 : 0; return; }
-        const uint32_t oi = (uint32_t)line + (uint32_t)p * ls;
+    // finish one FILLED voxel of pass 0's local search (rare path; the chunk phase has its own, vectorised finish)
+    auto emit_filled = [&](uint32_t oi, int p, int D, int b_yz) {
         if constexpr (STAGE == 2) {
-            if (a.out_i32 && i32) { (a.out_i32 + base)[oi] = filled ? -D : D; return; }
-            (reinterpret_cast<int16_t*>(a.out) + base)[oi] = (int16_t)(filled ? -min(D, kSat16) : min(D, kSat16));
-            if (side) (a.side_out + base)[oi] = filled ? -D : D;
+            if (out32) { (a.out_i32 + base)[oi] = -D; return; }
+            (reinterpret_cast<int16_t*>(a.out) + base)[oi] = (int16_t)(-imin(D, kSat16));
+            (a.side_out + base)[oi] = -D;
         } else {
             if (a.vb) {
                 int b = b_yz;
-                if (a.nx > 1) b = min(b, (int)min((int64_t)p + 1, a.nx - p));
-                if (b < 32768) D = min(D, b * b);
+                if (a.nx > 1) b = imin(b, (int)min((int64_t)p + 1, a.nx - p));
+                if (b < 32768) D = imin(D, (int)__umul24((uint32_t)b, (uint32_t)b));
             }
-            if (filled) mxQ = max(mxQ, D); else mxF = max(mxF, D);
+            mxQ = imax(mxQ, D);
             const float f = (D >= kInf32) ? __builtin_inff() : (float)(sqrt_exact_pos((double)D) * a.resolution);
-            (reinterpret_cast<float*>(a.out) + base)[oi] = filled ? -f : f;
+            (reinterpret_cast<float*>(a.out) + base)[oi] = -f;
+        }
+    };
+    int probe_far = 0, probe_tot = 0, probe_mid = 0;
+
+    // THE inner loop: 8 positions (multipliers nc[k] = -((2 p'_k) << B)) against the candidates qs, qs + step, ... <= qe
+    // taken in aligned pairs (qs even).  Candidates outside the caller's range that ride along in a pair are harmless:
+    // any candidate's value is an upper bound of the optimum, and whatever wins is a true argmin of the position.
+    auto scan8 = [&](const uint32_t* kl, int qs, int qe, int step, const int (&nc)[8], uint32_t (&best)[8]) {
+        int qc = qs - h;
+        const uint32_t* kp = kl + qs;
+        for (int q = qs; q <= qe; q += step) {
+            const uint2 kk = *reinterpret_cast<const uint2*>(kp);
+            const int qc1 = qc + 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) best[k] = umin(best[k], umin(mad_i24(qc, nc[k], kk.x), mad_i24(qc1, nc[k], kk.y)));
+            kp += step;
+            qc += step;
         }
     };
 
-#pragma unroll 1
-    for (int cls = 0; cls < 2; ++cls) {         // 0: sites of "distance to filled" (for free voxels); 1: the reverse
-        if (cls == 0 && t == 0) { flg[16] = 0u; flg[17] = 0u; flg[18] = 0u; flg[19] = 0u; flg[20] = 0u; }   // (ordered before their users by the barriers of pass 0)
-        // ---- stage the tile: rows -> keys, one pass ----------------------------------------------------------------------
-        // A lane reads 4 lines x 1 position (8 B; STAGE 3 adds the 16-B side-table group where the 16-bit value is
-        // saturated, or reads 16 B of an int32 plane field), kDcBatch independent row loads in flight, and writes the four
-        // keys straight to LDS.  Filled voxels are rare in the scenes this kernel serves: their sign bits go to the bit
-        // array with an LDS atomic each.  First / last site of a line: a bit per (line, iteration) in registers, two LDS
-        // atomics per lane at the end.
-        if (cls == 1 && ((a.dbg & 8) || probe)) break;
-        // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose
-        // in-row squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can
-        // only matter while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises flg[17] for the rest.
-        if (cls == 1 && flg[17] == 0u) break;   // (block-uniform)
-        if (cls == 0) for (int i = t; i < NL * SW; i += NT) sgn[i] = 0u;
-        if (t < NL) { span[2 * t] = 0xFFFFFFFFu; span[2 * t + 1] = 0u; }
-        __syncthreads();
-        {
-            const int sub = t & (LSUB - 1), r = t / LSUB;
-            uint32_t seen[4] = {0u, 0u, 0u, 0u};            // bit it: iteration `it` of this lane found a site on line 4 sub + k
-            uint32_t* const kbase = keys + (4 * sub) * pitch + r;
-            for (int pb = 0, itb = 0; pb < L; pb += PS * kDcBatch, itb += kDcBatch) {
-                int sv[kDcBatch][4];
-                if (STAGE == 3 && in32) {
+    // one pass over the tile.  CLS 0: sites of "distance to filled" (results for free voxels); 1: the reverse, on the
+    // negated field.
+    auto run_pass = [&](auto cls_tag) {
+        constexpr int cls = decltype(cls_tag)::value;
+        for (int i = t; i < (M + 2) * NL; i += NT) args[i] = 0xFFFFFFFFu;
+        if (cls == 0 && t < 32) misc[t] = 0u;
+
+        // ---- stage the tile: rows -> keys ------------------------------------------------------------------------------------
+        // A lane reads 4 lines x 1 position per load (VEC: one 8 / 16-byte load), kDcBatch loads in flight, and writes the
+        // four keys.
+        const int sub = t & 3, r = t >> 2;
+        uint32_t* const kb = keys + (4 * sub) * pitch + r;
+        int lsel[4];
 #pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = min(pb + PS * it + r, L - 1);
-                        const int4 e = *reinterpret_cast<const int4*>(in32 + ((uint32_t)p * ls + 4u * sub));
+        for (int k = 0; k < 4; ++k) lsel[k] = imin(4 * sub + k, nvalid - 1);
+        const uint32_t off_r = (uint32_t)r * ls + 4u * sub, off_last = (uint32_t)(L - 1) * ls + 4u * sub;
+        int lo_w = 0x7fffffff, hi_w = -1;                       // span seen by this wave (uniform)
+        uint32_t mt = 0xFFFFFFFFu;                              // smallest site value seen by this lane
+        for (int pb = 0; pb < L; pb += 64 * kDcBatch) {
+            int sv[kDcBatch][4];
+#pragma unroll
+            for (int it = 0; it < kDcBatch; ++it) {
+                // (rows past the end of the line re-read the last row; their keys are not written)
+                const uint32_t off = (pb + 64 * it + r < L) ? off_r + (uint32_t)(pb + 64 * it) * ls : off_last;
+                if constexpr (VEC) {
+                    if (STAGE == 3 && in32) {
+                        const int4 e = *reinterpret_cast<const int4*>(in32 + off);
                         sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
+                    } else {
+                        const uint2 raw = *reinterpret_cast<const uint2*>(in16 + off);
+                        sv[it][0] = (int)raw.x; sv[it][1] = (int)raw.y;         // (unpacked below, once every row is requested)
                     }
                 } else {
-                    uint2 raw[kDcBatch];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t idx = off - 4u * sub + (uint32_t)lsel[k];
+                        int v;
+                        if (STAGE == 3 && in32) v = in32[idx];
+                        else {
+                            v = in16[idx];
+                            if constexpr (STAGE == 3) if (abs(v) >= kSat16) v = side_in[idx];
+                        }
+                        sv[it][k] = v;
+                    }
+                }
+            }
+            if (pb == 0) __syncthreads();                       // args / misc initialised (the loads above are in flight meanwhile)
+            if constexpr (VEC) {
+                if (!(STAGE == 3 && in32)) {
 #pragma unroll
                     for (int it = 0; it < kDcBatch; ++it) {
-                        const int p = min(pb + PS * it + r, L - 1);
-                        raw[it] = *reinterpret_cast<const uint2*>(in16 + ((uint32_t)p * ls + 4u * sub));
-                    }
-#pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
-                        sv[it][0] = (int)(short)(raw[it].x & 0xffffu); sv[it][1] = (int)raw[it].x >> 16;
-                        sv[it][2] = (int)(short)(raw[it].y & 0xffffu); sv[it][3] = (int)raw[it].y >> 16;
-                    }
-                    if constexpr (STAGE == 3) {
-#pragma unroll
-                        for (int it = 0; it < kDcBatch; ++it) {
+                        const uint32_t rx = (uint32_t)sv[it][0], ry = (uint32_t)sv[it][1];
+                        sv[it][0] = (int)(short)(rx & 0xffffu); sv[it][1] = (int)rx >> 16;
+                        sv[it][2] = (int)(short)(ry & 0xffffu); sv[it][3] = (int)ry >> 16;
+                        if constexpr (STAGE == 3) {
                             // a 16-bit lane is saturated iff it holds +-32767 (-32768 is never stored): |v| + 1 has bit 15 set
-                            // per half: v >= 0 -> v, v < 0 -> ~v = |v| - 1; adding 1 (+ 1 more for the negative ones) gives |v| + 1
-                            const uint32_t n0 = (raw[it].x >> 15) & 0x00010001u, n1 = (raw[it].y >> 15) & 0x00010001u;
-                            const uint32_t m0 = (raw[it].x ^ (n0 * 0xFFFFu)) + 0x00010001u + n0;
-                            const uint32_t m1 = (raw[it].y ^ (n1 * 0xFFFFu)) + 0x00010001u + n1;
-                            const bool sat = ((m0 | m1) & 0x80008000u) != 0u;
-                            if (sat) {
-                                const int p = min(pb + PS * it + r, L - 1);
-                                const int4 e = *reinterpret_cast<const int4*>(side_in + ((uint32_t)p * ls + 4u * sub));
+                            const uint32_t n0 = (rx >> 15) & 0x00010001u, n1 = (ry >> 15) & 0x00010001u;
+                            const uint32_t m0 = (rx ^ (n0 * 0xFFFFu)) + 0x00010001u + n0;
+                            const uint32_t m1 = (ry ^ (n1 * 0xFFFFu)) + 0x00010001u + n1;
+                            if (((m0 | m1) & 0x80008000u) != 0u) {
+                                const uint32_t off = (pb + 64 * it + r < L) ? off_r + (uint32_t)(pb + 64 * it) * ls : off_last;
+                                const int4 e = *reinterpret_cast<const int4*>(side_in + off);
                                 sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
                             }
                         }
                     }
                 }
+            }
 #pragma unroll
-                for (int it = 0; it < kDcBatch; ++it) {
-                    const int p = pb + PS * it + r;
-                    if (p < L) {
-                        const uint32_t pp = __umul24((uint32_t)p, (uint32_t)p);
-                        const uint32_t seen_bit = 1u << (itb + it);
-                        if (cls == 0) {
-                            // Pass 0, branch-free: a free voxel is a site with its own value, a filled one a site with 0, "no
-                            // filled voxel in the rows swept so far" becomes finf by the clamp (finf > every real distance, and
-                            // the "none" codes 32767^2 / kInf32 are above it).  The bookkeeping of the (rare) filled voxels is
-                            // kept out of the way behind one test per group of 4.
-                            int neg = 0;
+            for (int it = 0; it < kDcBatch; ++it) {
+                const int p = pb + 64 * it + r;
+                const bool inl = p < L;
+                const int pc = p - h;
+                const uint32_t cpos = (mad_i24(pc, pc, (uint32_t)(h * h)) << B) | (uint32_t)p;
+                uint32_t F[4];
+                int neg = 0;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const int s1 = sv[it][k];
-                                uint32_t F;
-                                if constexpr (STAGE == 2) {
-                                    const uint32_t m = (uint32_t)max(s1, 0);
-                                    F = min(__umul24(m, m), finf);
-                                } else {
-                                    F = (uint32_t)min(max(s1, 0), (int)finf);
-                                }
-                                kbase[k * pitch + (pb + PS * it)] = ((F + pp) << B) | (uint32_t)p;
-                                seen[k] |= F != finf ? seen_bit : 0u;
-                                neg |= s1;
-                            }
-                            if (neg < 0) {
+                for (int k = 0; k < 4; ++k) {
+                    const int s1 = cls == 0 ? sv[it][k] : -sv[it][k];
+                    if constexpr (STAGE == 2) {
+                        const uint32_t m = (uint32_t)imax(s1, 0);
+                        F[k] = umin(__umul24(m, m), finf);
+                    } else {
+                        F[k] = (uint32_t)imin(imax(s1, 0), (int)finf);
+                    }
+                    neg |= s1;
+                }
+                if (inl) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    const int s1 = sv[it][k];
-                                    if (s1 < 0) {
-                                        uint32_t S = (uint32_t)(-s1);        // squared distance to the nearest free voxel so far
-                                        if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
-                                        atomicOr(&sgn[(4 * sub + k) * SW + (p >> 5)], 1u << (p & 31));
-                                        const uint32_t e = atomicAdd(&flg[16], 1u);          // few per tile: list them for the local search
-                                        if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | min(S, 255u);
-                                    }
-                                }
-                            }
-                            continue;
-                        }
+                    for (int k = 0; k < 4; ++k) kb[k * pitch + (pb + 64 * it)] = (F[k] << B) + cpos;
+                }
+                const uint32_t fmin4 = inl ? umin(umin(F[0], F[1]), umin(F[2], F[3])) : finf;
+                mt = umin(mt, fmin4);
+                const uint64_t bal = __ballot(fmin4 < finf);
+                if (bal) {                                      // (wave-uniform: scalar code)
+                    const int pw = pb + 64 * it + ((t >> 6) << 4);
+                    lo_w = imin(lo_w, pw + ((__ffsll((unsigned long long)bal) - 1) >> 2));
+                    hi_w = imax(hi_w, pw + ((63 - __clzll((long long)bal)) >> 2));
+                }
+                if (cls == 0 && neg < 0 && inl) {               // filled voxels (rare in the scenes this kernel serves): list them
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {           // pass 1: sites of "distance to free"
-                            int s1 = sv[it][k];
-                            if constexpr (STAGE == 2) {
-                                const int gz = abs(s1);
-                                const int sq = gz >= kInf16 ? kInf32 : (int)__umul24((uint32_t)gz, (uint32_t)gz);
-                                s1 = s1 < 0 ? -sq : sq;
-                            }
-                            uint32_t F;
-                            bool none;
-                            if (s1 < 0) {
-                                F = (uint32_t)(-s1);
-                                none = -s1 >= kInf32;
-                            } else {            // free voxel: a zero-valued site only next to a filled voxel of its line
-                                F = 0u;
-                                const uint32_t* sg = sgn + (4 * sub + k) * SW;
-                                bool nb = false;
-                                if (p > 0) nb |= (sg[(p - 1) >> 5] >> ((p - 1) & 31)) & 1u;
-                                if (p + 1 < L) nb |= (sg[(p + 1) >> 5] >> ((p + 1) & 31)) & 1u;
-                                none = !nb;
-                            }
-                            kbase[k * pitch + (pb + PS * it)] = (((none ? finf : F) + pp) << B) | (uint32_t)p;
-                            if (!none) seen[k] |= seen_bit;
+                    for (int k = 0; k < 4; ++k) {
+                        const int s1 = sv[it][k];
+                        if (s1 < 0 && 4 * sub + k < nvalid) {
+                            uint32_t S = (uint32_t)(-s1);       // squared distance to the nearest free voxel so far
+                            if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
+                            const uint32_t e = atomicAdd(&misc[16], 1u);
+                            if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | umin(S, 255u);
                         }
                     }
                 }
             }
+        }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (seen[k]) {                  // iteration it of this lane is position r + 64 it
-                    atomicMin(&span[2 * (4 * sub + k)], (uint32_t)(r + PS * (__ffs((int)seen[k]) - 1)));
-                    atomicMax(&span[2 * (4 * sub + k) + 1], (uint32_t)(r + PS * (31 - __clz((int)seen[k]))));
-                }
-            }
-            if (t < NL) keys[t * pitch + L] = ((finf + (uint32_t)L * (uint32_t)L) << B) | ((uint32_t)L & mask);   // sentinel
+        for (int off = 32; off >= 1; off >>= 1) mt = umin(mt, (uint32_t)__shfl_xor((int)mt, off));
+        if ((t & 63) == 0) { misc[t >> 6] = (uint32_t)lo_w; misc[4 + (t >> 6)] = (uint32_t)hi_w; misc[8 + (t >> 6)] = mt; }
+        if (t < 2 * NL) {                                       // two sentinels behind every line (pairs are read 8-byte aligned)
+            const int line = t >> 1, q = L + (t & 1), qc = q - h;
+            keys[line * pitch + q] = ((finf + (uint32_t)(qc * qc) + (uint32_t)(h * h)) << B) | ((uint32_t)q & mask);
         }
         __syncthreads();
+        DC_STAMP(0);
+        const int lo_t = imin(imin((int)misc[0], (int)misc[1]), imin((int)misc[2], (int)misc[3]));
+        const int hi_t = imax(imax((int)misc[4], (int)misc[5]), imax((int)misc[6], (int)misc[7]));
+        const uint32_t mt_t = umin(umin(misc[8], misc[9]), umin(misc[10], misc[11]));
+#ifdef SDFGPU_DEBUG_HOOKS
+        const bool act = lo_t <= hi_t && !(a.dbg & 1);          // profiling builds: dbg bit 0 = no search (wrong results), bit 1 = no fp64 finish, bit 2 = no stores
+#else
+        const bool act = lo_t <= hi_t;                          // the tile holds a site (block-uniform)
+#endif
 
-        // ---- upper levels: coarse positions p = 8 (i' - 1), i' = 1 .. M ---------------------------------------------------
-        // Levels with few positions split each position's candidate range over several lanes of the line's 16-lane row
-        // (min-reduced with shuffles); levels with many positions switch to lane = (line, slot): the 16 lanes of a row then
-        // work on the SAME position of 16 neighbouring lines, whose ranges are alike (the scene is coherent across
-        // lines), so the per-lane loops of a row have nearly the same trip count.
-        const int lineT = t & (NL - 1), slotT = t / NL;
-        const uint32_t qmnT = span[2 * lineT], qmxT = span[2 * lineT + 1];
-        const bool actT = qmnT <= qmxT;
-        {
-            const int lineU = t >> 4, g = t & 15;
-            const uint32_t* klU = keys + lineU * pitch;
-            uint16_t* aU = args + lineU * AP;
-            const uint32_t qmn = span[2 * lineU], qmx = span[2 * lineU + 1];
-            const bool actU = qmn <= qmx;
-            const uint32_t* klT = keys + lineT * pitch;
-            uint16_t* aT = args + lineT * AP;
-            for (int l = 0; l < ((a.dbg & 1) ? 0 : Kp); ++l) {
-                const int h = 1 << (Kp - 1 - l);
-                const int n = (M / h + 1) >> 1;                 // positions of this level: i' = h (2 j + 1) <= M
-                if (n <= 8) {
-                    int sh = 4;                                 // log2 of the lanes per position
-                    while ((16 >> sh) < n) --sh;
-                    const int G = 1 << sh;
-                    const int j = g >> sh, u = g & (G - 1);
-                    const int ip = h * (2 * j + 1);
-                    const bool valid = actU && ip <= M;
-                    int lo = 1, hi = 0;
-                    if (valid) {
-                        lo = (ip - h == 0) ? (int)qmn : (int)aU[ip - h];
-                        hi = (ip + h > M) ? (int)qmx : (int)aU[ip + h];
-                        // The first levels scan (nearly) the whole site span per position.  Any candidate's cost is an upper
-                        // bound v of the optimum, and a candidate farther than sqrt(v) from p costs more than v: clip the
-                        // range to p +- (sqrt(v) + 1).  On lines that pass near objects (every line of a uniformly sparse
-                        // scene, every position outside the span) this shrinks the scan from the span to a few candidates.
-                        const int pp = 8 * (ip - 1);
-                        const int pc = min(max(pp, lo), hi);
-                        const uint32_t cc = (2u * (uint32_t)pp) << B, p2b = __umul24((uint32_t)pp, (uint32_t)pp) << B;
-                        const uint32_t v = min(klU[pc] + p2b - __umul24(cc, (uint32_t)pc),
-                                               min(klU[lo] + p2b - __umul24(cc, (uint32_t)lo), klU[hi] + p2b - __umul24(cc, (uint32_t)hi))) >> B;
-                        if (v < finf) {
-                            const int w = (int)__builtin_sqrtf((float)v) + 2;
-                            lo = max(lo, pp - w);
-                            hi = min(hi, pp + w);
+        if (act) {
+            // ---- level A: positions 64 i ---------------------------------------------------------------------------------------
+            // Two forms, chosen per line (= per 16-lane row): (a) one position per lane group over a range clipped by the
+            // distance bound -- a few candidates per position wherever the line runs near sites or far from ALL of them;
+            // (b) when the clipped ranges stay long (objects at different distances: the bound v - m is then large), the 16
+            // lanes split the span and every lane takes its share of the candidates for 8 positions at once.
+            {
+                const int lineA = t >> 4, u = t & 15;
+                const uint32_t* klA = keys + lineA * pitch;
+                const int span_pairs = (hi_t - (lo_t & ~1)) / 2 + 1;
+                int G = 1;                                      // form (a): lanes per position
+                while (2 * G * MA <= 16) G *= 2;
+                const int v = u & (G - 1), i1 = u / G;
+                int lo = lo_t, hi = hi_t, nc1 = 0;
+                bool clip = false;
+                if (MA <= 16) {
+                    int prs = 0;
+                    if (i1 < MA) {
+                        const int p = 64 * i1;
+                        nc1 = ncof(p);
+                        // any candidate bounds the optimum: try the candidate next to p and the two ends of the span
+                        const int pcl = imin(imax(p, lo_t), hi_t);
+                        const uint32_t ub = umin(mad_i24(pcl - h, nc1, klA[pcl]), umin(mad_i24(lo_t - h, nc1, klA[lo_t]), mad_i24(hi_t - h, nc1, klA[hi_t])));
+                        const uint32_t dub = (ub >> B) - __umul24((uint32_t)p, (uint32_t)(2 * h - p));
+                        if (dub < finf) {
+                            const int w = (int)__builtin_sqrtf((float)(dub - umin(mt_t, dub))) + 2;
+                            lo = imax(lo, p - w);
+                            hi = imin(hi, p + w);
                         }
+                        prs = (hi - (lo & ~1)) / 2 + 1;
                     }
-                    uint32_t best = scan(klU, 8u * (uint32_t)(ip - 1), lo, hi, u, G);
-                    for (int off = 1; off < G; off <<= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off));
-                    if (valid && u == 0) aU[ip] = (uint16_t)(best & mask);
-                } else {
-                    for (int j = slotT; j < n; j += NS) {
-                        const int ip = h * (2 * j + 1);
-                        if (actT) {
-                            const int lo = (ip - h == 0) ? (int)qmnT : (int)aT[ip - h];
-                            const int hi = (ip + h > M) ? (int)qmxT : (int)aT[ip + h];
-                            const uint32_t best = scan(klT, 8u * (uint32_t)(ip - 1), lo, hi, 0, 1);
-                            aT[ip] = (uint16_t)(best & mask);
+                    int rmax = prs;                             // longest clipped range of the line (row maximum)
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x128, 0xF, 0xF, true));      // row_ror:8
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x124, 0xF, 0xF, true));      // row_ror:4
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x122, 0xF, 0xF, true));      // row_ror:2
+                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x121, 0xF, 0xF, true));      // row_ror:1
+                    // cost per lane: (a) ceil(rmax / G) trips of ~8 instructions, (b) ceil(span_pairs / 16) trips of ~29 per 8 positions
+                    clip = ((rmax + G - 1) / G) * 8 <= ((span_pairs + 15) / 16) * 29 * ((MA + 7) / 8);
+                }
+                if (clip) {
+                    if (i1 < MA) {
+                        uint32_t best = 0xFFFFFFFFu;
+                        int q = (lo & ~1) + 2 * v, qc = q - h;
+                        const uint32_t* kp = klA + q;
+                        for (; q <= hi; q += 2 * G) {
+                            const uint2 kk = *reinterpret_cast<const uint2*>(kp);
+                            best = umin(best, umin(mad_i24(qc, nc1, kk.x), mad_i24(qc + 1, nc1, kk.y)));
+                            kp += 2 * G;
+                            qc += 2 * G;
                         }
+                        atomicMin(&args[(8 * i1) * NL + lineA], best);
+                    }
+                } else {
+                    for (int g = 0; g < MA; g += 8) {
+                        int nc[8];
+                        uint32_t best[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            nc[k] = ncof(64 * imin(g + k, MA - 1));
+                            best[k] = 0xFFFFFFFFu;
+                        }
+                        scan8(klA, (lo_t & ~1) + 2 * u, hi_t, 32, nc, best);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (g + k < MA) atomicMin(&args[(8 * (g + k)) * NL + lineA], best[k]);
                     }
                 }
-                __syncthreads();
             }
-        }
-
-        // ---- chunk phase: lane = (line, chunk of 8 positions); finish and store -------------------------------------------
-        {
-            const int line = lineT, slot = slotT;
-            const uint32_t* kl = keys + line * pitch;
-            const uint16_t* al = args + line * AP;
-            const uint32_t qmx = qmxT;
-            const bool act = actT;
-            for (int i0 = 0; i0 < M; i0 += NS) {
-                const int i = i0 + slot;
-                const bool live = i < M;
-                const int p0 = kDcChunk * i;
-                int D[kDcChunk];
+            __syncthreads();
+            DC_STAMP(1);
+            // ---- level B: positions 64 i + 8 k inside interval i; lane = (line, interval[, share of the candidates]) ------------
+            {
+                int Hs = 1;                                     // lanes per interval (16 slots per line)
+                while (2 * Hs * MA <= 16) Hs *= 2;
+                const uint32_t* kl = keys + lineT * pitch;
+                for (int i = slotT / Hs; i < MA; i += 16 / Hs) {
+                    const int u = slotT % Hs;
+                    const int lo = (int)(args[(8 * i) * NL + lineT] & mask);
+                    const int hi = (i + 1 < MA) ? (int)(args[(8 * (i + 1)) * NL + lineT] & mask) : hi_t;
+                    int nc[8];
+                    uint32_t best[8];
 #pragma unroll
-                for (int k = 0; k < kDcChunk; ++k) D[k] = kInf32;
-                const int a0 = (live && act && !(a.dbg & 2)) ? (int)al[i + 1] : 0;
-                const int a8 = (live && act && !(a.dbg & 2)) ? ((i + 2 <= M) ? (int)al[i + 2] : (int)qmx) : -1;
-                if (live && act) {
-                    // all 8 positions against every candidate of [a0, a8] (usually a few: the argmin moves ~ half a site per
-                    // position), branch-free, two candidates per step; 2 VALU per evaluation, no per-position set-up.  Long ranges
-                    // take the same loop: a per-lane divide-and-conquer over the chunk's positions (3 R instead of 8 R evaluations
-                    // for a range of R) was kept for ranges >= 24 at first -- it ran the whole wave through both code paths and lost
-                    // everywhere (KE3 0.82 -> 0.75 ms on the streaming scene, KE2 0.80 -> 0.63 ms at Bernoulli p = 0.003).
-                    // With p_k = p0 + k: R_k(q) = (p_k^2 << B) - ((2 p_k) << B) q, R_k(a0) - R_{k-1}(a0) = ((2 (p0 - a0) + 2k - 1) << B).
-                    uint32_t R[kDcChunk], nc[kDcChunk], best[kDcChunk];
-                    const uint32_t W = (uint32_t)(2 * (p0 - a0)) << B;
-                    R[0] = (__umul24((uint32_t)p0, (uint32_t)p0) << B) - __umul24(((uint32_t)(2 * p0)) << B, (uint32_t)a0);
-                    nc[0] = 0u - ((uint32_t)(2 * p0) << B);
-                    best[0] = 0xFFFFFFFFu;
-#pragma unroll
-                    for (int k = 1; k < kDcChunk; ++k) {
-                        R[k] = R[k - 1] + W + ((uint32_t)(2 * k - 1) << B);
-                        nc[k] = nc[k - 1] - (2u << B);
+                    for (int k = 0; k < 8; ++k) {
+                        nc[k] = ncof(64 * i + 8 * k);
                         best[k] = 0xFFFFFFFFu;
                     }
-                    for (int q = a0; q <= a8; q += 2) {
-                        const uint32_t k0 = kl[q], k1 = kl[q + 1];
+                    scan8(kl, (lo & ~1) + 2 * u, hi, 2 * Hs, nc, best);
 #pragma unroll
-                        for (int k = 0; k < kDcChunk; ++k) {
-                            best[k] = min(best[k], min(k0 + R[k], k1 + R[k] + nc[k]));
-                            R[k] += 2u * nc[k];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < kDcChunk; ++k) {
-                        const uint32_t d = best[k] >> B;
-                        D[k] = d >= finf ? kInf32 : (int)d;
-                    }
-                }
-                uint32_t cm = 0u;                               // bit k: voxel p0 + k of this line is filled
-                if (live) cm = (sgn[line * SW + (p0 >> 5)] >> (p0 & 31)) & 0xFFu;
-#pragma unroll
-                for (int k = 0; k < kDcChunk; ++k) {
-                    const int p = p0 + k;
-                    const bool inl = live && p < L;
-                    const bool filled = (cm >> k) & 1u;
-                    const bool mine = inl && (filled == (cls == 1)) && !(a.dbg & 4);
-                    if constexpr (STAGE == 2) {
-                        // side-table convention (sdfgpu_sweep_x16.hpp): if ANY voxel of a group of 4 is saturated, the
-                        // exact values of the whole group must be in the side table.  A pass only knows its own class, so a
-                        // voxel also writes its exact value when its group holds a voxel of the other class (filled voxels
-                        // always write theirs).
-                        const int need = mine ? (D[k] >= kSat16 ? 1 : 0) : (inl ? 1 : 0);
-                        // OR over the 4 lanes of the group (= 4 neighbouring lines): two DPP quad permutes, no LDS traffic
-                        int any = need | __builtin_amdgcn_mov_dpp(need, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
-                        any |= __builtin_amdgcn_mov_dpp(any, 0x4E, 0xF, 0xF, true);                  // quad_perm [2,3,0,1]
-                        if (mine) emit(line, p, D[k], filled, cls == 1 || any, byz);
-                    } else {
-                        if (mine) emit(line, p, D[k], filled, false, byz);
-                    }
+                    for (int k = 1; k < 8; ++k)
+                        if (8 * i + k < M) atomicMin(&args[(8 * i + k) * NL + lineT], best[k]);
                 }
             }
+            __syncthreads();
+            DC_STAMP(2);
+        }
+
+        // ---- level C: lane = (line, chunk of 8 positions); finish and store ---------------------------------------------------
+        {
+            const uint32_t* kl = keys + lineT * pitch;
+            for (int i0 = 0; i0 < M; i0 += 16) {
+                const int i = i0 + slotT;
+                if (i >= M || !lineT_ok) continue;
+                const int p0 = 8 * i;
+                int D[8];
+                if (act) {
+                    const int a0 = (int)(args[i * NL + lineT] & mask);
+                    const int a8 = (i + 1 < M) ? (int)(args[(i + 1) * NL + lineT] & mask) : hi_t;
+                    int nc[8];
+                    uint32_t best[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        nc[k] = ncof(p0 + k);
+                        best[k] = 0xFFFFFFFFu;
+                    }
+                    DC_STAMP(4);
+                    scan8(kl, a0 & ~1, a8, 2, nc, best);
+                    DC_STAMP(3);
+                    // D = (best >> B) - (h^2 - p'^2), h^2 - p'^2 = p (2 h - p): a running value, + (2 h - 2 p - 1) per position
+                    uint32_t hp = __umul24((uint32_t)p0, (uint32_t)(2 * h - p0));
+                    const uint32_t c1 = (uint32_t)(2 * h - 2 * p0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t d = (best[k] >> B) - hp;
+                        D[k] = d >= finf ? kInf32 : (int)d;
+                        hp += c1 - (uint32_t)(2 * k + 1);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) D[k] = kInf32;
+                }
+                // positions past the end of the line count as "not mine" (D = 0).  Pass 0: a voxel is filled iff its distance
+                // to the nearest filled voxel is 0; pass 1: free iff its distance to the nearest free voxel is 0 -- so in
+                // both passes the voxels this pass must write are exactly those with D != 0.
+                if (p0 + 8 > L) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (p0 + k >= L) D[k] = 0;
+                }
+                const uint32_t ob = (uint32_t)lineT + (uint32_t)p0 * ls;      // element offset of the chunk's first voxel
+                if (probe) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        probe_tot += D[k] != 0 ? 1 : 0;
+                        probe_far += D[k] >= a.probe_thr ? 1 : 0;
+                        probe_mid += D[k] >= a.probe_thr2 ? 1 : 0;
+                    }
+                    continue;
+                }
+                if constexpr (STAGE == 2) {
+                    if (out32) {
+                        char* const op = reinterpret_cast<char*>(a.out_i32 + base);      // (uniform base + 32-bit byte offset)
+                        uint32_t bo = ob * 4u;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            if (D[k] != 0) *reinterpret_cast<int32_t*>(op + bo) = cls == 1 ? -D[k] : D[k];
+                            bo += 4u * ls;
+                        }
+                    } else {
+                        // side-table convention (sdfgpu_sweep_x16.hpp): if ANY voxel of a group of 4 is saturated, the exact
+                        // values of the whole group must be in the side table.  A pass only knows its own class, so a voxel
+                        // also writes its exact value when its group holds a voxel of the other class.
+                        int16_t* const op = reinterpret_cast<int16_t*>(a.out) + base;
+                        int32_t* const sp = a.side_out + base;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const bool inl = p0 + k < L, mine = D[k] != 0;
+                            const int need = mine ? (D[k] >= kSat16 ? 1 : 0) : (inl ? 1 : 0);
+                            int any = need | __builtin_amdgcn_mov_dpp(need, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                            any |= __builtin_amdgcn_mov_dpp(any, 0x4E, 0xF, 0xF, true);                  // quad_perm [2,3,0,1]
+                            if (mine) {
+                                const uint32_t oi = ob + (uint32_t)k * ls;
+                                const int Ds = imin(D[k], kSat16);
+                                op[oi] = (int16_t)(cls == 1 ? -Ds : Ds);
+                                if (cls == 1 || any) sp[oi] = cls == 1 ? -D[k] : D[k];
+                            }
+                        }
+                    }
+                } else {
+                    if (a.vb) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            int b = byz;
+                            if (a.nx > 1) b = imin(b, (int)min((int64_t)(p0 + k) + 1, a.nx - (p0 + k)));
+                            if (b < 32768) D[k] = imin(D[k], (int)__umul24((uint32_t)b, (uint32_t)b));      // (b >= 1: a voxel of the other class stays 0)
+                        }
+                    }
+                    char* const op = reinterpret_cast<char*>(reinterpret_cast<float*>(a.out) + base);     // (uniform base + 32-bit byte offset)
+                    uint32_t bo = ob * 4u;
+                    int mx = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        mx = imax(mx, D[k]);
+                        float f = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);                 // (D = 0: not stored)
+#ifdef SDFGPU_DEBUG_HOOKS
+                        if (a.dbg & 2) f = (float)D[k];
+                        if ((a.dbg & 4) && (k || slotT)) { bo += 4u * ls; continue; }
+#endif
+                        f = D[k] >= kInf32 ? __builtin_inff() : f;
+                        if (D[k] != 0) *reinterpret_cast<float*>(op + bo) = cls == 1 ? -f : f;
+                        bo += 4u * ls;
+                    }
+                    if (cls == 1) mxQ = imax(mxQ, mx); else mxF = imax(mxF, mx);
+                }
+            }
+            DC_STAMP(4);
             // Pass 0 finishes the tile's filled voxels itself when they are few and shallow (thin surfaces): one lane per
-            // listed voxel, exact local search along its line -- a candidate at offset d can only win while d^2 < the best so
-            // far, and S = 1 (a free voxel next door in the rows already swept) needs no search at all.  Deep or numerous
-            // filled voxels raise flg[17] and the second pass does the class properly.
-            if (cls == 0 && !(a.dbg & 8) && !probe) {
-                const uint32_t nf = flg[16];
+            // listed voxel, exact local search along its line.  Deep or numerous filled voxels raise misc[17] and the second
+            // pass does the class properly.
+            if (cls == 0 && !probe) {
+                const uint32_t nf = misc[16];
                 if (nf > (uint32_t)kDcLocalFilled) {
-                    if (t == 0) flg[17] = 1u;
+                    if (t == 0) misc[17] = 1u;
                 } else {
                     for (uint32_t e = (uint32_t)t; e < nf; e += (uint32_t)NT) {
                         const uint32_t ent = flist[e];
                         const int fl = (int)(ent >> 24), p = (int)((ent >> 8) & 0xffffu);
                         int D1 = (int)(ent & 0xffu);
-                        if (D1 > kDcLocalMax) { flg[17] = 1u; continue; }
+                        if (D1 > kDcLocalMax) { misc[17] = 1u; continue; }
                         for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
-                            if (p - d >= 0) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(fl, p - d), 0));
-                            if (p + d < L) D1 = min(D1, (int)__umul24(d, d) + max(-raw_signed(fl, p + d), 0));
+                            if (p - d >= 0) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p - d), 0));
+                            if (p + d < L) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p + d), 0));
                         }
-                        emit(fl, p, D1, true, true, byz_of(fl));
+                        emit_filled((uint32_t)fl + (uint32_t)p * ls, p, D1, byz_of(fl));
                     }
                 }
             }
         }
-        __syncthreads();                        // keys / args are rebuilt by the next class
-    }
+        DC_STAMP(5);
+        __syncthreads();                        // keys / args are rebuilt by the next class; misc[17] is complete
+        DC_STAMP(6);
+    };
 
+    run_pass(std::integral_constant<int, 0>{});
+    // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose in-row
+    // squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can only matter
+    // while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises misc[17] for the rest.
+    if (!probe && misc[17] != 0u) run_pass(std::integral_constant<int, 1>{});      // (block-uniform)
+
+#ifdef SDFGPU_PHASE_CLOCKS
+    if (a.clocks && (t & 63) == 0 && !probe && (blockIdx.x & 31u) == 5u) {     // a sample: same-address atomics serialise
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(a.clocks + (STAGE - 2) * 8 + k, clk[k]);
+    }
+#endif
     if (probe) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -532,17 +635,16 @@ __global__ __launch_bounds__(16 * NL, 4) void k_envelope_dc(const EnvDcArgs a) {
             probe_tot += __shfl_xor(probe_tot, off);
             probe_mid += __shfl_xor(probe_mid, off);
         }
-        // one pair of global atomics per workgroup (same-address atomics serialise at ~12 ns each)
-        if ((t & 63) == 0) { atomicAdd(&flg[18], (uint32_t)probe_far); atomicAdd(&flg[19], (uint32_t)probe_tot); atomicAdd(&flg[20], (uint32_t)probe_mid); }
+        if ((t & 63) == 0) { atomicAdd(&misc[18], (uint32_t)probe_far); atomicAdd(&misc[19], (uint32_t)probe_tot); atomicAdd(&misc[20], (uint32_t)probe_mid); }
         __syncthreads();
-        if (t == 0) { atomicAdd(a.probe_out, flg[18]); atomicAdd(a.probe_out + 1, flg[19]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, flg[20]); }
+        if (t == 0) { atomicAdd(a.probe_out, misc[18]); atomicAdd(a.probe_out + 1, misc[19]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, misc[20]); }
         return;
     }
     if constexpr (STAGE == 3) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            mxF = max(mxF, __shfl_xor(mxF, off));
-            mxQ = max(mxQ, __shfl_xor(mxQ, off));
+            mxF = imax(mxF, __shfl_xor(mxF, off));
+            mxQ = imax(mxQ, __shfl_xor(mxQ, off));
         }
         if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * (NT / 64) + (t >> 6), mxF, mxQ);
     }

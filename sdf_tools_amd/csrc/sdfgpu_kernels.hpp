@@ -481,6 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
         }
         // outward scan beyond the register window (exactness for sparse scenes)
         bool need = false;
+        int inexact = 0;                        // bit k: voxel k was still undecided when the bounded scan stopped
 #pragma unroll
         for (int k = 0; k < V; ++k) need |= best[k] >= (H + 1) * (H + 1);
         if (__any(need)) {
@@ -492,7 +493,12 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) act |= dd < best[k];
                 if (!__any(act)) break;
-                if (a.max_scan && d > a.max_scan) { far |= act; break; }     // leave it to the envelope kernel
+                if (a.max_scan && d > a.max_scan) {                          // leave it to the envelope kernel
+                    far |= act;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) inexact |= (dd < best[k]) ? (1 << k) : 0;
+                    break;
+                }
                 if (act) {
                     int s[V];
                     if (lo >= 0) {
@@ -567,7 +573,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
                     if (a.nz > 1) b = min(b, min((int64_t)vz[k] + 1, a.nz - vz[k]));
                     if (b < 32768) D = min(D, (int)(b * b));
                 }
-                if (m[k]) mxQ = max(mxQ, D); else mxF = max(mxF, D);
+                // (a voxel the bounded scan left undecided holds an upper bound only: the far-field kernel behind this sweep
+                //  rewrites it and reports its true value; it must not reach the extrema from here)
+                if (!((inexact >> k) & 1)) { if (m[k]) mxQ = max(mxQ, D); else mxF = max(mxF, D); }
                 // sdf_generation.hpp:254-265: sqrt and multiply in double, one narrowing cast
                 const float f = (D >= kInf32) ? __builtin_inff()
                                               : (float)(sqrt((double)D) * a.resolution);

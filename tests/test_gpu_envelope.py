@@ -29,6 +29,14 @@ CASES = [
     ("thin wall far away", np.pad(np.ones((1, 50, 32), np.uint8), ((60, 0), (0, 0), (0, 0))), True),
     ("2-D 300x400", synth.bernoulli_mask((1, 300, 400), 0.0002, 5), False),
     ("all free", np.zeros((20, 24, 32), np.uint8), False),
+    # shapes the first two generations of the far-field kernel refused (line groups that are not multiples of 16, rows
+    # that are not multiples of 4 elements): partial tiles, scalar loads, the int32 plane field between the two sweeps
+    ("two boxes 40x30x20 (partial tiles)", _two_boxes((40, 30, 20)), False),
+    ("two boxes 70x66x81 vb (odd rows)", _two_boxes((70, 66, 81)), True),
+    ("single voxel 25x20x15 (3d_sdf_demo_rviz.py:107 shape)", scenes.single_voxel((25, 20, 15), (2, 3, 13)), False),
+    ("convex-segments scene 100x100x50, dense tier off", scenes.convex_segments_scene()[0], False),
+    ("two boxes 1x100x50", _two_boxes((1, 100, 50)), True),
+    ("single voxel 3x9x1100 (1100-voxel lines)", scenes.single_voxel((3, 9, 1100), (1, 2, 1000)), False),
 ]
 
 
@@ -43,14 +51,21 @@ def test_far_field_scenes_are_exact(gpu, name, m, vb):
     assert len(bad) == 0, "%s: %d voxels differ, first at %s got %r want %r (path %s)" % (
         name, len(bad), bad[0].tolist(), sdf[tuple(bad[0])], ex[tuple(bad[0])], path)
     assert ext == ex_ext, (name, ext, ex_ext, path)
-    if name.startswith(("two boxes", "single voxel", "thin wall")):
-        assert path["far_y"] or path["far_x"]              # these really exercise the envelope kernels
-        gpu.set_option("envelope_mode", 1)                  # ... also as the only sweep of each axis
+    if name.startswith("convex-segments"):
+        gpu.set_option("dense", 0)                          # (the dense tier certifies this scene; here the general tiers must)
         try:
-            sdf3, ext3 = gpu.build(m, res, vb)
+            sdf0, ext0 = gpu.build(m, res, vb)
         finally:
-            gpu.set_option("envelope_mode", 0)
-        assert np.array_equal(sdf.view(np.uint32), sdf3.view(np.uint32)) and ext == ext3
+            gpu.set_option("dense", 1)
+        assert np.array_equal(sdf0.view(np.uint32), ex.view(np.uint32)) and ext0 == ex_ext
+    if name.startswith(("two boxes 64", "two boxes 96", "two boxes 70", "single voxel 40x48x512", "thin wall")):
+        assert path["far_y"] or path["far_x"]              # distances beyond the marching kernels' scan bound: the far-field kernel ran
+    gpu.set_option("envelope_mode", 1)                      # every scene also with the far-field kernel as the only sweep of each axis
+    try:
+        sdf3, ext3 = gpu.build(m, res, vb)
+    finally:
+        gpu.set_option("envelope_mode", 0)
+    assert np.array_equal(sdf.view(np.uint32), sdf3.view(np.uint32)) and ext == ext3, name
     gpu.set_option("envelope", 0)
     try:
         sdf2, ext2 = gpu.build(m, res, vb)                  # unbounded scans

@@ -27,7 +27,7 @@ for a in sys.argv:
         mask = synth.bernoulli_mask_torch((n, n, n), float(a.split("=")[1]), 1, device=dev)
 names = ["pack_bits", "dense_ball", "sweep_z", "sweep_y", "envelope_y", "sweep_x", "envelope_x"]
 result = {}
-for dc in ([1, 0] if "--both" in sys.argv else [1]):
+for dc in ([1, 0] if "--both" in sys.argv else [1]):      # 0: the far-field kernel off (unbounded marching scans)
     ctx.set_option("policy_reset", 1)
     ctx.set_option("dense", 0)
     ctx.set_option("envelope_dc", dc)
