@@ -393,10 +393,14 @@ def main():
             dominant_only = False
         ctx.set_profiling(0 if args.no_profile else (3 if dominant_only else 1))
     dt = timed_loop(step, args.steps, fence)
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.tensor([dt, float(rank)], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                                # (RCCL: each rank's own clock around the same K steps)
+        per_rank_ms = [float(e[0].item()) / args.steps * 1e3 for e in every]
+        ranks_seen = sorted(int(e[1].item()) for e in every)
+        dt = max(float(e[0].item()) for e in every)
 
     ms_per_step = dt / args.steps * 1e3
     value = n_total / (dt / args.steps) / 1e6
@@ -413,6 +417,10 @@ def main():
                    "x-slab x%d; RCCL halo exchange: 2 bit-planes (dense path) / %d int32 planes (general path)"
                    % (world, args.halo)},
     }
+    if world > 1:
+        result["multi_gpu"] = {"ranks_seen": ranks_seen, "rccl": dist.get_backend() == "nccl",
+                               "ms_per_step_by_rank": [round(v, 4) for v in per_rank_ms],
+                               "general_path_builds": builder.general_builds, "whole_line_sweeps": builder.fallbacks}
     # whole step against the compulsory 5 B/voxel (mask in, fp32 out) and against SURVEY 8(d)'s 17 B/voxel
     result["pipeline"] = {
         "compulsory_bytes_per_voxel": B_COMPULSORY_TOTAL,

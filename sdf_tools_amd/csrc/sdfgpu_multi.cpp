@@ -148,14 +148,21 @@ int compute_after_comm(sdfgpu_multi_handle h) {
 int exchange_msgs(sdfgpu_multi_handle h, const std::vector<Msg>& msgs) {
     if (msgs.empty()) return SDFGPU_OK;
     if (h->use_rccl) {
+        // an error inside the group must still close it (an open group would swallow every later RCCL call of the process)
         M_NCCL(h, ncclGroupStart());
-        for (const Msg& m : msgs) {
-            if (m.bytes == 0) continue;
+        int rc = SDFGPU_OK;
+        auto post = [&](const Msg& m) -> int {
             M_HIP(h, hipSetDevice(h->r[m.src].dev));
             M_NCCL(h, ncclSend(m.sp, m.bytes, ncclChar, m.dst, h->r[m.src].comm, h->r[m.src].cs));
             M_HIP(h, hipSetDevice(h->r[m.dst].dev));
             M_NCCL(h, ncclRecv(m.dp, m.bytes, ncclChar, m.src, h->r[m.dst].comm, h->r[m.dst].cs));
+            return SDFGPU_OK;
+        };
+        for (const Msg& m : msgs) {
+            if (m.bytes == 0) continue;
+            if ((rc = post(m)) != SDFGPU_OK) break;
         }
+        if (rc != SDFGPU_OK) { (void)ncclGroupEnd(); return rc; }
         M_NCCL(h, ncclGroupEnd());
     } else {
         for (const Msg& m : msgs) {
