@@ -2,15 +2,25 @@
 // sdf_tools::CollisionMapGrid (reference include/sdf_tools/collision_map.hpp) on the SDF path:
 // COLLISION_CELL (:20-32), the constructors (:215-270), SetValue (:405-420) and
 // ExtractSignedDistanceField (:680-712).  Connected components, topology and RViz export are out
-// of scope.
+// of scope.  Wire formats (N3): SerializeSelf / DeserializeSelf, SaveToFile /
+// LoadFromFile ("CMGZ" / "CMGR") and the CollisionMap message pair in the field order of
+// src/sdf_tools/collision_map.cpp:21-62, :205-283, :285-315.  The byte layout of the primitives
+// (arc_utilities::SerializeFixedSizePOD / SerializeEigen / SerializeVector / SerializeString) is the in-tree
+// include/arc_utilities/serialization.hpp: arc_utilities is not vendored in the reference checkout, so byte-level
+// interoperability with files written by the reference is UNVERIFIED.
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <fstream>
+#include <iterator>
+#include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
 
+#include "arc_utilities/serialization.hpp"
 #include "arc_utilities/voxel_grid.hpp"
+#include "arc_utilities/zlib_helpers.hpp"
 #include "sdf_tools/sdf.hpp"
 #include "sdf_tools/sdf_generation.hpp"
 
@@ -24,6 +34,13 @@ struct COLLISION_CELL {
     COLLISION_CELL(const float in_occupancy, const uint32_t in_component) : occupancy(in_occupancy), component(in_component) {}
 };
 static_assert(sizeof(COLLISION_CELL) == 8, "COLLISION_CELL must stay an 8-byte record (device classify kernel)");
+
+// Plain mirror of msg/CollisionMap.msg for builds without ROS (field names kept).
+struct CollisionMap {
+    struct Header { uint32_t seq = 0; double stamp = 0.0; std::string frame_id; } header;
+    std::vector<uint8_t> serialized_map;
+    bool is_compressed = false;
+};
 
 class CollisionMapGrid : public VoxelGrid::VoxelGrid<COLLISION_CELL> {
 protected:
@@ -78,6 +95,71 @@ public:
         return sdf_generation::ExtractSignedDistanceFieldFromCells(
             GetOriginTransform(), GetCellSizes(), GetNumXCells(), GetNumYCells(), GetNumZCells(), data_.data(),
             sizeof(COLLISION_CELL), offsetof(COLLISION_CELL, occupancy), unknown_is_filled, oob_value, GetFrame(), add_virtual_border);
+    }
+
+    // ---- wire formats: collision_map.cpp:21-62 (fields), :205-283 (files), :285-315 (messages) ------------------------
+    using CellSerializer = std::function<uint64_t(const COLLISION_CELL&, std::vector<uint8_t>&)>;
+    using CellDeserializer = std::function<std::pair<COLLISION_CELL, uint64_t>(const std::vector<uint8_t>&, const uint64_t)>;
+
+    uint64_t SerializeSelf(std::vector<uint8_t>& buffer,
+                           const CellSerializer& value_serializer = arc_utilities::SerializeFixedSizePOD<COLLISION_CELL>) const override {
+        (void)value_serializer;                                   // (the reference ignores it too: cells are fixed-size PODs)
+        const uint64_t start = buffer.size();
+        BaseSerializeSelf(buffer, arc_utilities::SerializeFixedSizePOD<COLLISION_CELL>);   // initialized .. OOB value (:28-57)
+        arc_utilities::SerializeFixedSizePOD<uint32_t>(number_of_components_, buffer);     // (:59)
+        arc_utilities::SerializeString(frame_, buffer);                                    // (:60)
+        arc_utilities::SerializeFixedSizePOD<uint8_t>((uint8_t)components_valid_, buffer); // (:61)
+        return buffer.size() - start;
+    }
+    uint64_t DeserializeSelf(const std::vector<uint8_t>& buffer, const uint64_t current,
+                             const CellDeserializer& value_deserializer = arc_utilities::DeserializeFixedSizePOD<COLLISION_CELL>) override {
+        (void)value_deserializer;
+        uint64_t pos = current;
+        pos += BaseDeserializeSelf(buffer, pos, arc_utilities::DeserializeFixedSizePOD<COLLISION_CELL>);
+        const auto nc = arc_utilities::DeserializeFixedSizePOD<uint32_t>(buffer, pos); pos += nc.second;
+        const auto fr = arc_utilities::DeserializeString(buffer, pos); pos += fr.second;
+        const auto cv = arc_utilities::DeserializeFixedSizePOD<uint8_t>(buffer, pos); pos += cv.second;
+        number_of_components_ = nc.first;
+        frame_ = fr.first;
+        components_valid_ = (bool)cv.first;
+        return pos - current;
+    }
+
+    static void SaveToFile(const CollisionMapGrid& map, const std::string& filepath, const bool compress) {
+        std::vector<uint8_t> buffer;
+        map.SerializeSelf(buffer);
+        std::ofstream out(filepath, std::ios::out | std::ios::binary);
+        const std::vector<uint8_t> body = compress ? ZlibHelpers::CompressBytes(buffer) : buffer;
+        out.write(compress ? "CMGZ" : "CMGR", 4);                 // 4-byte magic (:214-229)
+        out.write(reinterpret_cast<const char*>(body.data()), (std::streamsize)body.size());
+    }
+    static CollisionMapGrid LoadFromFile(const std::string& filepath) {
+        std::ifstream in(filepath, std::ios::in | std::ios::binary);
+        if (!in.good()) throw std::invalid_argument("File does not exist");
+        std::vector<uint8_t> all((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        if (all.size() < 4) throw std::invalid_argument("File is too small");
+        const std::string magic(all.begin(), all.begin() + 4);
+        const std::vector<uint8_t> body(all.begin() + 4, all.end());
+        CollisionMapGrid map;
+        if (magic == "CMGZ") map.DeserializeSelf(ZlibHelpers::DecompressBytes(body), 0);
+        else if (magic == "CMGR") map.DeserializeSelf(body, 0);
+        else throw std::invalid_argument("File has invalid header [" + magic + "]");
+        return map;
+    }
+    static CollisionMap GetMessageRepresentation(const CollisionMapGrid& map) {
+        CollisionMap msg;                                         // always zlib-compressed (:285-296); no ROS clock here: stamp stays 0
+        msg.header.frame_id = map.GetFrame();
+        std::vector<uint8_t> buffer;
+        map.SerializeSelf(buffer);
+        msg.serialized_map = ZlibHelpers::CompressBytes(buffer);
+        msg.is_compressed = true;
+        return msg;
+    }
+    static CollisionMapGrid LoadFromMessageRepresentation(const CollisionMap& message) {
+        CollisionMapGrid map;
+        if (message.is_compressed) map.DeserializeSelf(ZlibHelpers::DecompressBytes(message.serialized_map), 0);
+        else map.DeserializeSelf(message.serialized_map, 0);
+        return map;
     }
 
     // Same result through the generic predicate seam (kept for callers that pass their own predicate).

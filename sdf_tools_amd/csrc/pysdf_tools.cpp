@@ -63,6 +63,12 @@ PYBIND11_MODULE(pysdf_tools, m) {
         .def_readwrite("is_compressed", &SDF::is_compressed)
         .def_property("frame_id", [](const SDF& s) { return s.header.frame_id; }, [](SDF& s, const std::string& f) { s.header.frame_id = f; });
 
+    py::class_<CollisionMap>(m, "CollisionMap")                // plain mirror of msg/CollisionMap.msg
+        .def(py::init<>())
+        .def_readwrite("serialized_map", &CollisionMap::serialized_map)
+        .def_readwrite("is_compressed", &CollisionMap::is_compressed)
+        .def_property("frame_id", [](const CollisionMap& s) { return s.header.frame_id; }, [](CollisionMap& s, const std::string& f) { s.header.frame_id = f; });
+
     using VoxelGridVecd = VoxelGrid::VoxelGrid<std::vector<double>>;
 
     py::class_<SignedDistanceField>(m, "SignedDistanceField")
@@ -129,6 +135,16 @@ PYBIND11_MODULE(pysdf_tools, m) {
         .def(py::init<Isometry3d const&, std::string, double, int64_t, int64_t, int64_t, COLLISION_CELL const&>())
         .def("SetValue", [](CollisionMapGrid& g, int64_t x, int64_t y, int64_t z, const COLLISION_CELL& c) { return g.SetValue(x, y, z, c); })
         .def("SetValueByCoordinates", [](CollisionMapGrid& g, double x, double y, double z, const COLLISION_CELL& c) { return g.SetValue(x, y, z, c); })
+        // wire formats (collision_map.cpp:21-62, :205-315)
+        .def(py::init<>())
+        .def("SerializeSelf", [](const CollisionMapGrid& g) { std::vector<uint8_t> b; g.SerializeSelf(b); return py::bytes(reinterpret_cast<const char*>(b.data()), b.size()); })
+        .def_static("Deserialize", [](const py::bytes& data) { const std::string s = data; CollisionMapGrid g; g.DeserializeSelf(std::vector<uint8_t>(s.begin(), s.end()), 0); return g; })
+        .def("SaveToFile", [](const CollisionMapGrid& g, const std::string& path, bool compress) { CollisionMapGrid::SaveToFile(g, path, compress); })
+        .def_static("LoadFromFile", &CollisionMapGrid::LoadFromFile)
+        .def("GetMessageRepresentation", [](const CollisionMapGrid& g) { return CollisionMapGrid::GetMessageRepresentation(g); })
+        .def_static("LoadFromMessageRepresentation", &CollisionMapGrid::LoadFromMessageRepresentation)
+        .def("GetFrame", &CollisionMapGrid::GetFrame)
+        .def("GetResolution", &CollisionMapGrid::GetResolution)
         .def("GetRawData", &CollisionMapGrid::GetImmutableRawData, "Please don't mutate this")
         .def("GetValueByCoordinates", [](const CollisionMapGrid& g, double x, double y, double z) { const auto q = g.GetImmutable(x, y, z); return std::make_pair(q.first, q.second); },
              "Please don't mutate this", py::arg("x"), py::arg("y"), py::arg("z"))

@@ -20,7 +20,9 @@ def test_module_surface_matches_reference_bindings():
                                 "GetValueByCoordinates", "GetValueByIndex", "GetNumXCells", "GetNumYCells", "GetNumZCells"],
         "CollisionMapGrid": ["SetValue", "SetValueByCoordinates", "GetRawData", "GetValueByCoordinates",
                              "GetValueByIndex", "GetNumXCells", "GetNumYCells", "GetNumZCells",
-                             "ExtractSignedDistanceField"],
+                             "ExtractSignedDistanceField", "SerializeSelf", "SaveToFile", "LoadFromFile",
+                             "GetMessageRepresentation", "LoadFromMessageRepresentation"],
+        "CollisionMap": ["serialized_map", "is_compressed", "frame_id"],
         "VoxelGrid": ["GetRawData", "GetNumXCells", "GetNumYCells", "GetNumZCells", "GetValueByCoordinates",
                       "GetValueByIndex", "SerializeSelf", "DeserializeSelf"],
     }.items():
@@ -96,3 +98,62 @@ def test_empty_sdf_serialisation_round_trip():
     blob = s.SerializeSelf()
     s2 = m.SignedDistanceField()
     assert s2.DeserializeSelf(list(blob), 0) == len(blob)
+
+
+def _golden_grid():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "make_collision_map_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_collision_map_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.make_grid(m)
+
+
+def _cells(g):
+    return [(g.GetValueByIndex(x, y, z)[0].occupancy, g.GetValueByIndex(x, y, z)[0].component)
+            for x in range(g.GetNumXCells()) for y in range(g.GetNumYCells()) for z in range(g.GetNumZCells())]
+
+
+def test_collision_map_wire_format_is_pinned_and_round_trips(tmp_path):
+    """N3, collision-map half (reference src/sdf_tools/collision_map.cpp:21-62, :205-315): the serialised bytes of a fixed grid
+    equal the committed self-golden vector (field order: initialized, both transforms, cell vector, cell / grid sizes,
+    strides and counts, default and OOB cell, number of components, frame, components_valid), and every wire form --
+    raw bytes, CMGR / CMGZ files, the compressed message -- restores the same grid.  Interoperability with files written
+    by the reference itself is unverified (arc_utilities is not vendored there)."""
+    import os
+    import struct
+    g = _golden_grid()
+    blob = bytes(g.SerializeSelf())
+    golden = bytes.fromhex(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collision_map_serialized.hex")).read().strip())
+    assert blob == golden
+    # spot-check the layout: 1 byte initialized, 2 x 16 doubles of transforms, then the u64 cell count and 8-byte cells
+    assert blob[0] == 1 and struct.unpack_from("<Q", blob, 1 + 256)[0] == 12
+    occ, comp = struct.unpack_from("<fI", blob, 1 + 256 + 8 + 8 * 5)
+    assert (occ, comp) == (0.125 * 5, 15)
+    assert blob.endswith(struct.pack("<I", 0) + struct.pack("<Q", 12) + b"golden_frame" + b"\x00")
+    want = _cells(g)
+    back = m.CollisionMapGrid.Deserialize(blob)
+    assert _cells(back) == want and back.GetFrame() == "golden_frame" and back.GetResolution() == 0.5
+    cell, ok = back.GetValueByIndex(-1, 0, 0)
+    assert not ok and (cell.occupancy, cell.component) == (-7.5, 9)
+    for compress, magic in ((False, b"CMGR"), (True, b"CMGZ")):
+        path = str(tmp_path / ("map_%d.cmg" % compress))
+        g.SaveToFile(path, compress)
+        raw = open(path, "rb").read()
+        assert raw[:4] == magic and (compress or raw[4:] == blob)
+        assert _cells(m.CollisionMapGrid.LoadFromFile(path)) == want
+    with pytest.raises(Exception):
+        m.CollisionMapGrid.LoadFromFile(str(tmp_path / "missing.cmg"))
+    bad = str(tmp_path / "bad.cmg")
+    open(bad, "wb").write(b"XXXX" + blob)
+    with pytest.raises(Exception):
+        m.CollisionMapGrid.LoadFromFile(bad)
+    msg = g.GetMessageRepresentation()
+    assert msg.is_compressed and msg.frame_id == "golden_frame"
+    assert bytes(m.DecompressBytes(list(msg.serialized_map))) == blob
+    assert _cells(m.CollisionMapGrid.LoadFromMessageRepresentation(msg)) == want
+    plain = m.CollisionMap()
+    plain.serialized_map = list(blob)
+    plain.is_compressed = False
+    assert _cells(m.CollisionMapGrid.LoadFromMessageRepresentation(plain)) == want
