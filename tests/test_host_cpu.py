@@ -88,9 +88,10 @@ def test_multi_gpu_library_exports_every_declared_symbol_and_refuses_without_gpu
 
 
 def test_far_field_schedule_model_is_exact():
-    """tools/envelope_dc_model.py restates k_envelope_dc's schedule (32-bit keys, levels, pair-wise scans that may read one
-    candidate past the range, distance-bound clipping, exhaustive chunk phase) line by line on the CPU; it must equal a
-    brute-force min-plus evaluation on random lines incl. ties, runs, lengths that are not multiples of 8 and empty lines."""
+    """tools/envelope_dc_model.py restates k_envelope_dc's schedule (centred 32-bit keys, levels A / B / C, scans in aligned
+    pairs that read one candidate before and behind the range, distance-bound clipping with a tile-level bound, exhaustive
+    chunk phase) line by line on the CPU; it must equal a brute-force min-plus evaluation on random lines incl. ties, runs,
+    flat far-field lines, lengths that are not multiples of 8 / 64 and empty lines, with tile-level spans looser than the line's."""
     import importlib.util
     import random
     spec = importlib.util.spec_from_file_location(
@@ -116,3 +117,4 @@ def test_far_field_schedule_model_is_exact():
         finf = max([v for v in F if v < model.INF] + [0]) + (L - 1) ** 2 + 1
         got, _ = model.dc_line(F, finf)
         assert got == model.brute(F), (trial, L, kind)
+        model.check_line(rng, F)                                    # again with a looser span / bound and a forced level-A form

@@ -1,79 +1,105 @@
 #!/usr/bin/env python3
-"""Executable model of the divide-and-conquer lower-envelope sweep of sdfgpu_envelope_dc.hpp (k_envelope_dc):
-the same key encoding, level structure, pair-wise scans (including the harmless candidate hi + 1) and chunk phase,
-run line by line on the CPU and compared with a brute-force min-plus evaluation.  Development aid only (the GPU
-tests compare the kernel itself with the exact oracle); run: python tools/envelope_dc_model.py"""
+"""Executable model of the far-field sweep of sdfgpu_envelope_dc.hpp (k_envelope_dc, third generation): the same centred
+32-bit keys, the three levels (A: positions 64 i, clipped by the distance bound or over the whole span; B: positions 8 j
+inside the intervals of A; C: chunks of 8 positions inside the intervals of B), scans in ALIGNED PAIRS -- which read up to
+one candidate before and one behind the range they are given -- and a tile-level site span / smallest site value that may
+be looser than the line's own.  Run line by line on the CPU and compared with a brute-force min-plus evaluation.
+Development aid and a CPU test (tests/test_host_cpu.py); the GPU tests compare the kernel itself with the exact oracle.
+Run: python tools/envelope_dc_model.py"""
+import math
 import random
+import struct
 import sys
 
 INF = 1 << 30
+M32 = 0xFFFFFFFF
 
 
-def dc_line(F, FINF):
+def f32(x):
+    return struct.unpack("f", struct.pack("f", float(x)))[0]
+
+
+def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None):
+    """F: site values (INF = no site).  lo_t / hi_t: span handed to the line (a superset of its sites), mt_t: a lower bound
+    of the site values (the kernel keeps both per tile of 16 lines).  Returns (D, candidate evaluations)."""
     L = len(F)
     B = max(1, (L - 1).bit_length())
     mask = (1 << B) - 1
-    assert FINF + L * L < (1 << (32 - B)), "keys do not fit 32 bits"
-    key = [(((F[q] if F[q] < INF else FINF) + q * q) << B) | q for q in range(L)]
-    key.append(((FINF + L * L) << B) | (L & mask))                 # sentinel behind the line
-    sites = [q for q in range(L) if F[q] < INF]
-    if not sites:
+    h = (L + 1) // 2
+    assert FINF + (L + 2) ** 2 < (1 << (32 - B)), "keys do not fit 32 bits"
+    Fc = [min(v, FINF) for v in F]
+    key = [(((Fc[q] + (q - h) ** 2 + h * h) << B) | q) & M32 for q in range(L)]
+    for q in (L, L + 1):                                            # two sentinels behind the line
+        key.append((((FINF + (q - h) ** 2 + h * h) << B) | (q & mask)) & M32)
+    sites = [q for q in range(L) if Fc[q] < FINF]
+    if lo_t is None:
+        lo_t, hi_t = (sites[0], sites[-1]) if sites else (0, -1)
+    if mt_t is None:
+        mt_t = min([Fc[q] for q in sites] + [M32])
+    if lo_t > hi_t:
         return [INF] * L, 0
-    qmin, qmax = sites[0], sites[-1]
     M = (L + 7) // 8
-    a = [0] * (M + 2)
-    Kp = M.bit_length()
+    MA = (L + 63) // 64
+    args = [M32] * (M + 2)
     evals = [0]
 
-    def scan(p, lo, hi, u=0, G=1):
-        P2B = (p * p) << B
-        c = (2 * p) << B
-        q = lo + 2 * u
-        best = 0xFFFFFFFF
+    def nc(p):                                                      # -(2 p') << B
+        return ((h - p) << (B + 1))
+
+    def val(p, q):                                                  # key[q] - ((2 p') << B) * q'   (mod 2^32)
+        v = (key[q] + nc(p) * (q - h)) & M32
+        # (positions past the end of the line ride along in the last interval / chunk; their values may wrap and are dropped)
+        assert p >= L or v == ((((key[q] >> B) - (q - h) ** 2 - h * h + (p - q) ** 2 + h * h - (p - h) ** 2) << B) | (key[q] & mask)), "value left the 32-bit range"
+        return v
+
+    def scan(positions, lo, hi):                                    # aligned pairs: candidates (lo & ~1) .. hi | 1
+        assert lo <= hi, "empty range: the monotonicity of the argmins is broken"
+        best = [M32] * len(positions)
+        q = lo & ~1
         while q <= hi:
-            R = (P2B - c * q) & 0xFFFFFFFF
-            t0 = (key[q] + R) & 0xFFFFFFFF
-            t1 = (key[q + 1] + R - c) & 0xFFFFFFFF
-            assert t0 == ((((key[q] >> B) - q * q + (p - q) ** 2) << B) | (key[q] & mask))
-            best = min(best, t0, t1)
-            evals[0] += 2
-            q += 2 * G
+            for k, p in enumerate(positions):
+                best[k] = min(best[k], val(p, q), val(p, q + 1))
+                evals[0] += 2
+            q += 2
         return best
 
-    for l in range(Kp):
-        h = 1 << (Kp - 1 - l)
-        j = 0
-        while h * (2 * j + 1) <= M:
-            ip = h * (2 * j + 1)
-            lo = qmin if ip - h == 0 else a[ip - h]
-            hi = qmax if ip + h > M else a[ip + h]
-            assert lo <= hi
-            p = 8 * (ip - 1)
-            n_pos = (M // h + 1) >> 1
-            if n_pos <= 8:      # distance-bound clipping of the first levels (any candidate's cost bounds the optimum)
-                pc = min(max(p, lo), hi)
-                v = min((key[c] >> B) - c * c + (p - c) ** 2 for c in (pc, lo, hi))
-                if v < FINF:
-                    w = int(v ** 0.5) + 2
-                    lo, hi = max(lo, p - w), min(hi, p + w)
-                    assert lo <= hi
-            G = max(1, 16 >> l)
-            best = min(scan(p, lo, hi, u, G) for u in range(G))
-            a[ip] = best & mask
-            assert lo <= a[ip] <= hi
-            j += 1
+    def dist(best, p):
+        return (best >> B) - p * (2 * h - p)
+
+    # level A
+    for i in range(MA):
+        p = 64 * i
+        lo, hi = lo_t, hi_t
+        clip = force_clip if force_clip is not None else (i % 2 == 0)
+        if clip:
+            pcl = min(max(p, lo_t), hi_t)
+            ub = min(val(p, pcl), val(p, lo_t), val(p, hi_t))
+            dub = dist(ub, p)
+            if dub < FINF:
+                w = int(math.sqrt(f32(dub - min(mt_t, dub)))) + 2
+                lo, hi = max(lo, p - w), min(hi, p + w)
+        args[8 * i] = scan([p], lo, hi)[0]
+    # level B
+    for i in range(MA):
+        lo = args[8 * i] & mask
+        hi = (args[8 * (i + 1)] & mask) if i + 1 < MA else hi_t
+        pos = [64 * i + 8 * k for k in range(8)]
+        best = scan(pos, lo, hi)
+        for k in range(1, 8):
+            if 8 * i + k < M:
+                args[8 * i + k] = min(args[8 * i + k], best[k])
+    # level C
     D = [None] * L
     for i in range(M):
-        p0 = 8 * i
-        a0 = a[i + 1]
-        a8 = a[i + 2] if i + 2 <= M else qmax
-
-        # every position of the chunk against all of [a0, a8] (pairs: a8 + 1 may be read); the kernel has no other path
+        a0 = args[i] & mask
+        a8 = (args[i + 1] & mask) if i + 1 < M else hi_t
+        best = scan([8 * i + k for k in range(8)], a0, a8)
         for k in range(8):
-            if p0 + k < L:
-                best = min(scan(p0 + k, a0, a8), 0xFFFFFFFF)
-                D[p0 + k] = best >> B
-    return [d if d < FINF else INF for d in D], evals[0]
+            p = 8 * i + k
+            if p < L:
+                d = dist(best[k], p)
+                D[p] = INF if d >= FINF else d
+    return D, evals[0]
 
 
 def brute(F):
@@ -88,32 +114,46 @@ def brute(F):
     return out
 
 
+def random_line(rng, L):
+    dens = rng.choice([0.0, 0.01, 0.05, 0.3, 1.0])
+    vmax = rng.choice([1, 4, 50, 1000, 200000])
+    kind = rng.choice(["rand", "smooth", "ties", "runs", "flat"])
+    c = rng.randrange(-50, L + 50)
+    hh = rng.randrange(0, 300)
+    F = []
+    for q in range(L):
+        if kind == "smooth":
+            F.append(hh * hh + (q - c) ** 2 if rng.random() < max(dens, 0.3) else INF)
+        elif kind == "ties":
+            F.append(rng.choice([0, 1, 4]) if rng.random() < dens else INF)
+        elif kind == "runs":
+            F.append(0 if (q // 7) % 3 == 0 and dens > 0 else INF)
+        elif kind == "flat":
+            F.append(hh * hh + rng.randrange(0, 3) if rng.random() < max(dens, 0.2) else INF)
+        else:
+            F.append(rng.randrange(0, vmax + 1) if rng.random() < dens else INF)
+    return F
+
+
+def check_line(rng, F):
+    L = len(F)
+    FINF = max([v for v in F if v < INF] + [0]) + (L - 1) ** 2 + 1      # above every real result
+    sites = [q for q in range(L) if F[q] < INF]
+    kw = {}
+    if sites and rng.random() < 0.5:                                    # a looser (tile-level) span and bound
+        kw = dict(lo_t=rng.randrange(0, sites[0] + 1), hi_t=rng.randrange(sites[-1], L),
+                  mt_t=rng.randrange(0, min(F[q] for q in sites) + 1))
+    kw["force_clip"] = rng.choice([None, True, False])
+    got, ev = dc_line(F, FINF, **kw)
+    assert got == brute(F), (L, F, kw)
+    return ev
+
+
 def main():
     rng = random.Random(1)
-    total = 0
     for trial in range(3000):
-        L = rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 40, 64, 100, 127, 128, 200, 255, 256, 257, 512])
-        dens = rng.choice([0.0, 0.01, 0.05, 0.3, 1.0])
-        vmax = rng.choice([1, 4, 50, 1000, 200000])
-        kind = rng.choice(["rand", "smooth", "ties", "runs"])
-        F = []
-        c = rng.randrange(-50, L + 50)
-        hh = rng.randrange(0, 300)
-        for q in range(L):
-            if kind == "smooth":
-                F.append(hh * hh + (q - c) ** 2 if rng.random() < max(dens, 0.3) else INF)
-            elif kind == "ties":
-                F.append(rng.choice([0, 1, 4]) if rng.random() < dens else INF)
-            elif kind == "runs":
-                F.append(0 if (q // 7) % 3 == 0 and dens > 0 else INF)
-            else:
-                F.append(rng.randrange(0, vmax + 1) if rng.random() < dens else INF)
-        FINF = max([v for v in F if v < INF] + [0]) + (L - 1) ** 2 + 1      # above every real result
-        got, ev = dc_line(F, FINF)
-        want = brute(F)
-        assert got == want, (trial, L, kind, F, got, want)
-        total += ev
-    # cost on a smooth far-field line of 512 (every site on the envelope)
+        L = rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 40, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 512])
+        check_line(rng, random_line(rng, L))
     F = [150 * 150 + (q - 700) ** 2 for q in range(512)]
     got, ev = dc_line(F, 700 ** 2 + 150 ** 2 + 511 ** 2 + 1)
     assert got == brute(F)
