@@ -129,6 +129,17 @@ def load_traffic():
     return None
 
 
+def load_rocprof_times():
+    """profiles/kernel_times.json: {kernel name fragment: average ms} from the committed rocprofv3 --stats summary of the
+    bench command (written by tools/profile_round.sh); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "kernel_times.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def stage_table(ctx, ms_sum, builds, n_total):
     """Per-stage average ms of the profiled builds -> {stage: ms}, kernels used, dominant stage."""
     info = ctx.last_build_info()
@@ -447,6 +458,10 @@ def main():
             # the same steps again without any HIP events: reported next to `value`, never instead of it
             dt2 = timed_loop(step, args.steps, fence)
             result["value_without_stage_events"] = round(n_total / (dt2 / args.steps) / 1e6, 2)
+        # spread: the same K-step loop five more times (`value` stays the first, contract-timed loop)
+        reps = sorted(n_total / (timed_loop(step, args.steps, fence) / args.steps) / 1e6 for _ in range(5))
+        result["value_repeats"] = {"n": 5, "min": round(reps[0], 2), "median": round(reps[2], 2), "max": round(reps[4], 2),
+                                   "note": "five more runs of the same timed loop (events off), Mvoxels/s"}
         mx, mn = ctx.get_extrema()
         result["extrema"] = [mx, mn]
         if builds:
@@ -457,6 +472,9 @@ def main():
             dom = max(stage_ms, key=stage_ms.get)
             r = roofline_of(dom, stage_ms[dom], n_total, info["plane16"], load_traffic(), info)
             r["stages_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+            rp = load_rocprof_times()
+            if rp and rp.get(r.get("kernel")):
+                r["rocprof_avg_ms"] = rp[r["kernel"]]              # rocprofv3 --kernel-trace --stats of the same command (profiles/)
             r["note"] = ("frac = compulsory bytes of this kernel (bytes_per_voxel x voxels) / HIP-event duration / peak; "
                          "traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json)")
             result["roofline"] = r

@@ -404,8 +404,11 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
 // voxels (p = 0.03 leaves 6 % undecided: KF would take 2.5 ms where the sweeps take 1.1) -- raises `uncertified` and the guarded general sweeps redo the grid, so results are exact for any input.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFixR = 6;
-constexpr int kFixCap = 160;                                  // undecided voxels a tile may hand to KF: beyond ~2 % of a
-                                                              // tile the general sweeps are cheaper than visiting them
+constexpr int kFixCap = 512;                                  // undecided voxels a tile may hand to KF (round 3: 160 -> 512 with the
+                                                              // early exit below: Bernoulli p = 0.05 leaves 0.9 % undecided -- ~280 per
+                                                              // tile -- and took the marching sweeps at 0.84 ms instead; p = 0.03 leaves
+                                                              // 6 %, ~2000 per tile: there the sweeps are cheaper and the cap sends it on)
+constexpr int kFixDirect = 24;                                // tiles with at most this many undecided voxels read the bit field directly
 constexpr int kFixRows = (2 * kFixR + 1) * (2 * kFixR + 1);   // 169 (dx, dy) rows
 
 struct FixArgs {
@@ -443,36 +446,6 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     if (t == 0) { *count = 0u; a.tileflag[tile_id] = 0u; }
     for (int i = t; i < kFixRows; i += BD) order[i] = a.order[i];
     const int x0 = a.out_lo + (int)blockIdx.y * a.tx, y0 = (int)blockIdx.x * a.ty;
-    {
-        // rows / edge words replicate the nearest in-grid voxel.  Lanes = (row in pass, word slot): 2^lgp >= rw slots
-        const int lgp = lg + 1 > 2 ? lg + 1 : 2;
-        const int ws = t & ((1 << lgp) - 1), r0 = t >> lgp, rpp = BD >> lgp;
-        if (ws < rw) {
-            const int nrows = hx * hy;
-            for (int row0 = r0; row0 < nrows; row0 += 4 * rpp) {          // 4 independent loads in flight per lane
-                uint32_t v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = min(row0 + k * rpp, nrows - 1);
-                    const int jx = row / hy, jy = row - jx * hy;
-                    const int gx = min(max(x0 + jx - kFixR, 0), a.rows_x - 1);
-                    const int gy = min(max(y0 + jy - kFixR, 0), a.ny - 1);
-                    const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
-                    v[k] = src[min(max(ws - 1, 0), nzw - 1)];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int row = row0 + k * rpp;
-                    if (row < nrows) {
-                        uint32_t x = v[k];
-                        if (ws == 0) x = (x & 1u) ? ~0u : 0u;
-                        else if (ws == rw - 1) x = (x >> 31) ? ~0u : 0u;
-                        tile[row * rw + ws] = x;
-                    }
-                }
-            }
-        }
-    }
     __syncthreads();
     // this lane's word (same mapping as KD) -> list of its undecided voxels
     {
@@ -495,50 +468,126 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         if (t == 0) raise_flag(a.uncertified);
         return;
     }
+    // A tile with a handful of undecided voxels (Bernoulli p = 0.1: two per tile, in nearly every tile) reads the rows it
+    // needs straight from the L2-resident bit field -- 64 .. 169 rows of 3 words per voxel -- instead of staging the whole
+    // halo tile in LDS ((tx + 12) x (ty + 12) rows for two voxels was most of this kernel's time there).
+    const bool direct = n <= (uint32_t)kFixDirect;            // (block-uniform)
+    if (!direct) {
+    {
+            // rows / edge words replicate the nearest in-grid voxel.  Lanes = (row in pass, word slot): 2^lgp >= rw slots
+            const int lgp = lg + 1 > 2 ? lg + 1 : 2;
+            const int ws = t & ((1 << lgp) - 1), r0 = t >> lgp, rpp = BD >> lgp;
+            if (ws < rw) {
+                const int nrows = hx * hy;
+                for (int row0 = r0; row0 < nrows; row0 += 4 * rpp) {          // 4 independent loads in flight per lane
+                    uint32_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = min(row0 + k * rpp, nrows - 1);
+                        const int jx = row / hy, jy = row - jx * hy;
+                        const int gx = min(max(x0 + jx - kFixR, 0), a.rows_x - 1);
+                        const int gy = min(max(y0 + jy - kFixR, 0), a.ny - 1);
+                        const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
+                        v[k] = src[min(max(ws - 1, 0), nzw - 1)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = row0 + k * rpp;
+                        if (row < nrows) {
+                            uint32_t x = v[k];
+                            if (ws == 0) x = (x & 1u) ? ~0u : 0u;
+                            else if (ws == rw - 1) x = (x >> 31) ? ~0u : 0u;
+                            tile[row * rw + ws] = x;
+                        }
+                    }
+                }
+            }
+        }
+    __syncthreads();
+    }
     int mxF = 0, mxQ = 0;
     bool failed = false;
     const int nz = nzw << 5;
-    // one WAVE per voxel: the 169 rows are spread over the 64 lanes (3 each, no dependence between them) and the
-    // candidates are min-reduced across the wave -- a lane-per-voxel scan with early exit was 4x slower here
-    // because a tile rarely holds more than a handful of undecided voxels
-    const int lane = t & 63;
-    for (uint32_t i = (uint32_t)t >> 6; i < n; i += BD / 64) {
-        const uint32_t e = list[i];                           // wave-uniform
+    // one 16-lane ROW per voxel (4 voxels per wave): the 169 (dx, dy) rows, sorted by dx^2 + dy^2, go past in batches of
+    // 64 (4 per lane, no dependence between them), the candidates are min-reduced over the DPP row, and a voxel stops as
+    // soon as its best candidate is no larger than the smallest in-plane offset still to come -- the usual case after the
+    // first batch (it covers dx^2 + dy^2 <= 18; at p = 0.05 the nearest opposite voxel lies at d^2 ~ 9 .. 14).
+    // (Round 2 ran one WAVE per voxel without the early exit: right for the handful of voxels per tile of p = 0.1, 0.4 us
+    // per voxel at the ~280 per tile of p = 0.05.)
+    auto rowmin = [](int v) -> int {
+        v = min(v, __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true));      // row_ror:8
+        v = min(v, __builtin_amdgcn_mov_dpp(v, 0x124, 0xF, 0xF, true));      // row_ror:4
+        v = min(v, __builtin_amdgcn_mov_dpp(v, 0x122, 0xF, 0xF, true));      // row_ror:2
+        v = min(v, __builtin_amdgcn_mov_dpp(v, 0x121, 0xF, 0xF, true));      // row_ror:1
+        return v;
+    };
+    const int gl = t & 15, grp = t >> 4;
+    for (uint32_t i0 = 0; i0 < n; i0 += BD / 16) {             // (uniform trip count: every lane takes part in the reductions)
+        const uint32_t i = i0 + (uint32_t)grp;
+        const bool live = i < n;
+        const uint32_t e = list[live ? i : 0u];
         const int r = (int)(e >> 16), z = (int)(e & 0xffffu);
         const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
         const int w = z >> 5, b = z & 31;
         const uint32_t* c0 = tile + ((tx_ + kFixR) * hy + (ty_ + kFixR)) * rw + (w + 1);
-        const uint32_t cls = (c0[0] >> b) & 1u;
+        // the three words around bit b of row (dx, dy); rows / edge words beyond the grid replicate the nearest in-grid voxel
+        auto words = [&](int dx, int dy, uint32_t& prev, uint32_t& cur, uint32_t& next) {
+            if (!direct) {
+                const uint32_t* p = c0 + (dx * hy + dy) * rw;
+                prev = p[-1]; cur = p[0]; next = p[1];
+            } else {
+                const int gx = min(max(x0 + tx_ + dx, 0), a.rows_x - 1), gy = min(max(y0 + ty_ + dy, 0), a.ny - 1);
+                const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
+                cur = src[w];
+                prev = w > 0 ? src[w - 1] : ((src[0] & 1u) ? ~0u : 0u);
+                next = w + 1 < nzw ? src[w + 1] : ((src[nzw - 1] >> 31) ? ~0u : 0u);
+            }
+        };
+        uint32_t cw0, cw1, cw2;
+        words(0, 0, cw0, cw1, cw2);
+        const uint32_t cls = (cw1 >> b) & 1u;
         const uint32_t flip = cls ? ~0u : 0u;                 // after the XOR a set bit = voxel of the OTHER class
         int best = 1 << 20;
-#pragma unroll
+        bool done = !live;
+#pragma unroll 1
         for (int k0 = 0; k0 < kFixRows; k0 += 64) {
-            const int k = k0 + lane;
-            if (k < kFixRows) {
-                const uint32_t o = order[k];
-                const int d2 = (int)(o >> 16);
-                const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
-                const uint32_t* p = c0 + (dx * hy + dy) * rw;
-                const uint32_t prev = p[-1] ^ flip, cur = p[0] ^ flip, next = p[1] ^ flip;
-                // dz >= 0: bit dz of `up` = voxel z + dz
-                const uint32_t up = (uint32_t)((((uint64_t)next << 32) | cur) >> b) & ((2u << kFixR) - 1u);
-                if (up) { const int dz = __builtin_ctz(up); best = min(best, d2 + dz * dz); }
-                // dz < 0: bit i of `dn` = voxel z - kFixR + i
-                const uint32_t dn = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32 + b - kFixR)) & ((1u << kFixR) - 1u);
-                if (dn) { const int dz = kFixR - (31 - __builtin_clz(dn)); best = min(best, d2 + dz * dz); }
+            if (k0 > 0) {
+                done = done || rowmin(best) <= (int)(order[k0] >> 16);
+                if (__all(done)) break;
+            }
+            if (!done) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int k = k0 + gl + 16 * m;
+                    if (k < kFixRows) {
+                        const uint32_t o = order[k];
+                        const int d2 = (int)(o >> 16);
+                        const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
+                        uint32_t prev, cur, next;
+                        words(dx, dy, prev, cur, next);
+                        prev ^= flip; cur ^= flip; next ^= flip;
+                        // dz >= 0: bit dz of `up` = voxel z + dz
+                        const uint32_t up = (uint32_t)((((uint64_t)next << 32) | cur) >> b) & ((2u << kFixR) - 1u);
+                        if (up) { const int dz = __builtin_ctz(up); best = min(best, d2 + dz * dz); }
+                        // dz < 0: bit i of `dn` = voxel z - kFixR + i
+                        const uint32_t dn = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32 + b - kFixR)) & ((1u << kFixR) - 1u);
+                        if (dn) { const int dz = kFixR - (31 - __builtin_clz(dn)); best = min(best, d2 + dz * dz); }
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) best = min(best, __shfl_xor(best, off));
-        if (best <= kFixR * kFixR) {
-            if (lane == 0) {
-                const float f = (float)(sqrt((double)best) * a.resolution);
-                const int gx = x0 + tx_, gy = y0 + ty_;
-                a.out[((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z] = cls ? -f : f;
+        best = rowmin(best);
+        if (live) {
+            if (best <= kFixR * kFixR) {
+                if (gl == 0) {
+                    const float f = (float)(sqrt((double)best) * a.resolution);
+                    const int gx = x0 + tx_, gy = y0 + ty_;
+                    a.out[((int64_t)(gx - a.out_lo) * a.ny + gy) * nz + z] = cls ? -f : f;
+                }
+                if (cls) mxQ = max(mxQ, best); else mxF = max(mxF, best);
+            } else {
+                failed = true;
             }
-            if (cls) mxQ = max(mxQ, best); else mxF = max(mxF, best);
-        } else {
-            failed = true;
         }
     }
 #pragma unroll
