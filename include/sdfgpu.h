@@ -334,7 +334,7 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * redoes sweeps whose bounded scans did not decide every voxel, default; 0 = never: the marching scans stay unbounded), "tier_select" (1 = choose marching vs
  * envelope sweep per axis on the device inside each build from a probe of the sweep's input, default; 0 = learn
  * it from the previous build on the handle), "far_threshold_y" / "far_fraction_den_y" and "..._x" (an axis counts as
- * far-field when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 36, 8 for the
+ * far-field when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 5 for the
  * y sweep and 9, 24 for the x sweep), "mid_threshold_y" / "mid_fraction_den_y" (near-field y sweep: radius-8 marching
  * windows when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 24; den 0 = leave
  * the window to the host policy), "i32_handoff" (1 = when the y probe finds the scene far-field, the x sweep is the

@@ -91,8 +91,11 @@ struct sdfgpu_context {
     // voxels (Bernoulli p = 0.02: 1.31 vs 1.29 ms; p = 0.015: 1.54 vs 1.29 ms; p = 0.025: 1.21 vs 1.28 ms); the x marching sweep falls behind the far-field kernel as soon as its
     // radius-3 window stops deciding nearly every voxel (Bernoulli p = 0.03: 0.65 ms against 0.55; p = 0.04 and denser:
     // marching wins), so its threshold is d^2 >= 9 on 1 / 24 of the voxels (p = 0.03: 6 %, p = 0.04: 2.4 %)
-    int far_thr[2] = {36, 9};
-    int far_den[2] = {8, 24};
+    // (round 3, third-generation far-field kernel: KE2 0.57 -> 0.39 ms moves the y break-even from Bernoulli p ~ 0.018 up to
+    //  p ~ 0.035 -- tools/tier_sweep.py: p = 0.03 1.01 vs 0.97 ms, p = 0.02 1.16 vs 0.985, p = 0.04 0.87 vs 0.97 -- i.e. from
+    //  "d^2 >= 36 on an eighth" to "d^2 >= 16 on a fifth" of the voxels: (1 - p)^49 = 0.225 at p = 0.03, 0.135 at p = 0.04)
+    int far_thr[2] = {16, 9};
+    int far_den[2] = {5, 24};
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     bool dc_lds_attr[4] = {false, false, false, false};

@@ -41,6 +41,8 @@
 //     SLOWER on every scene (120 VGPRs, static tile assignment);
 //   * an LDS table of the finished values of small squared distances instead of the fp64 finish: no change -- removing the
 //     fp64 finish altogether does not change the time either (it overlaps with the integer pipe);
+//   * finishing 4 chunks per lane first and storing their 32 values back to back (store bursts like the bare memory pattern's):
+//     no change;
 //   * ablation of the x sweep on the two-box scene: no search 0.37 ms (of 0.55), no search and no stores 0.19 ms.
 // Exactness: integer arithmetic throughout; the finish is the reference's (sqrt and multiply in fp64, one cast,
 // sdf_generation.hpp:254-265).
