@@ -391,6 +391,9 @@ struct DcExtra {                 // int32 plane fields instead of p16 + side tab
     int64_t y_off = 0, ny_glob = -1;
     const uint32_t* i32_flag = nullptr;     // device word: use the int32 fields only when it is non-zero (nullptr: always)
 };
+struct DcDecide {                // a probe launch turns its counters into the tier decision itself (last workgroup)
+    int stage = 0; bool dense_tried = false, handoff = false, window_choice = false;
+};
 // Longer lines, larger grids (L > 2048, finf + (L + 2)^2 >= 2^(32 - B), 2^31 voxels or more): the marching sweeps with unbounded scans.
 DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny, int64_t nz, int64_t ny_full = -1) {
     DcGeometry g{};
@@ -414,11 +417,13 @@ bool far_geometry_ok(const sdfgpu_context* h, int stage, int64_t nx, int64_t ny,
     return envelope_dc_geometry(h, stage, nx, ny, nz, ny_full).ok;
 }
 
+int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff, bool window_choice);
+
 // KE2 / KE3: exact far-field sweeps.  guard: run iff (*guard != 0) != guard_invert (nullptr: always).
 int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int32_t* d_side_in, void* d_out,
                     int32_t* d_side_out, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
                     uint32_t* d_maxdsq, const uint32_t* guard, hipStream_t s, int guard_invert = 0,
-                    uint32_t* probe_out = nullptr, const DcExtra* ex = nullptr) {
+                    uint32_t* probe_out = nullptr, const DcExtra* ex = nullptr, const DcDecide* dec = nullptr) {
     (void)d_maxdsq;
     const DcGeometry g = envelope_dc_geometry(h, stage, nx, ny, nz, ex ? ex->ny_glob : -1);
     if (!g.ok) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "shape not taken by the far-field kernel (internal: callers check the geometry first)");
@@ -451,9 +456,14 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.probe_thr = h->far_thr[stage - 2];
             a.probe_thr2 = stage == 2 ? h->mid_thr_y : 0;
             a.probe_out = probe_out;
+            if (dec) {
+                a.decide_small = h->d_small; a.decide_stage = dec->stage; a.decide_dense_tried = dec->dense_tried ? 1 : 0;
+                a.decide_force = h->force_env; a.decide_den = h->far_den[dec->stage]; a.decide_handoff = dec->handoff ? 1 : 0;
+                a.decide_mid_den = (dec->stage == 0 && dec->window_choice) ? h->mid_den_y : 0;
+            }
             ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
             while (ntiles > 0 && (ntiles - 1) * a.probe_stride + ((ntiles - 1) * 7) % a.probe_stride >= all) --ntiles;
-            if (ntiles == 0) return SDFGPU_OK;
+            if (ntiles == 0) return dec ? launch_decide(h, dec->stage, dec->dense_tried, s, dec->handoff, dec->window_choice) : SDFGPU_OK;
         }
         // vector loads: 4 consecutive lines per load, whole tiles, aligned rows
         auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) % n) == 0; };
@@ -476,7 +486,8 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
     }
 }
 
-int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff = false, bool window_choice = false) {
+int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff = false, bool window_choice = false);
+int launch_decide(sdfgpu_handle h, int stage, bool dense_tried, hipStream_t s, bool handoff, bool window_choice) {
     hipLaunchKernelGGL(k_decide_tier, dim3(1), dim3(1), 0, s, h->d_small, stage, dense_tried ? 1 : 0, h->force_env,
                        1, h->far_den[stage], handoff ? 1 : 0, (stage == 0 && window_choice) ? h->mid_den_y : 0);
     HIP_TRY(h, hipGetLastError());
@@ -733,7 +744,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // ordered by the stream; a build issued on ANOTHER stream first waits for the previous build's last kernel.
     if (h->have_result && s != h->last_stream) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
     if (!h->small_clean) {
-        HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+        HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 128, s));
         HIP_TRY(h, hipMemsetAsync(h->d_slots, 0, (size_t)kSlots * kSlotWords * 4, s));   // a failed build may have left maxima behind
     }
     h->small_clean = false;
@@ -819,10 +830,12 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     const bool window_choice = select && (nz % 4) == 0 && h->march_h != 8 && h->mid_den_y > 0;
     auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff, window_choice); };   // probe counters -> guard words
     if (select) {
-        if (h->force_env < 0)
+        // probe + decision in one launch (the probe's last workgroup decides); a forced tier needs no probe
+        DcDecide dy; dy.stage = 0; dy.dense_tried = dense; dy.handoff = handoff; dy.window_choice = window_choice;
+        if (h->force_env < 0) {
             if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
-                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12)) return rc;
-        if (int rc = decide(0)) return rc;
+                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12, nullptr, &dy)) return rc;
+        } else if (int rc = decide(0)) return rc;
         // marching y sweep: general pipeline needed AND near-field; the probe also picks the window (radius 3 / radius 8)
         h->guard = h->d_small + 8;
         if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s, window_choice ? 3 : 0)) return rc;
@@ -854,11 +867,12 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (!envelope || fused) h->far_y = nullptr;
     else h->far_y = h->d_small + 4;             // (K3/16 raises far_y + 1 = far_x)
     if (select) {
-        if (h->force_env < 0)
+        DcDecide dx; dx.stage = 1; dx.dense_tried = dense; dx.handoff = handoff; dx.window_choice = window_choice;
+        if (h->force_env < 0) {
             if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
                                          nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12,
-                                         handoff ? &hand3 : nullptr)) return rc;
-        if (int rc = decide(1)) return rc;
+                                         handoff ? &hand3 : nullptr, &dx)) return rc;
+        } else if (int rc = decide(1)) return rc;
         h->guard = h->d_small + 10;
         if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
                                       0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
@@ -1248,15 +1262,16 @@ int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int6
     }
     // K1, then the y sweep picked on the device: probe -> decide -> marching (bounded scan) / envelope, int32 output
     if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 128, s));
     h->small_clean = false;
     if (int rc = launch_sweep_z(h, d_filled, nullptr, 0, 0, 0, nxs, ny, nz, (int16_t*)h->zfield.ptr, s)) return rc;
     DcExtra ex;
     ex.out_i32 = d_plane_dsq;
-    if (h->force_env < 0)
+    DcDecide dy; dy.stage = 0;
+    if (h->force_env < 0) {
         if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nxs, ny, nz, 1.0, 0,
-                                     h->d_small, nullptr, s, 0, h->d_small + 12, &ex)) return rc;
-    if (int rc = launch_decide(h, 0, false, s)) return rc;
+                                     h->d_small, nullptr, s, 0, h->d_small + 12, &ex, &dy)) return rc;
+    } else if (int rc = launch_decide(h, 0, false, s)) return rc;
     h->guard = h->d_small + 8;
     h->far_y = h->d_small + 4;
     h->scan_y = kScanExpectNear;
@@ -1267,7 +1282,7 @@ int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int6
     if (int rc2 = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nxs, ny, nz, 1.0, 0,
                                   h->d_small, h->d_small + 4, s, 0, nullptr, &ex)) return rc2;
     if (d_far) HIP_TRY(h, hipMemcpyAsync(d_far, h->d_small + 4, 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 128, s));
     h->small_clean = true;
     return SDFGPU_OK;
 }
@@ -1296,14 +1311,15 @@ int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int
                                     d_maxdsq, nullptr, s, y_global, ny_global)) return rc;
         return h->defer_fold ? SDFGPU_OK : fold_slots(h, d_maxdsq, s);
     }
-    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 128, s));
     h->small_clean = false;
     DcExtra ex;
     ex.in_i32 = d_plane_dsq; ex.y_off = y_global; ex.ny_glob = ny_global;
-    if (h->force_env < 0)
+    DcDecide dx; dx.stage = 1;
+    if (h->force_env < 0) {
         if (int rc = launch_envelope(h, 3, nullptr, nullptr, d_out_sdf, nullptr, nx, nys, nz, resolution, add_virtual_border,
-                                     h->d_small, nullptr, s, 0, h->d_small + 12, &ex)) return rc;
-    if (int rc = launch_decide(h, 1, false, s)) return rc;
+                                     h->d_small, nullptr, s, 0, h->d_small + 12, &ex, &dx)) return rc;
+    } else if (int rc = launch_decide(h, 1, false, s)) return rc;
     h->guard = h->d_small + 10;
     int rc = launch_sweep_x(h, d_plane_dsq, d_out_sdf, 0, nx, 0, nys, nz, 0, 0, 0, nx, resolution, add_virtual_border,
                             d_maxdsq, nullptr, s, y_global, ny_global, kScanExpectNear, h->d_small + 5);
@@ -1312,7 +1328,7 @@ int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int
     if (int rc2 = launch_envelope(h, 3, nullptr, nullptr, d_out_sdf, nullptr, nx, nys, nz, resolution, add_virtual_border,
                                   h->d_small, h->d_small + 5, s, 0, nullptr, &ex)) return rc2;
     if (!h->defer_fold) if (int rc3 = fold_slots(h, d_maxdsq, s)) return rc3;
-    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 64, s));
+    HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 128, s));
     h->small_clean = true;
     return SDFGPU_OK;
 }

@@ -88,6 +88,10 @@ struct EnvDcArgs {
     int probe_thr;
     int probe_thr2;           // second, lower threshold (y probe: radius-8 vs radius-3 marching window), counted into probe_out[-1]
     uint32_t* probe_out;
+    // probe launches also turn their counters into the tier decision (the last workgroup to finish does what k_decide_tier
+    // does): decide_small = the status block, nullptr = no decision here
+    uint32_t* decide_small;
+    int decide_stage, decide_dense_tried, decide_force, decide_den, decide_handoff, decide_mid_den;
     // both axes far-field: when *i32_flag != 0 the y sweep hands its result to the x sweep as an exact int32 plane field
     // (out_i32 / in_i32, the side-table buffer used whole) instead of p16 + side table; nullptr = the pointers alone decide
     const uint32_t* i32_flag;
@@ -144,16 +148,55 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 #define DC_STAMP(k) do {} while (0)
 #endif
 
+// Device-side tier selection for one axis (stage 0 = y, 1 = x), one thread.  small = the context's status block:
+// [3] uncertified (dense tier could not decide the scene), [4] / [5] "y / x sweep belongs to the far-field kernel" (also
+// raised by a marching sweep that hits its scan bound), [8 + 2 stage] guard word of the marching sweep, [12] / [13] the
+// probe's counters.  The marching sweep runs iff the general pipeline is needed at all and the probe found the axis
+// near-field; otherwise the far-field flag is raised and the (flag-guarded) far-field kernel does the sweep.
+__device__ __forceinline__ void decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den,
+                                            int handoff, int mid_den) {
+    auto ld = [&](int i) -> uint32_t { return __hip_atomic_load(small + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const bool active = dense_tried ? ld(3) != 0u : true;
+    const uint32_t far_n = ld(12), tot = ld(13), mid_n = ld(11);
+    // far when more than num / den of the sampled voxels need a long scan (64-bit: counts are < 2^24, factors small)
+    bool far = force >= 0 ? force != 0 : (uint64_t)far_n * (uint64_t)den > (uint64_t)tot * (uint64_t)num;
+    if (stage == 1 && ld(7) != 0u) far = true;                  // the y probe chose the far-field pair with int32 hand-off
+    // y sweep, near-field: radius-8 register windows when more than 1 / mid_den of the voxels are beyond the radius-3 one
+    const bool wide = stage == 0 && mid_den > 0 && (uint64_t)mid_n * (uint64_t)mid_den > (uint64_t)tot;
+    small[8 + 2 * stage] = (active && !far && !wide) ? 1u : 0u;
+    if (stage == 0) small[9] = (active && !far && wide) ? 1u : 0u;
+    if (active && far) small[4 + stage] = 1u;
+    if (stage == 0 && active && far && handoff) small[7] = 1u;
+    small[11] = 0u;
+    small[12] = 0u;
+    small[13] = 0u;
+    small[14 + stage] = tot ? (far_n * 1000u) / tot : 0u;         // per-mille of far voxels in the sample (diagnostics)
+}
+__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff,
+                              int mid_den) {
+    decide_tier(small, stage, dense_tried, force, num, den, handoff, mid_den);
+}
+// ... called by the last workgroup of a probe launch (every workgroup passes here exactly once, early exits included)
+__device__ __forceinline__ void probe_done(const EnvDcArgs& a) {
+    if (!a.decide_small || threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(a.decide_small + 16, 1u) == gridDim.x - 1u) {
+        __threadfence();
+        decide_tier(a.decide_small, a.decide_stage, a.decide_dense_tried, a.decide_force, 1, a.decide_den, a.decide_handoff, a.decide_mid_den);
+        a.decide_small[16] = 0u;
+    }
+}
+
 template <int STAGE, bool VEC>
 __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     constexpr int NL = kDcLines, NT = 256;
     extern __shared__ __attribute__((aligned(16))) uint32_t dc_smem[];
     if (a.guard) {
         const uint32_t gv = *a.guard;
-        if ((gv != 0u) == (a.guard_invert != 0)) return;
+        if ((gv != 0u) == (a.guard_invert != 0)) { probe_done(a); return; }
     }
     const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
-    if (a.probe_stride > 0 && a.i32_flag && i32) return;       // the x tier is already decided: no probe
+    if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
     const int L = a.L, B = a.B, pitch = a.pitch, M = a.M, h = a.h;
     const int MA = (L + 63) >> 6;
     const uint32_t mask = (1u << B) - 1u, finf = a.finf;
@@ -457,6 +500,20 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             }
             __syncthreads();
             DC_STAMP(1);
+            if (probe) {
+                // the probe's statistic from the coarse positions alone (64 i of every line: an unbiased sample of the voxels)
+                if (t < NL * imin(MA, 16)) {
+                    const int i = t >> 4, p = 64 * i;
+                    const uint32_t d = (args[(8 * i) * NL + (t & 15)] >> B) - __umul24((uint32_t)p, (uint32_t)(2 * h - p));
+                    const int D = d >= finf ? kInf32 : (int)d;
+                    if ((t & 15) < nvalid) {
+                        probe_tot += D != 0 ? 1 : 0;
+                        probe_far += D >= a.probe_thr ? 1 : 0;
+                        probe_mid += D >= a.probe_thr2 ? 1 : 0;
+                    }
+                }
+                return;                                     // (from the pass; the counters are summed below)
+            }
             // ---- level B: positions 64 i + 8 k inside interval i; lane = (line, interval[, share of the candidates]) ------------
             {
                 int Hs = 1;                                     // lanes per interval (16 slots per line)
@@ -483,6 +540,10 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             DC_STAMP(2);
         }
 
+        if (probe) {                            // (a tile without sites: every sampled voxel is at "infinity")
+            if (t < NL * imin(MA, 16) && (t & 15) < nvalid) { probe_tot += 1; probe_far += 1; probe_mid += 1; }
+            return;
+        }
         // ---- level C: lane = (line, chunk of 8 positions); finish and store ---------------------------------------------------
         {
             const uint32_t* kl = keys + lineT * pitch;
@@ -640,6 +701,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         if ((t & 63) == 0) { atomicAdd(&misc[18], (uint32_t)probe_far); atomicAdd(&misc[19], (uint32_t)probe_tot); atomicAdd(&misc[20], (uint32_t)probe_mid); }
         __syncthreads();
         if (t == 0) { atomicAdd(a.probe_out, misc[18]); atomicAdd(a.probe_out + 1, misc[19]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, misc[20]); }
+        probe_done(a);
         return;
     }
     if constexpr (STAGE == 3) {
@@ -650,30 +712,6 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
         if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * (NT / 64) + (t >> 6), mxF, mxQ);
     }
-}
-
-// Device-side tier selection for one axis (stage 0 = y, 1 = x), one thread.  small = the context's status block:
-// [3] uncertified (dense tier could not decide the scene), [4] / [5] "y / x sweep belongs to the envelope kernel" (also
-// raised by a marching sweep that hits its scan bound), [8 + 2 stage] guard word of the marching sweep, [12] / [13] the
-// probe's counters.  The marching sweep runs iff the general pipeline is needed at all and the probe found the axis
-// near-field; otherwise the envelope flag is raised and the (flag-guarded) envelope kernel does the sweep.
-__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff,
-                              int mid_den) {
-    const bool active = dense_tried ? small[3] != 0u : true;
-    const uint32_t far_n = small[12], tot = small[13], mid_n = small[11];
-    // far when more than num / den of the sampled voxels need a long scan (64-bit: counts are < 2^24, factors small)
-    bool far = force >= 0 ? force != 0 : (uint64_t)far_n * (uint64_t)den > (uint64_t)tot * (uint64_t)num;
-    if (stage == 1 && small[7] != 0u) far = true;               // the y probe chose the far-field pair with int32 hand-off
-    // y sweep, near-field: radius-8 register windows when more than 1 / mid_den of the voxels are beyond the radius-3 one
-    const bool wide = stage == 0 && mid_den > 0 && (uint64_t)mid_n * (uint64_t)mid_den > (uint64_t)tot;
-    small[8 + 2 * stage] = (active && !far && !wide) ? 1u : 0u;
-    if (stage == 0) small[9] = (active && !far && wide) ? 1u : 0u;
-    if (active && far) small[4 + stage] = 1u;
-    if (stage == 0 && active && far && handoff) small[7] = 1u;
-    small[11] = 0u;
-    small[12] = 0u;
-    small[13] = 0u;
-    small[14 + stage] = tot ? (far_n * 1000u) / tot : 0u;         // per-mille of far voxels in the sample (diagnostics)
 }
 
 }  // namespace sdfgpu
