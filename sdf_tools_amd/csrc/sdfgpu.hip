@@ -98,7 +98,6 @@ struct sdfgpu_context {
     int far_den[2] = {5, 24};
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
-    bool dc_lds_attr[4] = {false, false, false, false};
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
@@ -468,19 +467,28 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         // vector loads: 4 consecutive lines per load, whole tiles, aligned rows
         auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) % n) == 0; };
         const bool vec = (nz % 4) == 0 && (a.group_lines % NL) == 0 && al(d_in16, 8) && al(d_side_in, 16) && al(a.in_i32, 16);
-        const size_t lds = envelope_dc_lds_bytes(a.L);
-        const void* fn = stage == 2 ? (vec ? (const void*)k_envelope_dc<2, true> : (const void*)k_envelope_dc<2, false>)
-                                    : (vec ? (const void*)k_envelope_dc<3, true> : (const void*)k_envelope_dc<3, false>);
-        const int fi = (stage - 2) * 2 + (vec ? 1 : 0);
-        if (lds > 64 * 1024 && !h->dc_lds_attr[fi]) {
-            HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            h->dc_lds_attr[fi] = true;
+#ifdef SDFGPU_DEBUG_HOOKS
+        const size_t lds = envelope_dc_lds_bytes(a.L, NL) + (size_t)(h->dc_debug >> 8) * 1024;  // profiling builds: LDS padding = lower occupancy
+#else
+        const size_t lds = envelope_dc_lds_bytes(a.L, NL);
+#endif
+        // (the kernel is a template over lines per tile and lanes; measured at 512^3: 8-line tiles -- 20 KB of LDS, 7 - 8
+        //  workgroups per CU -- with 128 or 256 lanes are 12 - 25 % slower than 16 lines x 256 lanes, 16 lines x 512 lanes
+        //  +-5 %, 32 lines x 512 lanes +-3 %; 2 instead of 4 workgroups per CU is 1.55x slower)
+        constexpr int NT = 256;
+        auto launch = [&](auto kern) -> int {
+            if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3((unsigned)NT), lds, s, a);
+            return SDFGPU_OK;
+        };
+        int rc;
+        switch ((stage == 3 ? 1 : 0) + (vec ? 2 : 0)) {
+            case 0: rc = launch(k_envelope_dc<2, false, 256, 16>); break;
+            case 1: rc = launch(k_envelope_dc<3, false, 256, 16>); break;
+            case 2: rc = launch(k_envelope_dc<2, true, 256, 16>); break;
+            default: rc = launch(k_envelope_dc<3, true, 256, 16>); break;
         }
-        const dim3 grid((unsigned)ntiles), block(256);
-        if (stage == 2 && vec) hipLaunchKernelGGL((k_envelope_dc<2, true>), grid, block, lds, s, a);
-        else if (stage == 2) hipLaunchKernelGGL((k_envelope_dc<2, false>), grid, block, lds, s, a);
-        else if (vec) hipLaunchKernelGGL((k_envelope_dc<3, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((k_envelope_dc<3, false>), grid, block, lds, s, a);
+        if (rc) return rc;
         HIP_TRY(h, hipGetLastError());
         return SDFGPU_OK;
     }

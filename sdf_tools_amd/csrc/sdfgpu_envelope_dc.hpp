@@ -33,7 +33,9 @@
 //     shapes without 4-element alignment use scalar loads (template parameter VEC).
 // Measured and not kept (512^3, two-box scene and Bernoulli 1 % .. 0.01 %; tools/ff_check.sh, profiling builds with
 // -DSDFGPU_DEBUG_HOOKS / -DSDFGPU_PHASE_CLOCKS):
-//   * 512 lanes per tile inside 64 VGPRs (8 waves per SIMD): +-5 % either way -- not latency-bound;
+//   * 512 lanes per tile inside 64 VGPRs (8 waves per SIMD): +-5 % either way; 8-line tiles (20 KB of LDS, 7 - 8 workgroups
+//     per CU) with 128 or 256 lanes: 12 - 25 % slower; padding the LDS so that only 2 workgroups fit a CU: 1.55x slower --
+//     4 workgroups of 4 waves per CU is a plateau;
 //   * 32-line tiles (128-byte row segments, 512 lanes): +-3 %, and twice the filled voxels per tile push Bernoulli 3 % into the
 //     second pass; the bare memory pattern (tools/probe/tile_copy_probe.hip) is 0.27 ms with 16-line and 0.22 ms with 32-line
 //     tiles against 0.17 ms for a linear copy of the same 8 B/voxel;
@@ -119,13 +121,13 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
 }
 
 
-constexpr int kDcLines = 16;
-constexpr int kDcBatch = 8;          // staging: row loads in flight per lane (a 512-line is staged from ONE round of loads)
+constexpr int kDcLines = 16;          // lines per tile (the kernel is a template over 8 / 16 lines and 128 / 256 / 512 lanes: 16 x 256 is the measured optimum)
+constexpr int NB = 8;          // staging: row loads in flight per lane (a 512-line is staged from ONE round of loads)
 
 inline int envelope_dc_pitch(int L) { return ((L + 63) / 64) * 64 + 2; }        // >= L + 2, == 2 mod 64, even (8-byte pairs)
-inline size_t envelope_dc_lds_bytes(int L) {
+inline size_t envelope_dc_lds_bytes(int L, int lines = kDcLines) {
     const int M = (L + 7) / 8;
-    return ((size_t)kDcLines * envelope_dc_pitch(L) + (size_t)(M + 2) * kDcLines + 32 + kDcLocalFilled) * 4;
+    return ((size_t)lines * envelope_dc_pitch(L) + (size_t)(M + 2) * lines + 48 + kDcLocalFilled) * 4;
 }
 
 // a * b + c on the low 24 bits of a and b (signed), low 32 bits of the result: one full-rate instruction.  (Written as
@@ -187,9 +189,18 @@ __device__ __forceinline__ void probe_done(const EnvDcArgs& a) {
     }
 }
 
-template <int STAGE, bool VEC>
-__global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
-    constexpr int NL = kDcLines, NT = 256;
+// NL lines per tile, NT lanes: S = NT / NL lanes ("slots") per line.  The kernel is sensitive to how many WORKGROUPS a CU
+// holds (their phases interleave; 2 instead of 4 per CU is 1.55x slower), and that number is set by the LDS footprint:
+// 16 lines x 512 positions x 4 B of keys = 39 KB -> 4 per CU; 8 lines -> 20 KB -> 7 - 8 per CU.
+template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines>
+__global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envelope_dc(const EnvDcArgs a) {
+    constexpr int S = NT / NL;              // lanes per line
+    constexpr int LPR = NL / 4;             // staging: lanes per row (4 lines each)
+    constexpr int LPR_SH = NL == 16 ? 2 : 1;
+    constexpr int PP = NT / LPR;            // rows staged per load round of the workgroup
+    constexpr int NB = 512 / PP > 0 ? 512 / PP : 1;         // loads in flight per lane (a 512-line is staged from ONE round)
+    constexpr int NW = NT / 64;             // waves
+    static_assert(NL == 8 || NL == 16, "tile of 8 or 16 lines");
     extern __shared__ __attribute__((aligned(16))) uint32_t dc_smem[];
     if (a.guard) {
         const uint32_t gv = *a.guard;
@@ -204,8 +215,8 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     auto ncof = [&](int p) -> int { return (int)((uint32_t)(h - p) << (B + 1)); };
     uint32_t* const keys = dc_smem;                             // [16][pitch]
     uint32_t* const args = keys + NL * pitch;                   // [M + 2][16]  best value (distance << B | argmin) of coarse position 8 i
-    uint32_t* const misc = args + (M + 2) * NL;                 // [0..3] span lo per wave, [4..7] span hi, [8..11] smallest site value, [16] filled voxels listed, [17] second pass wanted, [18..20] probe
-    uint32_t* const flist = misc + 32;                          // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
+    uint32_t* const misc = args + (M + 2) * NL;                 // per wave: [0..7] span lo, [8..15] span hi, [16..23] smallest site value; [24] filled voxels listed, [25] second pass wanted, [26..28] probe
+    uint32_t* const flist = misc + 48;                          // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
     const int t = threadIdx.x;
 #ifdef SDFGPU_PHASE_CLOCKS
     unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
         return (int)b;
     };
-    const int lineT = t & (NL - 1), slotT = t >> 4;             // (line, slot) mapping of levels B and C
+    const int lineT = t & (NL - 1), slotT = t / NL;             // (line, slot) mapping of levels B and C
     const bool lineT_ok = lineT < nvalid;
     const int byz = byz_of(lineT);
 
@@ -304,12 +315,12 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
     auto run_pass = [&](auto cls_tag) {
         constexpr int cls = decltype(cls_tag)::value;
         for (int i = t; i < (M + 2) * NL; i += NT) args[i] = 0xFFFFFFFFu;
-        if (cls == 0 && t < 32) misc[t] = 0u;
+        if (cls == 0 && t < 48) misc[t] = 0u;
 
         // ---- stage the tile: rows -> keys ------------------------------------------------------------------------------------
-        // A lane reads 4 lines x 1 position per load (VEC: one 8 / 16-byte load), kDcBatch loads in flight, and writes the
+        // A lane reads 4 lines x 1 position per load (VEC: one 8 / 16-byte load), NB loads in flight, and writes the
         // four keys.
-        const int sub = t & 3, r = t >> 2;
+        const int sub = t & (LPR - 1), r = t / LPR;
         uint32_t* const kb = keys + (4 * sub) * pitch + r;
         int lsel[4];
 #pragma unroll
@@ -317,12 +328,12 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         const uint32_t off_r = (uint32_t)r * ls + 4u * sub, off_last = (uint32_t)(L - 1) * ls + 4u * sub;
         int lo_w = 0x7fffffff, hi_w = -1;                       // span seen by this wave (uniform)
         uint32_t mt = 0xFFFFFFFFu;                              // smallest site value seen by this lane
-        for (int pb = 0; pb < L; pb += 64 * kDcBatch) {
-            int sv[kDcBatch][4];
+        for (int pb = 0; pb < L; pb += PP * NB) {
+            int sv[NB][4];
 #pragma unroll
-            for (int it = 0; it < kDcBatch; ++it) {
+            for (int it = 0; it < NB; ++it) {
                 // (rows past the end of the line re-read the last row; their keys are not written)
-                const uint32_t off = (pb + 64 * it + r < L) ? off_r + (uint32_t)(pb + 64 * it) * ls : off_last;
+                const uint32_t off = (pb + PP * it + r < L) ? off_r + (uint32_t)(pb + PP * it) * ls : off_last;
                 if constexpr (VEC) {
                     if (STAGE == 3 && in32) {
                         const int4 e = *reinterpret_cast<const int4*>(in32 + off);
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             if constexpr (VEC) {
                 if (!(STAGE == 3 && in32)) {
 #pragma unroll
-                    for (int it = 0; it < kDcBatch; ++it) {
+                    for (int it = 0; it < NB; ++it) {
                         const uint32_t rx = (uint32_t)sv[it][0], ry = (uint32_t)sv[it][1];
                         sv[it][0] = (int)(short)(rx & 0xffffu); sv[it][1] = (int)rx >> 16;
                         sv[it][2] = (int)(short)(ry & 0xffffu); sv[it][3] = (int)ry >> 16;
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                             const uint32_t m0 = (rx ^ (n0 * 0xFFFFu)) + 0x00010001u + n0;
                             const uint32_t m1 = (ry ^ (n1 * 0xFFFFu)) + 0x00010001u + n1;
                             if (((m0 | m1) & 0x80008000u) != 0u) {
-                                const uint32_t off = (pb + 64 * it + r < L) ? off_r + (uint32_t)(pb + 64 * it) * ls : off_last;
+                                const uint32_t off = (pb + PP * it + r < L) ? off_r + (uint32_t)(pb + PP * it) * ls : off_last;
                                 const int4 e = *reinterpret_cast<const int4*>(side_in + off);
                                 sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
                             }
@@ -368,8 +379,8 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                 }
             }
 #pragma unroll
-            for (int it = 0; it < kDcBatch; ++it) {
-                const int p = pb + 64 * it + r;
+            for (int it = 0; it < NB; ++it) {
+                const int p = pb + PP * it + r;
                 const bool inl = p < L;
                 const int pc = p - h;
                 const uint32_t cpos = (mad_i24(pc, pc, (uint32_t)(h * h)) << B) | (uint32_t)p;
@@ -388,15 +399,15 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                 }
                 if (inl) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) kb[k * pitch + (pb + 64 * it)] = (F[k] << B) + cpos;
+                    for (int k = 0; k < 4; ++k) kb[k * pitch + (pb + PP * it)] = (F[k] << B) + cpos;
                 }
                 const uint32_t fmin4 = inl ? umin(umin(F[0], F[1]), umin(F[2], F[3])) : finf;
                 mt = umin(mt, fmin4);
                 const uint64_t bal = __ballot(fmin4 < finf);
                 if (bal) {                                      // (wave-uniform: scalar code)
-                    const int pw = pb + 64 * it + ((t >> 6) << 4);
-                    lo_w = imin(lo_w, pw + ((__ffsll((unsigned long long)bal) - 1) >> 2));
-                    hi_w = imax(hi_w, pw + ((63 - __clzll((long long)bal)) >> 2));
+                    const int pw = pb + PP * it + (t >> 6) * (64 / LPR);
+                    lo_w = imin(lo_w, pw + ((__ffsll((unsigned long long)bal) - 1) >> LPR_SH));
+                    hi_w = imax(hi_w, pw + ((63 - __clzll((long long)bal)) >> LPR_SH));
                 }
                 if (cls == 0 && neg < 0 && inl) {               // filled voxels (rare in the scenes this kernel serves): list them
 #pragma unroll
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                         if (s1 < 0 && 4 * sub + k < nvalid) {
                             uint32_t S = (uint32_t)(-s1);       // squared distance to the nearest free voxel so far
                             if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
-                            const uint32_t e = atomicAdd(&misc[16], 1u);
+                            const uint32_t e = atomicAdd(&misc[24], 1u);
                             if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | umin(S, 255u);
                         }
                     }
@@ -414,16 +425,17 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mt = umin(mt, (uint32_t)__shfl_xor((int)mt, off));
-        if ((t & 63) == 0) { misc[t >> 6] = (uint32_t)lo_w; misc[4 + (t >> 6)] = (uint32_t)hi_w; misc[8 + (t >> 6)] = mt; }
+        if ((t & 63) == 0) { misc[t >> 6] = (uint32_t)lo_w; misc[8 + (t >> 6)] = (uint32_t)hi_w; misc[16 + (t >> 6)] = mt; }
         if (t < 2 * NL) {                                       // two sentinels behind every line (pairs are read 8-byte aligned)
             const int line = t >> 1, q = L + (t & 1), qc = q - h;
             keys[line * pitch + q] = ((finf + (uint32_t)(qc * qc) + (uint32_t)(h * h)) << B) | ((uint32_t)q & mask);
         }
         __syncthreads();
         DC_STAMP(0);
-        const int lo_t = imin(imin((int)misc[0], (int)misc[1]), imin((int)misc[2], (int)misc[3]));
-        const int hi_t = imax(imax((int)misc[4], (int)misc[5]), imax((int)misc[6], (int)misc[7]));
-        const uint32_t mt_t = umin(umin(misc[8], misc[9]), umin(misc[10], misc[11]));
+        int lo_t = 0x7fffffff, hi_t = -1;
+        uint32_t mt_t = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { lo_t = imin(lo_t, (int)misc[w]); hi_t = imax(hi_t, (int)misc[8 + w]); mt_t = umin(mt_t, misc[16 + w]); }
 #ifdef SDFGPU_DEBUG_HOOKS
         const bool act = lo_t <= hi_t && !(a.dbg & 1);          // profiling builds: dbg bit 0 = no search (wrong results), bit 1 = no fp64 finish, bit 2 = no stores
 #else
@@ -432,20 +444,20 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
 
         if (act) {
             // ---- level A: positions 64 i ---------------------------------------------------------------------------------------
-            // Two forms, chosen per line (= per 16-lane row): (a) one position per lane group over a range clipped by the
+            // Two forms, chosen per wave (= 64 / S whole lines): (a) one position per lane group over a range clipped by the
             // distance bound -- a few candidates per position wherever the line runs near sites or far from ALL of them;
             // (b) when the clipped ranges stay long (objects at different distances: the bound v - m is then large), the 16
             // lanes split the span and every lane takes its share of the candidates for 8 positions at once.
             {
-                const int lineA = t >> 4, u = t & 15;
+                const int lineA = t / S, u = t % S;
                 const uint32_t* klA = keys + lineA * pitch;
                 const int span_pairs = (hi_t - (lo_t & ~1)) / 2 + 1;
                 int G = 1;                                      // form (a): lanes per position
-                while (2 * G * MA <= 16) G *= 2;
+                while (2 * G * MA <= S) G *= 2;
                 const int v = u & (G - 1), i1 = u / G;
                 int lo = lo_t, hi = hi_t, nc1 = 0;
                 bool clip = false;
-                if (MA <= 16) {
+                if (MA <= S) {
                     int prs = 0;
                     if (i1 < MA) {
                         const int p = 64 * i1;
@@ -461,13 +473,9 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                         }
                         prs = (hi - (lo & ~1)) / 2 + 1;
                     }
-                    int rmax = prs;                             // longest clipped range of the line (row maximum)
-                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x128, 0xF, 0xF, true));      // row_ror:8
-                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x124, 0xF, 0xF, true));      // row_ror:4
-                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x122, 0xF, 0xF, true));      // row_ror:2
-                    rmax = imax(rmax, __builtin_amdgcn_mov_dpp(rmax, 0x121, 0xF, 0xF, true));      // row_ror:1
-                    // cost per lane: (a) ceil(rmax / G) trips of ~8 instructions, (b) ceil(span_pairs / 16) trips of ~29 per 8 positions
-                    clip = ((rmax + G - 1) / G) * 8 <= ((span_pairs + 15) / 16) * 29 * ((MA + 7) / 8);
+                    // cost per lane: (a) ceil(prs / G) trips of ~8 instructions, (b) ceil(span_pairs / S) trips of ~29 per 8 positions;
+                    // decided per wave (whole lines: 64 / S of them)
+                    clip = __all(((prs + G - 1) / G) * 8 <= ((span_pairs + S - 1) / S) * 29 * ((MA + 7) / 8));
                 }
                 if (clip) {
                     if (i1 < MA) {
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
                             nc[k] = ncof(64 * imin(g + k, MA - 1));
                             best[k] = 0xFFFFFFFFu;
                         }
-                        scan8(klA, (lo_t & ~1) + 2 * u, hi_t, 32, nc, best);
+                        scan8(klA, (lo_t & ~1) + 2 * u, hi_t, 2 * S, nc, best);
 #pragma unroll
                         for (int k = 0; k < 8; ++k)
                             if (g + k < MA) atomicMin(&args[(8 * (g + k)) * NL + lineA], best[k]);
@@ -502,11 +510,11 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             DC_STAMP(1);
             if (probe) {
                 // the probe's statistic from the coarse positions alone (64 i of every line: an unbiased sample of the voxels)
-                if (t < NL * imin(MA, 16)) {
-                    const int i = t >> 4, p = 64 * i;
-                    const uint32_t d = (args[(8 * i) * NL + (t & 15)] >> B) - __umul24((uint32_t)p, (uint32_t)(2 * h - p));
+                if (slotT < imin(MA, S)) {
+                    const int i = slotT, p = 64 * i;
+                    const uint32_t d = (args[(8 * i) * NL + lineT] >> B) - __umul24((uint32_t)p, (uint32_t)(2 * h - p));
                     const int D = d >= finf ? kInf32 : (int)d;
-                    if ((t & 15) < nvalid) {
+                    if (lineT < nvalid) {
                         probe_tot += D != 0 ? 1 : 0;
                         probe_far += D >= a.probe_thr ? 1 : 0;
                         probe_mid += D >= a.probe_thr2 ? 1 : 0;
@@ -516,10 +524,10 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             }
             // ---- level B: positions 64 i + 8 k inside interval i; lane = (line, interval[, share of the candidates]) ------------
             {
-                int Hs = 1;                                     // lanes per interval (16 slots per line)
-                while (2 * Hs * MA <= 16) Hs *= 2;
+                int Hs = 1;                                     // lanes per interval (S slots per line)
+                while (2 * Hs * MA <= S) Hs *= 2;
                 const uint32_t* kl = keys + lineT * pitch;
-                for (int i = slotT / Hs; i < MA; i += 16 / Hs) {
+                for (int i = slotT / Hs; i < MA; i += S / Hs) {
                     const int u = slotT % Hs;
                     const int lo = (int)(args[(8 * i) * NL + lineT] & mask);
                     const int hi = (i + 1 < MA) ? (int)(args[(8 * (i + 1)) * NL + lineT] & mask) : hi_t;
@@ -541,13 +549,13 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
         }
 
         if (probe) {                            // (a tile without sites: every sampled voxel is at "infinity")
-            if (t < NL * imin(MA, 16) && (t & 15) < nvalid) { probe_tot += 1; probe_far += 1; probe_mid += 1; }
+            if (slotT < imin(MA, S) && lineT < nvalid) { probe_tot += 1; probe_far += 1; probe_mid += 1; }
             return;
         }
         // ---- level C: lane = (line, chunk of 8 positions); finish and store ---------------------------------------------------
         {
             const uint32_t* kl = keys + lineT * pitch;
-            for (int i0 = 0; i0 < M; i0 += 16) {
+            for (int i0 = 0; i0 < M; i0 += S) {
                 const int i = i0 + slotT;
                 if (i >= M || !lineT_ok) continue;
                 const int p0 = 8 * i;
@@ -653,18 +661,18 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             }
             DC_STAMP(4);
             // Pass 0 finishes the tile's filled voxels itself when they are few and shallow (thin surfaces): one lane per
-            // listed voxel, exact local search along its line.  Deep or numerous filled voxels raise misc[17] and the second
+            // listed voxel, exact local search along its line.  Deep or numerous filled voxels raise misc[25] and the second
             // pass does the class properly.
             if (cls == 0 && !probe) {
-                const uint32_t nf = misc[16];
+                const uint32_t nf = misc[24];
                 if (nf > (uint32_t)kDcLocalFilled) {
-                    if (t == 0) misc[17] = 1u;
+                    if (t == 0) misc[25] = 1u;
                 } else {
                     for (uint32_t e = (uint32_t)t; e < nf; e += (uint32_t)NT) {
                         const uint32_t ent = flist[e];
                         const int fl = (int)(ent >> 24), p = (int)((ent >> 8) & 0xffffu);
                         int D1 = (int)(ent & 0xffu);
-                        if (D1 > kDcLocalMax) { misc[17] = 1u; continue; }
+                        if (D1 > kDcLocalMax) { misc[25] = 1u; continue; }
                         for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
                             if (p - d >= 0) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p - d), 0));
                             if (p + d < L) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p + d), 0));
@@ -675,15 +683,15 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             }
         }
         DC_STAMP(5);
-        __syncthreads();                        // keys / args are rebuilt by the next class; misc[17] is complete
+        __syncthreads();                        // keys / args are rebuilt by the next class; misc[25] is complete
         DC_STAMP(6);
     };
 
     run_pass(std::integral_constant<int, 0>{});
     // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose in-row
     // squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can only matter
-    // while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises misc[17] for the rest.
-    if (!probe && misc[17] != 0u) run_pass(std::integral_constant<int, 1>{});      // (block-uniform)
+    // while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises misc[25] for the rest.
+    if (!probe && misc[25] != 0u) run_pass(std::integral_constant<int, 1>{});      // (block-uniform)
 
 #ifdef SDFGPU_PHASE_CLOCKS
     if (a.clocks && (t & 63) == 0 && !probe && (blockIdx.x & 31u) == 5u) {     // a sample: same-address atomics serialise
@@ -698,9 +706,9 @@ __global__ __launch_bounds__(256, 4) void k_envelope_dc(const EnvDcArgs a) {
             probe_tot += __shfl_xor(probe_tot, off);
             probe_mid += __shfl_xor(probe_mid, off);
         }
-        if ((t & 63) == 0) { atomicAdd(&misc[18], (uint32_t)probe_far); atomicAdd(&misc[19], (uint32_t)probe_tot); atomicAdd(&misc[20], (uint32_t)probe_mid); }
+        if ((t & 63) == 0) { atomicAdd(&misc[26], (uint32_t)probe_far); atomicAdd(&misc[27], (uint32_t)probe_tot); atomicAdd(&misc[28], (uint32_t)probe_mid); }
         __syncthreads();
-        if (t == 0) { atomicAdd(a.probe_out, misc[18]); atomicAdd(a.probe_out + 1, misc[19]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, misc[20]); }
+        if (t == 0) { atomicAdd(a.probe_out, misc[26]); atomicAdd(a.probe_out + 1, misc[27]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, misc[28]); }
         probe_done(a);
         return;
     }

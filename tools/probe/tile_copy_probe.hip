@@ -10,7 +10,7 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); exit(1); } } while (0)
 
-template <int NLN, int NT, int STORE>      // STORE 0: chunk mapping (lane = line, slot of 8 positions); 1: row mapping
+template <int NLN, int NT, int STORE>      // STORE 0: chunk mapping (lane = line, slot of 8 positions); 1: row mapping; 2: chunk mapping, input TILE-MAJOR (a tile's rows contiguous)
 __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* __restrict__ out, int L, uint32_t ls, int xcd_order) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int pitch = L + 2;
@@ -21,7 +21,8 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
         tile = ((int64_t)(seq >> 2) * 8 + xcd) * 4 + (seq & 3u);
     }
     const int64_t base = tile * NLN;
-    const int* ip = in + base;
+    const int* ip = STORE == 2 ? in + tile * (int64_t)NLN * L : in + base;
+    const uint32_t lsi = STORE == 2 ? (uint32_t)NLN : ls;
     float* op = out + base;
     constexpr int LPR = NLN / 4;            // lanes per row
     constexpr int PP = NT / LPR;            // rows per load round
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
             const int p = pb + PP * it + r;
-            v[it] = *reinterpret_cast<const int4*>(ip + (uint32_t)(p < L ? p : L - 1) * ls + 4u * sub);
+            v[it] = *reinterpret_cast<const int4*>(ip + (uint32_t)(p < L ? p : L - 1) * lsi + 4u * sub);
         }
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
         }
     }
     __syncthreads();
-    if (STORE == 0) {
+    if (STORE == 0 || STORE == 2) {
         const int line = t % NLN, slot = t / NLN;
         constexpr int S = NT / NLN;
         for (int i0 = 0; i0 < L / 8; i0 += S) {
@@ -97,6 +98,7 @@ int main() {
         printf("xcd_order=%d\n", xcd);
         printf("  16 lines x 256 lanes, chunk stores: %.4f ms\n", run<16, 256, 0>(in, out, n, xcd));
         printf("  16 lines x 256 lanes, row stores:   %.4f ms\n", run<16, 256, 1>(in, out, n, xcd));
+        printf("  16 lines x 256 lanes, chunk stores, tile-major input: %.4f ms\n", run<16, 256, 2>(in, out, n, xcd));
         printf("  32 lines x 512 lanes, chunk stores: %.4f ms\n", run<32, 512, 0>(in, out, n, xcd));
         printf("  32 lines x 512 lanes, row stores:   %.4f ms\n", run<32, 512, 1>(in, out, n, xcd));
         printf("  32 lines x 256 lanes, row stores:   %.4f ms\n", run<32, 256, 1>(in, out, n, xcd));
