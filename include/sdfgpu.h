@@ -322,22 +322,19 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * when the shape allows, default; 0 = int32 plane field), "x16_voxels_per_lane" (4 or 8),
  * "x16_window" (2 or 3), "dense" (1 = try the bit-parallel dense kernel first, default; 0 = general
  * pipeline only), "envelope" (1 = bound the outward scans of K2 / K3 and redo far-field sweeps with the
- * lower-envelope kernels, default; 0 = unbounded scans), "envelope_mode" (force / clear the per-axis
- * "envelope kernel alone" policy state), "policy_reset" (forget what was learned from earlier builds),
+ * lower-envelope kernels, default; 0 = unbounded scans), "envelope_mode" (1 = the far-field kernel is the
+ * only sweep of both axes, no probes; 0 = back to the choice made on the device inside each build), "policy_reset"
+ * (forget what was learned from earlier builds: only whether the dense tier is worth trying is learned),
  * "dense_retry" (after an uncertified dense attempt, try the dense kernels again only every N-th build;
  * default 16, 0 = always try), "fixup" (the fix-up kernel behind the dense ball kernel for almost-dense
  * scenes, default 1), "fixup_mode" (force the policy state that launches it with the next build),
- * "march_window" / "x16_window" = 8 (force the radius-8 register windows of the y / x marching sweeps,
- * which the policy otherwise selects for mid-sparse scenes; "wide_y_from": the largest squared distance of the previous
- * build above which it does so for the y sweep, default 16), "dense_generic" (1 = shapes the tuned dense kernels do not take -- nz not 32 * 2^k, virtual border -- use their
+ * "march_window" / "x16_window" = 8 (force the radius-8 register windows of the y / x marching sweeps;
+ * the y window is otherwise chosen by the probe), "dense_generic" (1 = shapes the tuned dense kernels do not take -- nz not 32 * 2^k, virtual border -- use their
  * generic forms, default; 0 = such shapes skip the dense tier), "envelope_dc" (1 = the far-field kernel k_envelope_dc
- * redoes sweeps whose bounded scans did not decide every voxel, default; 0 = never: the marching scans stay unbounded), "tier_select" (1 = choose marching vs
- * envelope sweep per axis on the device inside each build from a probe of the sweep's input, default; 0 = learn
- * it from the previous build on the handle), "far_threshold_y" / "far_fraction_den_y" and "..._x" (an axis counts as
+ * redoes sweeps whose bounded scans did not decide every voxel, default; 0 = never: the marching scans stay unbounded), "far_threshold_y" / "far_fraction_den_y" and "..._x" (an axis counts as
  * far-field when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 5 for the
  * y sweep and 9, 24 for the x sweep), "mid_threshold_y" / "mid_fraction_den_y" (near-field y sweep: radius-8 marching
- * windows when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 24; den 0 = leave
- * the window to the host policy), "i32_handoff" (1 = when the y probe finds the scene far-field, the x sweep is the
+ * windows when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 24; den 0 = always the radius-3 window), "i32_handoff" (1 = when the y probe finds the scene far-field, the x sweep is the
  * far-field kernel too and takes an exact int32 plane field from the y sweep, default; 0 = 16-bit plane field + side
  * table between them and a probe of its own for the x axis).  Every option leaves the results exact: switches that
  * skip work for profiling ("dc_debug", "ball_variant") exist only in libraries built with -DSDFGPU_DEBUG_HOOKS and are

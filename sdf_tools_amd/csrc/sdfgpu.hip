@@ -83,7 +83,6 @@ struct sdfgpu_context {
     bool envelope_on = true;         // bound the outward scans and redo far-field sweeps with the envelope kernels
     bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
-    bool tier_select = true;         // pick marching vs envelope sweep per axis on the device, inside the build (probe + decide)
     int force_env = -1;              // -1 automatic, 1 = envelope kernels only (option "envelope_mode")
     // an axis is far-field when more than 1 / den of the probed voxels have d^2 >= thr.  Per axis, from the measured
     // break-even of the two sweeps at 512^3 (tools/p_sweep.py, tools/ythr_probe.py): the y marching sweep (2 B rows, radius-8
@@ -102,8 +101,6 @@ struct sdfgpu_context {
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
     int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // outward-scan bounds of the marching kernels
-    bool env_mode_y = false, env_mode_x = false;               // policy: run the envelope kernel alone on that axis
-    bool prev_env_y = false, prev_env_x = false;
     bool fused_always = false;
     uint32_t* d_slots = nullptr;     // [kSlots][kSlotWords] extrema / flag slots of the dense kernel (kept zero between launches)
     uint32_t* d_result = nullptr;    // [8] the status block of the last finished build (d_small is cleared by its fold)
@@ -122,9 +119,6 @@ struct sdfgpu_context {
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
     int mid_thr_y = 16, mid_den_y = 24;   // y probe: radius-8 marching window when more than 1 / den of the voxels have d^2 >= thr
-    int wide_x_from = 32;            // ... and radius-8 x windows from this one
-    int wide_y_from = 16;            // policy: radius-8 y windows when the largest squared distance exceeds this
-    bool wide_y = false, wide_x = false;   // policy: radius-8 windows for the next build's y / x marching sweep
     bool last_plane16 = false;
     int profiling = 0;            // 0 off, 1 an event behind every stage, 2 events around the dense ball kernel only,
                                   // 3 like 2 but only on every 4th build
@@ -237,7 +231,7 @@ int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s, int for
     dim3 grid((unsigned)nbx, (unsigned)nchunks), block(kBlock);
     bool wide = false;
     if constexpr (STAGE == 2 && !VB) {                       // radius-8 window: y sweep only
-        if (vec4 && force_window != 3 && (force_window == 8 || h->march_h == 8 || h->wide_y)) {
+        if (vec4 && force_window != 3 && (force_window == 8 || h->march_h == 8)) {
             hipLaunchKernelGGL((k_sweep_march<2, 4, 8, false>), grid, block, 0, s, a);
             wide = true;
         }
@@ -346,7 +340,7 @@ int launch_sweep_x16(sdfgpu_handle h, const int16_t* d_in16, const int32_t* d_si
     const bool slab = lo_trunc || hi_trunc || side_lo > 0 || side_hi < a.L;
     if (V == 8) launch_x16_variant<8, 3>(a, grid, block, vb != 0, slab, s);
     else if (h->x16_h == 2) launch_x16_variant<4, 2>(a, grid, block, vb != 0, slab, s);
-    else if ((h->x16_h == 8 || (h->x16_h == 3 && h->wide_x)) && !vb && !slab)      // wide window: plain grids only
+    else if (h->x16_h == 8 && !vb && !slab)      // wide window (option only): plain grids
         hipLaunchKernelGGL((k_sweep_x16<4, 8, false, false>), grid, block, 0, s, a);
     else launch_x16_variant<4, 3>(a, grid, block, vb != 0, slab, s);
     HIP_TRY(h, hipGetLastError());
@@ -669,13 +663,11 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // shapes / modes the tuned dense kernels do not take go through their generic forms (any nz, virtual border)
     const bool dense_generic = !dense && h->dense_on && h->dense_generic_on && nx <= 0x7fffffff && ny <= 0x7fffffff;
     dense = dense || dense_generic;
-    // Learn from the previous build on this handle, if its flags have arrived (never a wait).  Every
-    // setting below is exact; the policy only moves work around:
+    // Learn from the previous build on this handle, if its flags have arrived (never a wait).  Every setting below is exact;
+    // the policy only decides whether the DENSE tier is worth trying (which tier does a sweep is decided on the device inside
+    // the build -- round 3 removed the host-learned "envelope mode" and window widths):
     //   dense-certified  -> the general kernels will exit on their guard: enqueue the cheapest form of them
-    //                       (fused K12 + K3, unbounded scans, no envelope kernels)
-    //   far_y / far_x    -> the marching sweep of that axis would be thrown away: run the envelope kernel
-    //                       alone next time ("envelope mode"); leave that mode again once the result's
-    //                       largest squared distance is back inside the marching kernels' scan range
+    //                       (fused K12 + K3, unbounded scans, no far-field kernels)
     if (h->flags_pending && hipEventQuery(h->flags_ev) == hipSuccess) {
         h->flags_pending = false;
         const bool general_ran = !h->prev_dense || h->h_flags[3] != 0;
@@ -697,30 +689,6 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
             h->dense_skip = h->dense_backoff;
         }
         if (h->prev_dense && h->h_flags[3] == 0) h->dense_backoff = 0;        // certified again: start over
-        //   mid-sparse scenes (largest squared distance beyond the radius-3 window's 16): radius-8 register windows
-        //   decide most voxels without the outward scan (measured at 512^3: y sweep 0.96 -> 0.53 ms at p = 0.02,
-        //   x sweep 1.22 -> 0.60 ms at p = 0.01; the wider x window only pays from a largest squared distance of ~32 upward:
-        //   p = 0.03 has 28 and gets slower, p = 0.02 has 37 and gets faster)
-        if (general_ran) {
-            const uint32_t md = std::max(h->h_flags[0], h->h_flags[1]);
-            h->wide_y = md > (uint32_t)h->wide_y_from && md <= 100u;           // (beyond ~100 the scans past a radius-8 window dominate again:
-            h->wide_x = md >= (uint32_t)h->wide_x_from && md <= 160u;          //  p = 0.003 has 130: x sweep 1.7 -> 1.2 ms; p = 0.001 has 270 and
-                                                          //  its x sweep took 5.0 instead of 2.4 ms)
-        } else {
-            h->wide_y = h->wide_x = false;
-        }
-        if (general_ran) {
-            const uint32_t max_d = std::max(h->h_flags[0], h->h_flags[1]);
-            // (hysteresis: an axis enters envelope mode on its far flag -- an IN-PLANE distance beyond the scan bound --
-            //  and leaves it only when the 3-D maximum is far below that bound; p = 0.003 has in-plane distances of 44
-            //  with a 3-D maximum of 11 and used to alternate between the two modes)
-            const bool near = max_d <= (uint32_t)((kScanExpectNear / 4) * (kScanExpectNear / 4));
-            h->env_mode_y = h->prev_env_y ? !near : (h->h_flags[4] != 0);
-            h->env_mode_x = h->prev_env_x ? !near : (h->h_flags[5] != 0);
-            if (h->force_env > 0) h->env_mode_y = h->env_mode_x = true;      // option "envelope_mode" is sticky
-        } else {
-            h->env_mode_y = h->env_mode_x = false;
-        }
     }
     if (dense && h->dense_skip > 0) { --h->dense_skip; dense = false; }
     // bounded marching scans + the far-field kernel behind them, on every shape that kernel takes; other shapes (lines beyond
@@ -728,23 +696,16 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // exact int32 plane values from the y to the x sweep.
     const bool envelope = h->envelope_on && !(h->expect_dense && dense) &&
                           far_geometry_ok(h, 2, nx, ny, nz) && far_geometry_ok(h, 3, nx, ny, nz);
-    // Device-side tier selection (needs the divide-and-conquer envelope kernel on both axes): the marching-vs-envelope
-    // choice of each axis is made INSIDE this build from a probe of the sweep's own input, so a fresh context (the
-    // reference's API is one-shot: collision_map.hpp:680-712 builds and returns) never runs a sweep that is thrown away.
-    // Other shapes keep the host policy below (choice learned from the previous build on the handle).
-    const bool dev_select = envelope && p16 && h->tier_select;
-    const bool env_y = envelope && !dev_select && h->env_mode_y, env_x = envelope && !dev_select && h->env_mode_x;
+    // Device-side tier selection: the marching-vs-far-field choice of each axis is made INSIDE this build from a probe of the
+    // sweep's own input, so a fresh context (the reference's API is one-shot: collision_map.hpp:680-712 builds and returns)
+    // never runs a sweep that is thrown away, and a handle's latency does not depend on what it built before.
+    const bool dev_select = envelope;
     // K12 (fused z+y) only as the guarded stand-by behind a dense build that is expected to be certified
     // again; everywhere else K1 + K2 (rows from the int16 z field) scan much faster than the fused kernel
     // recomputes, and only they can hand a far-field y sweep to the envelope kernel.
     const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
     const bool select = dev_select && !fused;
-    // With the tier chosen on the device, the far-field kernel takes the x axis from the point where the radius-3 window
-    // stops deciding nearly every voxel (0.55 ms flat at 512^3); the radius-8 x window (0.64 ms flat, it spills) can only
-    // lose against both from there on -- measured: p = 0.04 0.64 vs 0.36 ms with the radius-3 window.  It stays for shapes
-    // the far-field kernel does not take.
-    if (select) h->wide_x = false;
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
@@ -830,10 +791,15 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // Both axes far-field (decided by the y probe): the y sweep hands the x sweep exact int32 values in the side-table
     // buffer (used whole) instead of p16 + side table -- one store / one load per voxel, no saturation handling, and the
     // x probe is skipped.  d_small[7] carries the choice on the device.
-    const bool handoff = select && h->i32_handoff;
+    const bool handoff = select && p16 && h->i32_handoff;        // (shapes without the 16-bit plane field hand int32 values over anyway)
     DcExtra hand2{}, hand3{};
     hand2.out_i32 = (int32_t*)h->yzfield.ptr; hand2.i32_flag = h->d_small + 7;
     hand3.in_i32 = (const int32_t*)h->yzfield.ptr; hand3.i32_flag = h->d_small + 7;
+    DcExtra plain2{}, plain3{};                                 // shapes without the 16-bit plane field: int32 in / out, unconditionally
+    plain2.out_i32 = (int32_t*)h->yzfield.ptr;
+    plain3.in_i32 = (const int32_t*)h->yzfield.ptr;
+    const DcExtra* const ex2 = !p16 ? &plain2 : handoff ? &hand2 : nullptr;
+    const DcExtra* const ex3 = !p16 ? &plain3 : handoff ? &hand3 : nullptr;
     // (the radius-8 y window exists for 4-voxel lanes only; a forced window leaves nothing to choose)
     const bool window_choice = select && (nz % 4) == 0 && h->march_h != 8 && h->mid_den_y > 0;
     auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff, window_choice); };   // probe counters -> guard words
@@ -842,7 +808,8 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         DcDecide dy; dy.stage = 0; dy.dense_tried = dense; dy.handoff = handoff; dy.window_choice = window_choice;
         if (h->force_env < 0) {
             if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, h->plane16.ptr, (int32_t*)h->yzfield.ptr,
-                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12, nullptr, &dy)) return rc;
+                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12,
+                                         !p16 ? &plain2 : nullptr, &dy)) return rc;
         } else if (int rc = decide(0)) return rc;
         // marching y sweep: general pipeline needed AND near-field; the probe also picks the window (radius 3 / radius 8)
         h->guard = h->d_small + 8;
@@ -856,18 +823,14 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     } else if (fused) {
         if (int rc = launch_sweep_zy_fused(h, d_filled, zy_out, zy_side, nx, ny, nz, s)) return rc;
         launched_since_mark = true;
-    } else if (!env_y) {
+    } else {                                                    // (no far-field kernel for this shape / switched off: unbounded scans)
         if (int rc = launch_sweep_y(h, (const int16_t*)h->zfield.ptr, zy_out, zy_side, nx, ny, nz, s)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(4));
-    DcExtra plain2{}, plain3{};                                 // shapes without the 16-bit plane field: int32 in / out, unconditionally
-    plain2.out_i32 = (int32_t*)h->yzfield.ptr;
-    plain3.in_i32 = (const int32_t*)h->yzfield.ptr;
-    if (envelope && !fused) {
+    if (select) {
         if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, p16 ? h->plane16.ptr : nullptr, p16 ? (int32_t*)h->yzfield.ptr : nullptr,
-                                     nx, ny, nz, resolution, vb, h->d_small, env_y ? h->guard : h->d_small + 4, s, 0, nullptr,
-                                     !p16 ? &plain2 : handoff ? &hand2 : nullptr)) return rc;
+                                     nx, ny, nz, resolution, vb, h->d_small, h->d_small + 4, s, 0, nullptr, ex2)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(5));
@@ -877,32 +840,32 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (select) {
         DcDecide dx; dx.stage = 1; dx.dense_tried = dense; dx.handoff = handoff; dx.window_choice = window_choice;
         if (h->force_env < 0) {
-            if (int rc = launch_envelope(h, 3, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, nullptr,
-                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12,
-                                         handoff ? &hand3 : nullptr, &dx)) return rc;
+            if (int rc = launch_envelope(h, 3, p16 ? (const int16_t*)h->plane16.ptr : nullptr, p16 ? (const int32_t*)h->yzfield.ptr : nullptr, d_out, nullptr,
+                                         nx, ny, nz, resolution, vb, h->d_small, general_guard, s, 0, h->d_small + 12, ex3, &dx)) return rc;
         } else if (int rc = decide(1)) return rc;
         h->guard = h->d_small + 10;
-        if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
-                                      0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+        if (p16) {
+            if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
+                                          0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+        } else {
+            if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
+                                        resolution, vb, h->d_small, h->d_small + 2, s, 0, -1, h->scan_x, h->far_y + 1)) return rc;
+        }
         h->guard = general_guard;
         launched_since_mark = true;
     } else if (p16) {
-        if (!env_x) {
-            if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
-                                          0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
-            launched_since_mark = true;
-        }
-    } else if (!env_x) {
+        if (int rc = launch_sweep_x16(h, (const int16_t*)h->plane16.ptr, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0,
+                                      0, nx, ny, nz, 0, 0, 0, nx, resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
+        launched_since_mark = true;
+    } else {
         if (int rc = launch_sweep_x(h, (const int32_t*)h->yzfield.ptr, d_out, 0, nx, 0, ny, nz, 0, 0, 0, nx,
-                                    resolution, vb, h->d_small, h->d_small + 2, s, 0, -1,
-                                    h->far_y ? h->scan_x : 0, h->far_y ? h->far_y + 1 : nullptr)) return rc;
+                                    resolution, vb, h->d_small, h->d_small + 2, s)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(6));
-    if (envelope && !fused) {
+    if (select) {
         if (int rc = launch_envelope(h, 3, p16 ? (const int16_t*)h->plane16.ptr : nullptr, p16 ? (const int32_t*)h->yzfield.ptr : nullptr, d_out, nullptr,
-                                     nx, ny, nz, resolution, vb, h->d_small, env_x ? h->guard : h->d_small + 5, s, 0, nullptr,
-                                     !p16 ? &plain3 : handoff ? &hand3 : nullptr)) return rc;
+                                     nx, ny, nz, resolution, vb, h->d_small, h->d_small + 5, s, 0, nullptr, ex3)) return rc;
         launched_since_mark = true;
     }
     // one kernel folds the maxima, publishes the status block (device copy for get_extrema, pinned host copy for the
@@ -923,8 +886,6 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->prev_dense = dense;
         h->prev_generic = dense_generic;
         h->prev_fix_mode = cur_fix_mode;
-        h->prev_env_y = env_y && !fused;
-        h->prev_env_x = env_x;
     }
     if (prof) {
         HIP_TRY(h, mark(7));
@@ -1260,7 +1221,7 @@ int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int6
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nxs * ny * nz;
     hipStream_t s = (hipStream_t)stream;
-    const bool tiered = h->envelope_on && h->tier_select && far_geometry_ok(h, 2, nxs, ny, nz) &&
+    const bool tiered = h->envelope_on && far_geometry_ok(h, 2, nxs, ny, nz) &&
                         (nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
     if (!tiered) {
         if (fused_zy_eligible(h, d_filled, d_plane_dsq, nz)) return launch_sweep_zy_fused(h, d_filled, d_plane_dsq, nullptr, nxs, ny, nz, s);
@@ -1312,7 +1273,7 @@ int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int
     hipStream_t s = (hipStream_t)stream;
     h->guard = nullptr;
     h->far_y = nullptr;
-    const bool tiered = h->envelope_on && h->tier_select && far_geometry_ok(h, 3, nx, nys, nz, ny_global) &&
+    const bool tiered = h->envelope_on && far_geometry_ok(h, 3, nx, nys, nz, ny_global) &&
                         (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
     if (!tiered) {
         if (int rc = launch_sweep_x(h, d_plane_dsq, d_out_sdf, 0, nx, 0, nys, nz, 0, 0, 0, nx, resolution, add_virtual_border,
@@ -1718,12 +1679,11 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
-    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->env_mode_y = h->env_mode_x = false; h->dense_skip = 0; h->dense_backoff = 0; h->fix_mode = false; h->wide_y = h->wide_x = false; }
+    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->dense_skip = 0; h->dense_backoff = 0; h->fix_mode = false; }
     else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; }
     else if (n == "fixup_mode") h->fix_mode = value != 0;
     else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; h->dense_backoff = 0; }
-    else if (n == "envelope_mode") { h->flags_pending = false; h->env_mode_y = h->env_mode_x = value != 0; h->force_env = value != 0 ? 1 : -1; }
-    else if (n == "tier_select") h->tier_select = value != 0;
+    else if (n == "envelope_mode") { h->flags_pending = false; h->force_env = value != 0 ? 1 : -1; }
     else if (n == "far_threshold_y") h->far_thr[0] = value;
     else if (n == "far_threshold_x") h->far_thr[1] = value;
     else if (n == "far_fraction_den_y") h->far_den[0] = value > 0 ? value : 8;
@@ -1731,8 +1691,6 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "x16_voxels_per_lane") h->x16_v = value;
     else if (n == "x16_window") h->x16_h = value;
     else if (n == "march_window") h->march_h = value == 8 ? 8 : 3;
-    else if (n == "wide_y_from") h->wide_y_from = value;
-    else if (n == "wide_x_from") h->wide_x_from = value;
     else if (n == "mid_threshold_y") h->mid_thr_y = value;
     else if (n == "mid_fraction_den_y") h->mid_den_y = value;
     else return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
