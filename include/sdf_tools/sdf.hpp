@@ -141,8 +141,15 @@ public:
         const Eigen::Quaterniond q(origin_transform_.rotation());
         const bool identity = q.w() == 1.0 && q.x() == 0.0 && q.y() == 0.0 && q.z() == 0.0;
         const Eigen::Quaterniond qi = q.inverse();
+        // The reference returns an EMPTY vector for a cell on the boundary shell when edge gradients are off (:464): those
+        // cells get `empty_fill`.  Emptiness is decided from the index, not from the value: a genuine NaN (inf - inf on a grid
+        // without filled or without free voxels) is what the reference returns there too and must stay.
+        const int64_t sx = ny * nz;
         for (size_t i = 0; i < g.size(); i += 3) {
-            if (std::isnan(g[i])) { g[i] = g[i + 1] = g[i + 2] = empty_fill; continue; }
+            if (!enable_edge_gradients) {
+                const int64_t v = (int64_t)(i / 3), x = v / sx, y = (v - x * sx) / nz, z = v - x * sx - y * nz;
+                if (x <= 0 || y <= 0 || z <= 0 || x >= nx - 1 || y >= ny - 1 || z >= nz - 1) { g[i] = g[i + 1] = g[i + 2] = empty_fill; continue; }
+            }
             if (identity) continue;                           // q * (0, g) * q^-1 == g exactly
             const Eigen::Quaterniond r = q * (Eigen::Quaterniond(0.0, g[i], g[i + 1], g[i + 2]) * qi);
             g[i] = r.x(); g[i + 1] = r.y(); g[i + 2] = r.z();

@@ -22,8 +22,11 @@
  *   - a handle is bound to one GPU; use one handle per host thread
  *   - builds on one handle share its scratch fields and status block.  Builds issued on the same stream are
  *     ordered by the stream; a build issued on a different stream than the previous one first waits (on the
- *     device, hipStreamWaitEvent) for the previous build's last kernel.  The stage-level entry points
- *     (sdfgpu_sweep_*_device, sdfgpu_dense_ball_device, sdfgpu_slab_dense_phase ...) write only caller-owned
+ *     device, hipStreamWaitEvent) for the previous build's last kernel.  The tiered stage entry points
+ *     (sdfgpu_sweep_zy_device / sdfgpu_sweep_zy_tiered_device, sdfgpu_sweep_x_lines_device) use the status block and
+ *     scratch fields too and take part in the same ordering (they wait for the handle's previous work when that ran
+ *     on another stream, and later work waits for them).  The remaining stage-level entry points
+ *     (sdfgpu_sweep_x_device, sdfgpu_dense_ball_device, sdfgpu_slab_dense_phase ...) write only caller-owned
  *     buffers plus the handle's extrema slots: issue all stage calls of one build on one stream.
  *   - host-buffer entry points use the caller's output buffer as scratch while they run (its pages are
  *     faulted in while the input travels to the GPU): when such a call fails, the contents of out_sdf /

@@ -56,7 +56,8 @@ def build_libsdfgpu_multi(force=False, verbose=False):
     if not force and not _newer(LIB_MULTI, deps + [LIB]):
         return LIB_MULTI
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", "/opt/rocm/include",
-           src, "-o", LIB_MULTI, "-L", PKG, "-lsdfgpu", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN"]
+           src, "-o", LIB_MULTI, "-L", PKG, "-lsdfgpu", "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN",
+           "-Wl,-rpath,/opt/rocm/lib"]          # (librccl.so is found without LD_LIBRARY_PATH: pysdf_tools links this library)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

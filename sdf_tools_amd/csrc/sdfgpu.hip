@@ -109,7 +109,10 @@ struct sdfgpu_context {
     uint32_t* h_flags = nullptr;     // pinned host copy of the status block, written by the fold kernel of every build
     hipEvent_t flags_ev = nullptr;
     bool flags_pending = false;
-    hipEvent_t build_done_ev = nullptr;   // recorded behind every build: a build on another stream waits for it first
+    hipEvent_t build_done_ev = nullptr;   // recorded behind every build (and every stage call that uses the status block):
+                                          // work on another stream waits for it first
+    bool order_valid = false;             // build_done_ev has been recorded on order_stream
+    hipStream_t order_stream = nullptr;
     bool prev_dense = false;
     bool prev_generic = false;       // ... and it was the generic form (no fix-up kernel behind it)
     bool expect_dense = false;
@@ -711,7 +714,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
     // Builds on one handle share its status block, extrema slots and scratch fields.  On the same stream they are
     // ordered by the stream; a build issued on ANOTHER stream first waits for the previous build's last kernel.
-    if (h->have_result && s != h->last_stream) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
+    if (h->order_valid && s != h->order_stream) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
     if (!h->small_clean) {
         HIP_TRY(h, hipMemsetAsync(h->d_small, 0, 128, s));
         HIP_TRY(h, hipMemsetAsync(h->d_slots, 0, (size_t)kSlots * kSlotWords * 4, s));   // a failed build may have left maxima behind
@@ -892,6 +895,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         for (auto e : ev) h->events.push_back(e);
     }
     HIP_TRY(h, hipEventRecord(h->build_done_ev, s));
+    h->order_valid = true; h->order_stream = s;
     h->last_stream = s;
     h->last_resolution = resolution;
     h->last_n = n;
@@ -1221,6 +1225,10 @@ int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int6
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nxs * ny * nz;
     hipStream_t s = (hipStream_t)stream;
+    // (this call uses the handle's status block and scratch fields like a whole build does: it takes part in the same
+    //  cross-stream ordering -- waits for the handle's previous work when that ran on another stream, and is waited for)
+    if (h->order_valid && s != h->order_stream) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
+    struct OrderEnd { sdfgpu_handle h; hipStream_t s; ~OrderEnd() { if (hipEventRecord(h->build_done_ev, s) == hipSuccess) { h->order_valid = true; h->order_stream = s; } } } order_end{h, s};
     const bool tiered = h->envelope_on && far_geometry_ok(h, 2, nxs, ny, nz) &&
                         (nz % 4) == 0 && (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
     if (!tiered) {
@@ -1273,6 +1281,8 @@ int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int
     hipStream_t s = (hipStream_t)stream;
     h->guard = nullptr;
     h->far_y = nullptr;
+    if (h->order_valid && s != h->order_stream) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
+    struct OrderEnd { sdfgpu_handle h; hipStream_t s; ~OrderEnd() { if (hipEventRecord(h->build_done_ev, s) == hipSuccess) { h->order_valid = true; h->order_stream = s; } } } order_end{h, s};
     const bool tiered = h->envelope_on && far_geometry_ok(h, 3, nx, nys, nz, ny_global) &&
                         (reinterpret_cast<uintptr_t>(d_plane_dsq) % 16) == 0;
     if (!tiered) {

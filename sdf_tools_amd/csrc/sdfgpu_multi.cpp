@@ -186,11 +186,25 @@ int read_small(sdfgpu_multi_handle h) {         // status blocks of all ranks ->
     return SDFGPU_OK;
 }
 
+// The limits of sdfgpu_build* (check_dims in sdfgpu.hip), applied before anything is allocated or uploaded: an oversized
+// or malformed request must come back as UNSUPPORTED_SIZE / INVALID_ARGUMENT, not as a hipMalloc failure half-way.
+int check_request(sdfgpu_multi_handle h, int64_t nx, int64_t ny, int64_t nz, const void* cells, size_t stride, size_t off) {
+    const int G = (int)h->r.size();
+    if (nx <= 0 || ny <= 0 || nz <= 0) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid dimensions must be positive");
+    constexpr int64_t kMaxDim = 16384;
+    if (nx > kMaxDim || ny > kMaxDim || nz > kMaxDim || nx * nx + ny * ny + nz * nz >= (1ll << 30))
+        return mfail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "grid %lld x %lld x %lld exceeds the supported extent (dims <= 16384, nx^2+ny^2+nz^2 < 2^30)",
+                     (long long)nx, (long long)ny, (long long)nz);
+    if (nx < G) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid has fewer x planes (%lld) than ranks (%d)", (long long)nx, G);
+    if (cells && (stride < 4 || (stride % 4) || (off % 4) || off + 4 > stride))
+        return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
+    return SDFGPU_OK;
+}
+
 int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx, int64_t ny, int64_t nz, double res, int vb,
                  float* const* d_out, double* out_max, double* out_min) {
     const int G = (int)h->r.size();
-    if (nx <= 0 || ny <= 0 || nz <= 0) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid dimensions must be positive");
-    if (nx < G) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid has fewer x planes (%lld) than ranks (%d)", (long long)nx, G);
+    if (int rc = check_request(h, nx, ny, nz, nullptr, 0, 0)) return rc;
     const int64_t plane = ny * nz;
     int64_t min_slab = nx;
     for (int q = 0; q < G; ++q) {
@@ -391,8 +405,7 @@ int build_host(sdfgpu_multi_handle h, const uint8_t* filled, const void* cells, 
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if ((!filled && !cells) || !out) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
     const int G = (int)h->r.size();
-    if (nx <= 0 || ny <= 0 || nz <= 0) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid dimensions must be positive");
-    if (nx < G) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "grid has fewer x planes (%lld) than ranks (%d)", (long long)nx, G);
+    if (int rc = check_request(h, nx, ny, nz, cells, stride, off)) return rc;
     const int64_t plane = ny * nz;
     std::vector<const uint8_t*> dm((size_t)G);
     std::vector<float*> dout((size_t)G);
