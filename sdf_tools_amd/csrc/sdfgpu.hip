@@ -3,6 +3,7 @@
 // (reference include/sdf_tools/sdf_generation.hpp:209-420).  No CPU fallback.
 #include "sdfgpu_kernels.hpp"
 #include "sdfgpu_sweep_x16.hpp"
+#include "sdfgpu_sweep_y16.hpp"
 #include "sdfgpu_fused_zy.hpp"
 #include "sdfgpu_dense.hpp"
 #include "sdfgpu_envelope_dc.hpp"
@@ -119,6 +120,7 @@ struct sdfgpu_context {
     bool last_dense = false;
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
+    bool y16_on = true;              // y sweep of that pipeline through the packed 16-bit kernel (option "y16"; 0 = the 32-bit marching kernel)
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
     int mid_thr_y = 16, mid_den_y = 24;   // y probe: radius-8 marching window when more than 1 / den of the voxels have d^2 >= thr
@@ -240,6 +242,8 @@ int launch_march(sdfgpu_handle h, SweepArgs a, bool vec4, hipStream_t s, int for
         }
     }
     if (wide) {}
+    else if (STAGE == 2 && vec4 && a.out16 && h->y16_on && kH == 3)      // y sweep into the 16-bit plane field: packed 16-bit window
+        hipLaunchKernelGGL((k_sweep_y16<3>), grid, block, 0, s, a);
     else if (vec4) hipLaunchKernelGGL((k_sweep_march<STAGE, 4, kH, VB>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_march<STAGE, 1, kH, VB>), grid, block, 0, s, a);
     HIP_TRY(h, hipGetLastError());
@@ -1676,6 +1680,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "rows_per_chunk_zy") h->tune_tzy = value;
     else if (n == "fused_window") h->fused_h = value;
     else if (n == "plane16") h->plane16_on = value != 0;
+    else if (n == "y16") h->y16_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
     else if (n == "dense_generic") h->dense_generic_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;
