@@ -455,11 +455,13 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.probe_stride = (int)std::max<int64_t>(1, std::min<int64_t>(64, ntiles / 256));
             a.probe_thr = h->far_thr[stage - 2];
             a.probe_thr2 = stage == 2 ? h->mid_thr_y : 0;
+            a.probe_thr3 = (stage == 2 && dec) ? h->far_thr[1] : 0;
             a.probe_out = probe_out;
             if (dec) {
                 a.decide_small = h->d_small; a.decide_stage = dec->stage; a.decide_dense_tried = dec->dense_tried ? 1 : 0;
                 a.decide_force = h->force_env; a.decide_den = h->far_den[dec->stage]; a.decide_handoff = dec->handoff ? 1 : 0;
                 a.decide_mid_den = (dec->stage == 0 && dec->window_choice) ? h->mid_den_y : 0;
+                a.decide_xden = h->far_den[1];
             }
             ntiles = (ntiles + a.probe_stride - 1) / a.probe_stride;
             while (ntiles > 0 && (ntiles - 1) * a.probe_stride + ((ntiles - 1) * 7) % a.probe_stride >= all) --ntiles;

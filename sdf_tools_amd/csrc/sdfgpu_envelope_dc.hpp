@@ -89,11 +89,13 @@ struct EnvDcArgs {
     int probe_stride;
     int probe_thr;
     int probe_thr2;           // second, lower threshold (y probe: radius-8 vs radius-3 marching window), counted into probe_out[-1]
+    int probe_thr3;           // y probe: the x sweep's far threshold, counted into probe_out[5] (status word 17): the x result is
+                              // never larger than the y result, so a y probe that finds few such voxels settles the x tier too
     uint32_t* probe_out;
     // probe launches also turn their counters into the tier decision (the last workgroup to finish does what k_decide_tier
     // does): decide_small = the status block, nullptr = no decision here
     uint32_t* decide_small;
-    int decide_stage, decide_dense_tried, decide_force, decide_den, decide_handoff, decide_mid_den;
+    int decide_stage, decide_dense_tried, decide_force, decide_den, decide_handoff, decide_mid_den, decide_xden;
     // both axes far-field: when *i32_flag != 0 the y sweep hands its result to the x sweep as an exact int32 plane field
     // (out_i32 / in_i32, the side-table buffer used whole) instead of p16 + side table; nullptr = the pointers alone decide
     const uint32_t* i32_flag;
@@ -156,13 +158,17 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 // probe's counters.  The marching sweep runs iff the general pipeline is needed at all and the probe found the axis
 // near-field; otherwise the far-field flag is raised and the (flag-guarded) far-field kernel does the sweep.
 __device__ __forceinline__ void decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den,
-                                            int handoff, int mid_den) {
+                                            int handoff, int mid_den, int xden = 0) {
     auto ld = [&](int i) -> uint32_t { return __hip_atomic_load(small + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     const bool active = dense_tried ? ld(3) != 0u : true;
     const uint32_t far_n = ld(12), tot = ld(13), mid_n = ld(11);
     // far when more than num / den of the sampled voxels need a long scan (64-bit: counts are < 2^24, factors small)
     bool far = force >= 0 ? force != 0 : (uint64_t)far_n * (uint64_t)den > (uint64_t)tot * (uint64_t)num;
     if (stage == 1 && ld(7) != 0u) far = true;                  // the y probe chose the far-field pair with int32 hand-off
+    if (stage == 1 && force < 0 && ld(18) != 0u) far = false;   // the y probe already settled it: near-field (no x probe ran)
+    // (only when the y sweep itself stays near-field: a far-field y sweep may hand the x sweep int32 values, which only the
+    //  far-field x kernel reads)
+    if (stage == 0) small[18] = (force < 0 && !far && tot != 0u && (uint64_t)ld(17) * (uint64_t)xden <= (uint64_t)tot) ? 1u : 0u;
     // y sweep, near-field: radius-8 register windows when more than 1 / mid_den of the voxels are beyond the radius-3 one
     const bool wide = stage == 0 && mid_den > 0 && (uint64_t)mid_n * (uint64_t)mid_den > (uint64_t)tot;
     small[8 + 2 * stage] = (active && !far && !wide) ? 1u : 0u;
@@ -172,11 +178,13 @@ __device__ __forceinline__ void decide_tier(uint32_t* __restrict__ small, int st
     small[11] = 0u;
     small[12] = 0u;
     small[13] = 0u;
+    small[17] = 0u;
+    if (stage == 1) small[18] = 0u;
     small[14 + stage] = tot ? (far_n * 1000u) / tot : 0u;         // per-mille of far voxels in the sample (diagnostics)
 }
 __global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff,
                               int mid_den) {
-    decide_tier(small, stage, dense_tried, force, num, den, handoff, mid_den);
+    decide_tier(small, stage, dense_tried, force, num, den, handoff, mid_den, 0);
 }
 // ... called by the last workgroup of a probe launch (every workgroup passes here exactly once, early exits included)
 __device__ __forceinline__ void probe_done(const EnvDcArgs& a) {
@@ -184,7 +192,7 @@ __device__ __forceinline__ void probe_done(const EnvDcArgs& a) {
     __threadfence();
     if (atomicAdd(a.decide_small + 16, 1u) == gridDim.x - 1u) {
         __threadfence();
-        decide_tier(a.decide_small, a.decide_stage, a.decide_dense_tried, a.decide_force, 1, a.decide_den, a.decide_handoff, a.decide_mid_den);
+        decide_tier(a.decide_small, a.decide_stage, a.decide_dense_tried, a.decide_force, 1, a.decide_den, a.decide_handoff, a.decide_mid_den, a.decide_xden);
         a.decide_small[16] = 0u;
     }
 }
@@ -208,6 +216,8 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
     }
     const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
     if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
+    if (a.probe_stride > 0 && STAGE == 3 && a.decide_small &&
+        __hip_atomic_load(a.decide_small + 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { probe_done(a); return; }   // ... settled by the y probe
     const int L = a.L, B = a.B, pitch = a.pitch, M = a.M, h = a.h;
     const int MA = (L + 63) >> 6;
     const uint32_t mask = (1u << B) - 1u, finf = a.finf;
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
             (reinterpret_cast<float*>(a.out) + base)[oi] = -f;
         }
     };
-    int probe_far = 0, probe_tot = 0, probe_mid = 0;
+    int probe_far = 0, probe_tot = 0, probe_mid = 0, probe_x9 = 0;
 
     // THE inner loop: 8 positions (multipliers nc[k] = -((2 p'_k) << B)) against the candidates qs, qs + step, ... <= qe
     // taken in aligned pairs (qs even).  Candidates outside the caller's range that ride along in a pair are harmless:
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                         probe_tot += D != 0 ? 1 : 0;
                         probe_far += D >= a.probe_thr ? 1 : 0;
                         probe_mid += D >= a.probe_thr2 ? 1 : 0;
+                        probe_x9 += D >= a.probe_thr3 ? 1 : 0;
                     }
                 }
                 return;                                     // (from the pass; the counters are summed below)
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
         }
 
         if (probe) {                            // (a tile without sites: every sampled voxel is at "infinity")
-            if (slotT < imin(MA, S) && lineT < nvalid) { probe_tot += 1; probe_far += 1; probe_mid += 1; }
+            if (slotT < imin(MA, S) && lineT < nvalid) { probe_tot += 1; probe_far += 1; probe_mid += 1; probe_x9 += 1; }
             return;
         }
         // ---- level C: lane = (line, chunk of 8 positions); finish and store ---------------------------------------------------
@@ -705,10 +716,15 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
             probe_far += __shfl_xor(probe_far, off);
             probe_tot += __shfl_xor(probe_tot, off);
             probe_mid += __shfl_xor(probe_mid, off);
+            probe_x9 += __shfl_xor(probe_x9, off);
         }
-        if ((t & 63) == 0) { atomicAdd(&misc[26], (uint32_t)probe_far); atomicAdd(&misc[27], (uint32_t)probe_tot); atomicAdd(&misc[28], (uint32_t)probe_mid); }
+        if ((t & 63) == 0) { atomicAdd(&misc[26], (uint32_t)probe_far); atomicAdd(&misc[27], (uint32_t)probe_tot); atomicAdd(&misc[28], (uint32_t)probe_mid); atomicAdd(&misc[29], (uint32_t)probe_x9); }
         __syncthreads();
-        if (t == 0) { atomicAdd(a.probe_out, misc[26]); atomicAdd(a.probe_out + 1, misc[27]); if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, misc[28]); }
+        if (t == 0) {
+            atomicAdd(a.probe_out, misc[26]); atomicAdd(a.probe_out + 1, misc[27]);
+            if (a.probe_thr2 > 0) atomicAdd(a.probe_out - 1, misc[28]);
+            if (a.probe_thr3 > 0) atomicAdd(a.probe_out + 5, misc[29]);        // (probe_out = status word 12: + 5 = word 17)
+        }
         probe_done(a);
         return;
     }
