@@ -120,6 +120,7 @@ struct sdfgpu_context {
     bool last_dense = false;
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
+    bool z_wave_on = true;           // z sweep with wave-private rows where nz allows it (option "z_wave"; 0 = the workgroup form)
     bool y16_on = true;              // y sweep of that pipeline through the packed 16-bit kernel (option "y16"; 0 = the 32-bit marching kernel)
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
@@ -211,6 +212,19 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
     if (d_cells) {
         CellLoader ld{reinterpret_cast<const char*>(d_cells), (int64_t)stride, (int64_t)off, unknown};
         hipLaunchKernelGGL(k_sweep_z_generic<CellLoader>, grid, block, lds, s, ld, d_out, nrows, (int)nz, rpb, h->guard);
+    } else if (h->z_wave_on && (nz == 64 || nz == 128 || nz == 256 || nz == 512 || nz == 1024) &&
+               (reinterpret_cast<uintptr_t>(d_mask) % 16) == 0) {
+        // whole rows per wave (16 nz-lanes): no workgroup barrier; 16 workgroups per CU's worth of persistent waves
+        const int rw = 1024 / (int)nz;                                  // rows per wave step
+        const int64_t ngroups = (nrows + rw - 1) / rw;
+        dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), 4096));
+        switch ((int)nz) {
+            case 64: hipLaunchKernelGGL(k_sweep_z_wave16<4>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
+            case 128: hipLaunchKernelGGL(k_sweep_z_wave16<8>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
+            case 256: hipLaunchKernelGGL(k_sweep_z_wave16<16>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
+            case 512: hipLaunchKernelGGL(k_sweep_z_wave16<32>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
+            default: hipLaunchKernelGGL(k_sweep_z_wave16<64>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
+        }
     } else if ((nz % 16) == 0 && (reinterpret_cast<uintptr_t>(d_mask) % 16) == 0) {
         hipLaunchKernelGGL(k_sweep_z_vec16, grid, block, lds, s, d_mask, d_out, nrows, (int)nz, rpb, h->guard);
     } else {
@@ -1683,6 +1697,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "fused_window") h->fused_h = value;
     else if (n == "plane16") h->plane16_on = value != 0;
     else if (n == "y16") h->y16_on = value != 0;
+    else if (n == "z_wave") h->z_wave_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
     else if (n == "dense_generic") h->dense_generic_on = value != 0;
     else if (n == "envelope") h->envelope_on = value != 0;

@@ -299,6 +299,95 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
     }
 }
 
+// Wave-private form of the fast path for nz = 16 CPR, CPR in {4 .. 64} lanes per row (nz = 64 .. 1024): a wave owns
+// 64 / CPR whole rows per step (1024 voxels), keeps their bitmap in its own 128 bytes of LDS and never meets the other
+// waves of the workgroup -- no workgroup barrier between "pack" and "search", so one wave's loads and stores run under
+// another wave's bit searches (the barrier form ran at memory time PLUS compute time: 0.115 ms at 512^3 for 0.07 ms of
+// traffic and 0.045 ms of VALU work).  The row classes come from two ballots instead of LDS atomics.
+template <int CPR>
+__global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __restrict__ mask, int16_t* __restrict__ out,
+                                                          int64_t nrows, const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
+    constexpr int W = CPR / 4;                     // 64-bit words per row
+    constexpr int RW = 64 / CPR;                   // rows per wave step
+    constexpr int nz = 16 * CPR;
+    __shared__ __attribute__((aligned(16))) uint64_t bm_all[(kBlock / 64) * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* const bm = bm_all + wave * 16;
+    uint16_t* const bm16 = reinterpret_cast<uint16_t*>(bm);
+    const int r = lane / CPR, c = lane - r * CPR;
+    const uint64_t* const row = bm + r * W;
+    const int64_t ngroups = (nrows + RW - 1) / RW;
+    const int64_t gstep = (int64_t)gridDim.x * (kBlock / 64);
+    auto fetch = [&](int64_t g) -> uint4 {
+        const int64_t rr = g * RW + r;
+        if (g < ngroups && rr < nrows) return *reinterpret_cast<const uint4*>(mask + rr * nz + 16 * c);
+        return make_uint4(0u, 0u, 0u, 0u);
+    };
+    int64_t g = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+    uint4 vnext = fetch(g);
+    for (; g < ngroups; g += gstep) {
+        const uint4 v = vnext;
+        vnext = fetch(g + gstep);
+        const int64_t rr = g * RW + r;
+        const bool valid = rr < nrows;
+        const uint32_t bits = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) | (nonzero_bits4(v.w) << 12);
+        const uint64_t bF = __ballot(bits != 0u), bE = __ballot(bits != 0xFFFFu);
+        const uint64_t rmask = CPR == 64 ? ~0ull : (((1ull << (CPR & 63)) - 1ull) << (r * CPR));
+        const bool anyF = (bF & rmask) != 0ull, anyE = (bE & rmask) != 0ull;
+        bm16[lane] = (uint16_t)bits;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (valid) {
+            uint4* dst = reinterpret_cast<uint4*>(out + rr * nz + 16 * c);
+            if (!(anyF && anyE)) {
+                const uint32_t u = anyE ? 0x7fff7fffu : 0x80018001u;       // +32767 (all free) / -32767 (all filled)
+                dst[0] = make_uint4(u, u, u, u);
+                dst[1] = make_uint4(u, u, u, u);
+            } else {
+                const int w = c >> 2, sub = c & 3;
+                const uint64_t word = row[w];
+                const int zb0 = 16 * sub, z0 = 64 * w + zb0;
+                const uint32_t chunk = bits;
+                const uint64_t lowm = (1ull << zb0) - 1ull;
+                const uint64_t higm = sub == 3 ? 0ull : (~0ull << (zb0 + 16));
+                const uint64_t fl = word & lowm, el = ~word & lowm;
+                const uint64_t fr = word & higm, er = ~word & higm;
+                int lastF = fl ? 64 * w + 63 - __clzll((long long)fl) : far_left(row, w, true);
+                int lastE = el ? 64 * w + 63 - __clzll((long long)el) : far_left(row, w, false);
+                int nextF = fr ? 64 * w + __ffsll((unsigned long long)fr) - 1 : far_right(row, w, W, nz, true);
+                int nextE = er ? 64 * w + __ffsll((unsigned long long)er) - 1 : far_right(row, w, W, nz, false);
+                int dl[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const bool own = (chunk >> k) & 1u;
+                    const int z = z0 + k;
+                    dl[k] = z - (own ? lastE : lastF);
+                    lastF = own ? z : lastF;
+                    lastE = own ? lastE : z;
+                }
+                uint32_t pk[8];
+#pragma unroll
+                for (int k = 15; k >= 0; --k) {
+                    const bool own = (chunk >> k) & 1u;
+                    const int z = z0 + k;
+                    const int dr = (own ? nextE : nextF) - z;
+                    nextF = own ? z : nextF;
+                    nextE = own ? nextE : z;
+                    const int d = min(min(dl[k], dr), kInf16);
+                    const uint32_t u = (uint32_t)(own ? -d : d) & 0xffffu;
+                    if (k & 1) pk[k >> 1] = u << 16; else pk[k >> 1] |= u;
+                }
+                dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                // the bitmap is rewritten by the next step
+    }
+}
+
 // Generic path: any nz, any loader (mask bytes or COLLISION_CELL records).
 // A wave ballots 64 voxels into one bitmap word; a lane then owns one voxel.
 template <class Loader>

@@ -61,6 +61,8 @@ SHAPES_P = [
     ((33, 9, 64), 0.3), ((10, 70, 48), 0.5), ((3, 3, 130), 0.1), ((40, 40, 40), 0.02),
     ((20, 40, 1), 0.1), ((1, 1, 50), 0.2), ((7, 1, 9), 0.5), ((1, 1, 1), 0.0), ((2, 3, 256), 0.97),
     ((64, 64, 64), 0.5), ((70, 66, 80), 0.001),
+    # nz in {64 .. 1024}: the wave-private z sweep, with row counts that leave its last wave step ragged
+    ((5, 7, 64), 0.3), ((3, 11, 128), 0.05), ((9, 5, 256), 0.5), ((3, 5, 512), 0.01), ((2, 3, 1024), 0.002),
 ]
 
 
@@ -255,6 +257,33 @@ def test_tuning_does_not_change_results(gpu):
     finally:
         gpu.set_tuning(0, 0)
         gpu.set_option("dense", 1)
+
+
+@pytest.mark.parametrize("nz", [64, 128, 256, 512, 1024])
+def test_z_sweep_forms_agree(gpu, nz):
+    """k_sweep_z_wave16 (whole rows per wave) against k_sweep_z_vec16 (workgroup form): same z field, word for word, on rows
+    of one class, rows with a single voxel of the other class at either end, and random rows."""
+    rng = np.random.default_rng(nz)
+    m = (rng.random((7, 13, nz)) < 0.03).astype(np.uint8)
+    m[0, 0] = 0; m[0, 1] = 1                                  # rows of one class
+    m[0, 2] = 0; m[0, 2, 0] = 1                               # one filled voxel at the low end
+    m[0, 3] = 0; m[0, 3, nz - 1] = 1                          # ... at the high end
+    m[0, 4] = 1; m[0, 4, nz // 2] = 0                         # one free voxel in a filled row
+    m[1] = (rng.random((13, nz)) < 0.5)
+    gpu.set_option("dense", 0)
+    try:
+        sdf_a, ext_a = gpu.build(m, 1.0)
+        za = gpu.debug_zsweep(m.shape).copy()
+        gpu.set_option("z_wave", 0)
+        sdf_b, ext_b = gpu.build(m, 1.0)
+        zb = gpu.debug_zsweep(m.shape).copy()
+    finally:
+        gpu.set_option("z_wave", 1)
+        gpu.set_option("dense", 1)
+    ez, _ = _exact_stage_fields(m)
+    assert np.array_equal(za, ez), _report("z sweep (wave form)", za, ez)
+    assert np.array_equal(zb, ez), _report("z sweep (workgroup form)", zb, ez)
+    assert np.array_equal(sdf_a, sdf_b) and ext_a == ext_b
 
 
 def test_host_copies_chunked_path(gpu):
