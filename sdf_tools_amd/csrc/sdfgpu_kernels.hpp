@@ -299,6 +299,23 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restr
     }
 }
 
+// packed 16-bit pairs in one 32-bit register (v_pk_*_u16 / _i16)
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) { return as_u32(as_us2(a) + as_us2(b)); }
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return as_u32(as_us2(a) - as_us2(b)); }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b)));
+}
+__device__ __forceinline__ uint32_t pk_neg_i16(uint32_t a) {
+    return __builtin_bit_cast(uint32_t, (ss2)(0) - __builtin_bit_cast(ss2, a));
+}
+
 // Wave-private form of the fast path for nz = 16 CPR, CPR in {4 .. 64} lanes per row (nz = 64 .. 1024): a wave owns
 // 64 / CPR whole rows per step (1024 voxels), keeps their bitmap in its own 128 bytes of LDS and never meets the other
 // waves of the workgroup -- no workgroup barrier between "pack" and "search", so one wave's loads and stores run under
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __rest
         return make_uint4(0u, 0u, 0u, 0u);
     };
     int64_t g = (int64_t)blockIdx.x * (kBlock / 64) + wave;
-    uint4 vnext = fetch(g);
+    uint4 vnext = fetch(g);                 // (a second step in flight per wave changes nothing: measured)
     for (; g < ngroups; g += gstep) {
         const uint4 v = vnext;
         vnext = fetch(g + gstep);
@@ -358,26 +375,34 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __rest
                 int lastE = el ? 64 * w + 63 - __clzll((long long)el) : far_left(row, w, false);
                 int nextF = fr ? 64 * w + __ffsll((unsigned long long)fr) - 1 : far_right(row, w, W, nz, true);
                 int nextE = er ? 64 * w + __ffsll((unsigned long long)er) - 1 : far_right(row, w, W, nz, false);
-                int dl[16];
+                // Two running scans over the lane's 16 voxels with PACKED counters: one register holds {distance to the last
+                // filled voxel, distance to the last free voxel} as 16-bit halves.  A voxel clears the half of its own class
+                // (mask m), which leaves its distance to the opposite class in the other half and zero in its own; the
+                // counters then advance by one (v_pk_add_u16).  Left and right scans meet in a packed min, and the signed
+                // result is (low half) - (high half): +d for a free voxel, -d for a filled one.  "None on this side" starts
+                // at kNone, which 16 steps cannot carry past 16 bits and which never survives the min: this branch only
+                // runs on rows that hold both classes.
+                constexpr int kNone = 0x7C00;
+                uint32_t cl = (uint32_t)min(z0 - lastF, kNone) | ((uint32_t)min(z0 - lastE, kNone) << 16);
+                uint32_t cr = (uint32_t)min(nextF - (z0 + 15), kNone) | ((uint32_t)min(nextE - (z0 + 15), kNone) << 16);
+                uint32_t m[16], dl[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const bool own = (chunk >> k) & 1u;
-                    const int z = z0 + k;
-                    dl[k] = z - (own ? lastE : lastF);
-                    lastF = own ? z : lastF;
-                    lastE = own ? lastE : z;
+                    m[k] = 0x0000FFFFu ^ (uint32_t)__builtin_amdgcn_sbfe((int)chunk, k, 1);   // filled: 0xFFFF0000, free: 0x0000FFFF
+                    dl[k] = cl & m[k];
+                    cl = pk_add_u16(dl[k], 0x00010001u);
                 }
                 uint32_t pk[8];
 #pragma unroll
-                for (int k = 15; k >= 0; --k) {
-                    const bool own = (chunk >> k) & 1u;
-                    const int z = z0 + k;
-                    const int dr = (own ? nextE : nextF) - z;
-                    nextF = own ? z : nextF;
-                    nextE = own ? nextE : z;
-                    const int d = min(min(dl[k], dr), kInf16);
-                    const uint32_t u = (uint32_t)(own ? -d : d) & 0xffffu;
-                    if (k & 1) pk[k >> 1] = u << 16; else pk[k >> 1] |= u;
+                for (int k = 15; k >= 1; k -= 2) {
+                    const uint32_t r1 = cr & m[k];
+                    cr = pk_add_u16(r1, 0x00010001u);
+                    const uint32_t r0 = cr & m[k - 1];
+                    cr = pk_add_u16(r0, 0x00010001u);
+                    const uint32_t b1 = pk_min_u16(dl[k], r1), b0 = pk_min_u16(dl[k - 1], r0);     // voxels k, k - 1
+                    const uint32_t lo = __builtin_amdgcn_perm(b1, b0, 0x05040100u);               // {lo(b0), lo(b1)}
+                    const uint32_t hi = __builtin_amdgcn_perm(b1, b0, 0x07060302u);               // {hi(b0), hi(b1)}
+                    pk[k >> 1] = pk_sub_u16(lo, hi);
                 }
                 dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);

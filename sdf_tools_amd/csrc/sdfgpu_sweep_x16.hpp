@@ -21,26 +21,9 @@
 
 namespace sdfgpu {
 
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-typedef short ss2 __attribute__((ext_vector_type(2)));
-
 constexpr int kSat16 = 32767;        // saturated plane-field value: look in the side table
 constexpr unsigned kCap16 = 16383;   // in-window clamp (leaves head-room for + d^2)
 constexpr int kLutN = 1024;
-
-__device__ __forceinline__ uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
-
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_us2(a), as_us2(b))); }
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) { return as_u32(as_us2(a) + as_us2(b)); }
-__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) { return as_u32(as_us2(a) - as_us2(b)); }
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ss2, a), __builtin_bit_cast(ss2, b)));
-}
-__device__ __forceinline__ uint32_t pk_neg_i16(uint32_t a) {
-    return __builtin_bit_cast(uint32_t, (ss2)(0) - __builtin_bit_cast(ss2, a));
-}
 
 // two signed int16 plane values -> packed (P, Q) clamped to kCap16
 __device__ __forceinline__ void split_pq(uint32_t w, uint32_t& P, uint32_t& Q) {
