@@ -126,11 +126,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_sweep_y16(const SweepArgs a) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 if (lo_ok) {
-                    const uint32_t sel = (WP[(r + H - d) % R][j] & mfree[j]) | (WQ[(r + H - d) % R][j] & ~mfree[j]);
+                    const uint32_t sel = bit_select(mfree[j], WP[(r + H - d) % R][j], WQ[(r + H - d) % R][j]);
                     best[j] = pk_min_u16(best[j], pk_add_u16(sel, dd2));
                 }
                 if (hi_ok) {
-                    const uint32_t sel = (WP[(r + H + d) % R][j] & mfree[j]) | (WQ[(r + H + d) % R][j] & ~mfree[j]);
+                    const uint32_t sel = bit_select(mfree[j], WP[(r + H + d) % R][j], WQ[(r + H + d) % R][j]);
                     best[j] = pk_min_u16(best[j], pk_add_u16(sel, dd2));
                 }
             }
