@@ -23,4 +23,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_env_SQ -o p --output-format csv -- python $R/tools/env_bench.py 512 4 > $O/pmc_env_SQ.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY -d $O/pmc_env_SQ2 -o p --output-format csv -- python $R/tools/env_bench.py 512 4 > $O/pmc_env_SQ2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_general_SQ -o p --output-format csv -- python $R/tools/pmc_workload.py 512 dense=0 > $O/pmc_general_SQ.log 2>&1
 ls $O
