@@ -121,6 +121,7 @@ struct sdfgpu_context {
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
     bool z_wave_on = true;           // z sweep with wave-private rows where nz allows it (option "z_wave"; 0 = the workgroup form)
+    bool probe_window = true;        // tier probes as window statistics (option "probe_window"; 0 = level A of the far-field search on sampled tiles)
     bool y16_on = true;              // y sweep of that pipeline through the packed 16-bit kernel (option "y16"; 0 = the 32-bit marching kernel)
     int x16_v = 4, x16_h = 3;        // K3/16 variant: voxels per lane, window radius
     int march_h = 3;                 // K2 (y sweep) register-window radius: 3 or 8 (forced)
@@ -466,6 +467,34 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
 #endif
         if (ntiles > 0x7fffffffLL) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "envelope grid too large");
         const int64_t all = ntiles;
+        if (probe_out && dec && h->probe_window) {
+            // the window statistic (k_probe_window): thresholds up to 81 = windows up to radius 8
+            const int thr = h->far_thr[stage - 2], thr2 = stage == 2 ? h->mid_thr_y : 0, thr3 = stage == 2 ? h->far_thr[1] : 0;
+            int W = 0;
+            while ((W + 1) * (W + 1) < std::max(thr, std::max(thr2, thr3))) ++W;
+            const bool handoff_in = ex && ex->i32_flag;                      // p16 shape: int32 values only behind the flag, which ends the probe
+            const int32_t* in32 = (stage == 3 && ex && ex->in_i32 && !handoff_in) ? ex->in_i32 : nullptr;
+            const int16_t* in16 = in32 ? nullptr : d_in16;
+            if (W <= 8 && (in16 || in32)) {
+                ProbeArgs pa{};
+                pa.in16 = in16; pa.in32 = in32;
+                pa.n = nx * ny * nz; pa.ls = a.line_stride; pa.L = a.L; pa.W = W;
+                pa.thr = thr; pa.thr2 = thr2; pa.thr3 = thr3;
+                pa.nsamples = (uint32_t)std::min<int64_t>(pa.n, 32768);
+                pa.step = std::max<int64_t>(1, pa.n / pa.nsamples);
+                if (pa.step > 0xffffff) pa.step = 0xffffff;                 // (the kernel hashes the offset inside a stretch in 24 bits)
+                pa.probe_out = probe_out; pa.guard = guard; pa.i32_flag = handoff_in ? ex->i32_flag : nullptr;
+                pa.decide_small = h->d_small; pa.decide_stage = dec->stage; pa.decide_dense_tried = dec->dense_tried ? 1 : 0;
+                pa.decide_force = h->force_env; pa.decide_den = h->far_den[dec->stage]; pa.decide_handoff = dec->handoff ? 1 : 0;
+                pa.decide_mid_den = (dec->stage == 0 && dec->window_choice) ? h->mid_den_y : 0;
+                pa.decide_xden = h->far_den[1];
+                const unsigned nb = (pa.nsamples + 255u) / 256u;
+                if (stage == 2) hipLaunchKernelGGL(k_probe_window<2>, dim3(nb), dim3(256), 0, s, pa);
+                else hipLaunchKernelGGL(k_probe_window<3>, dim3(nb), dim3(256), 0, s, pa);
+                HIP_TRY(h, hipGetLastError());
+                return SDFGPU_OK;
+            }
+        }
         if (probe_out) {                                        // sample ~256 tiles spread over the grid, store nothing
             a.probe_stride = (int)std::max<int64_t>(1, std::min<int64_t>(64, ntiles / 256));
             a.probe_thr = h->far_thr[stage - 2];
@@ -1698,6 +1727,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "fused_window") h->fused_h = value;
     else if (n == "plane16") h->plane16_on = value != 0;
     else if (n == "y16") h->y16_on = value != 0;
+    else if (n == "probe_window") h->probe_window = value != 0;
     else if (n == "z_wave") h->z_wave_on = value != 0;
     else if (n == "dense") h->dense_on = value != 0;
     else if (n == "dense_generic") h->dense_generic_on = value != 0;

@@ -197,6 +197,87 @@ __device__ __forceinline__ void probe_done(const EnvDcArgs& a) {
     }
 }
 
+// The probe as a window statistic (round 3).  What the tier decision needs is the share of free voxels whose distance
+// after this sweep is still >= thr (16 for y, 9 for x): small thresholds, and "d^2 >= thr" is decided exactly by the
+// candidates within |offset| < sqrt(thr) along the axis -- 2 W + 1 values of the sweep's own input per sampled voxel, no
+// tile staging, no search.  One lane per sample, ~32 k samples spread over the grid, one set of atomics per workgroup, the
+// last workgroup turns the counters into the decision (decide_tier): 7 us instead of the 25 us of level A on 256 sampled
+// tiles.  (k_envelope_dc keeps its probe mode for thresholds above 81.)
+struct ProbeArgs {
+    const int16_t* in16;      // z field (stage 2) / 16-bit plane field (stage 3), or nullptr
+    const int32_t* in32;      // int32 plane field (stage 3 of shapes without the 16-bit one), or nullptr
+    int64_t n, ls, step;      // voxels, line stride, sample stride
+    int L, W;                 // positions along the axis, window radius
+    int thr, thr2, thr3;
+    uint32_t nsamples;
+    uint32_t* probe_out;      // status word 12 (see decide_tier)
+    const uint32_t* guard;    // nullptr: always run; else run iff *guard != 0
+    const uint32_t* i32_flag; // stage 3: non-zero = the y probe chose the int32 hand-off, the x tier is decided
+    uint32_t* decide_small;
+    int decide_stage, decide_dense_tried, decide_force, decide_den, decide_handoff, decide_mid_den, decide_xden;
+};
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_probe_window(const ProbeArgs a) {
+    __shared__ uint32_t cnt[4];
+    const int t = threadIdx.x;
+    bool run = true;
+    if (a.guard && *a.guard == 0u) run = false;
+    if (STAGE == 3 && a.i32_flag && *a.i32_flag != 0u) run = false;
+    if (STAGE == 3 && __hip_atomic_load(a.decide_small + 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) run = false;   // settled by the y probe
+    if (run) {                                                  // (block-uniform)
+        if (t < 4) cnt[t] = 0u;
+        __syncthreads();
+        const uint32_t sidx = blockIdx.x * 256u + (uint32_t)t;
+        int far = 0, tot = 0, mid = 0, x9 = 0;
+        if (sidx < a.nsamples) {
+            // one sample in every stretch of `step` voxels, at a hashed offset inside it (a plain stride is a multiple of the row
+            // length on power-of-two grids: every sample on the z = 0 face)
+            const int64_t idx = (int64_t)sidx * a.step + (int64_t)(((sidx * 0x9E3779B1u) >> 8) % (uint32_t)a.step);
+            const int p = (int)((idx / a.ls) % a.L);
+            auto value = [&](int64_t i) -> int {
+                if (a.in32) return a.in32[i];
+                return (int)a.in16[i];
+            };
+            const int c = value(idx);
+            if (c > 0) {                                        // a free voxel: distance to the nearest filled one
+                int D = kInf32;
+                for (int d = -a.W; d <= a.W; ++d) {
+                    const int q = p + d;
+                    if (q < 0 || q >= a.L) continue;
+                    const int v = value(idx + (int64_t)d * a.ls);
+                    int f;
+                    if (v <= 0) f = 0;
+                    else if (STAGE == 2) f = v >= kInf16 ? kInf32 : v * v;          // z distances
+                    else f = (!a.in32 && v >= 32767) ? kInf32 : imin(v, kInf32);   // squared in-plane distances (16-bit: saturated)
+                    D = imin(D, f >= kInf32 ? kInf32 : f + d * d);
+                }
+                tot = 1;
+                far = D >= a.thr ? 1 : 0;
+                mid = (a.thr2 > 0 && D >= a.thr2) ? 1 : 0;
+                x9 = (a.thr3 > 0 && D >= a.thr3) ? 1 : 0;
+            }
+        }
+        const uint32_t bf = (uint32_t)__popcll(__ballot(far)), bt = (uint32_t)__popcll(__ballot(tot));
+        const uint32_t bm = (uint32_t)__popcll(__ballot(mid)), bx = (uint32_t)__popcll(__ballot(x9));
+        if ((t & 63) == 0) { atomicAdd(&cnt[0], bf); atomicAdd(&cnt[1], bt); atomicAdd(&cnt[2], bm); atomicAdd(&cnt[3], bx); }
+        __syncthreads();
+        if (t == 0) {
+            atomicAdd(a.probe_out, cnt[0]); atomicAdd(a.probe_out + 1, cnt[1]);
+            if (a.thr2 > 0) atomicAdd(a.probe_out - 1, cnt[2]);
+            if (a.thr3 > 0) atomicAdd(a.probe_out + 5, cnt[3]);
+        }
+    }
+    if (t == 0) {                                               // every workgroup passes here once: the last one decides
+        __threadfence();
+        if (atomicAdd(a.decide_small + 16, 1u) == gridDim.x - 1u) {
+            __threadfence();
+            decide_tier(a.decide_small, a.decide_stage, a.decide_dense_tried, a.decide_force, 1, a.decide_den, a.decide_handoff,
+                        a.decide_mid_den, a.decide_xden);
+            a.decide_small[16] = 0u;
+        }
+    }
+}
+
 // NL lines per tile, NT lanes: S = NT / NL lanes ("slots") per line.  The kernel is sensitive to how many WORKGROUPS a CU
 // holds (their phases interleave; 2 instead of 4 per CU is 1.55x slower), and that number is set by the LDS footprint:
 // 16 lines x 512 positions x 4 B of keys = 39 KB -> 4 per CU; 8 lines -> 20 KB -> 7 - 8 per CU.
