@@ -339,7 +339,10 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * y sweep and 9, 24 for the x sweep), "mid_threshold_y" / "mid_fraction_den_y" (near-field y sweep: radius-8 marching
  * windows when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 24; den 0 = always the radius-3 window), "i32_handoff" (1 = when the y probe finds the scene far-field, the x sweep is the
  * far-field kernel too and takes an exact int32 plane field from the y sweep, default; 0 = 16-bit plane field + side
- * table between them and a probe of its own for the x axis).  Every option leaves the results exact: switches that
+ * table between them and a probe of its own for the x axis), "probe_window" (1 = the tier probes are window statistics
+ * over ~32 k sampled voxels, default; 0 = level A of the far-field search on sampled tiles), "y16" (1 = the y sweep of
+ * the 16-bit pipeline through the packed 16-bit kernel, default; 0 = the 32-bit marching kernel), "z_wave" (1 = z sweep
+ * with whole rows per wave where nz is 64 ... 1024 and a power of two, default; 0 = the workgroup form).  Every option leaves the results exact: switches that
  * skip work for profiling ("dc_debug", "ball_variant") exist only in libraries built with -DSDFGPU_DEBUG_HOOKS and are
  * rejected with SDFGPU_ERR_INVALID_ARGUMENT by the shipped one. */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);

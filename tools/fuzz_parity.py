@@ -59,6 +59,8 @@ while time.time() - t0 < budget:
     ctx.set_option("envelope_mode", 1 if rng.random() < 0.2 else 0)
     ctx.set_option("far_threshold_y", int(rng.choice([1, 4, 64])))
     ctx.set_option("far_threshold_x", int(rng.choice([1, 9, 25])))
+    ctx.set_option("probe_window", int(rng.random() < 0.7))      # window statistic / level A on sampled tiles
+    ctx.set_option("z_wave", int(rng.random() < 0.8))
     got, ext = ctx.build(m, res, vb)
     want, want_ext, _ = O.exact_sdf(m, res, vb)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
