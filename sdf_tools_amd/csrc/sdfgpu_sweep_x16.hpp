@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
 
     uint32_t WP[R][NP], WQ[R][NP];       // window, packed u16 pairs
     int mxF = 0, mxQ = 0;
+    uint32_t mxF16 = 0u, mxQ16 = 0u;     // ... of the rows the window decided alone: packed halves, folded into mxF / mxQ at the end
     bool unresolved = false;
     bool far = false;
 
@@ -214,6 +215,30 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
         uint32_t worst = pk_max_u16(best[0], best[1]);
         if constexpr (V == 8) worst = pk_max_u16(worst, pk_max_u16(best[2], best[3]));
         const bool need = ((worst & 0xffffu) >= kLim) || ((worst >> 16) >= kLim);
+        const bool any_need = __any(need);
+        if constexpr (!VB && !SLAB) {
+            if (!any_need) {
+                // Every voxel of the wave decided by the window (all values < (H+1)^2): finish from the packed values -- maxima
+                // tracked as packed halves per class, distance from the table, sign bit from the class mask.  4 VALU
+                // instructions and one LDS read per voxel instead of ~15.
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const uint32_t nfree = ~mfree[j];
+                    mxF16 = pk_max_u16(mxF16, best[j] & mfree[j]);
+                    mxQ16 = pk_max_u16(mxQ16, best[j] & nfree);
+                    const float f0 = lut[best[j] & 0xffffu], f1 = lut[best[j] >> 16];
+                    o[2 * j] = __uint_as_float(__float_as_uint(f0) ^ (nfree << 31));
+                    o[2 * j + 1] = __uint_as_float(__float_as_uint(f1) ^ (nfree & 0x80000000u));
+                }
+                if (valid) {
+                    float4* dst = reinterpret_cast<float4*>(a.out + base + (int64_t)(p - a.out_lo) * ls);
+#pragma unroll
+                    for (int q = 0; q < V / 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+                }
+                return;
+            }
+        }
         int D[V];
         bool filled[V];
         int inexact = 0;
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
             D[k] = (int)((best[k >> 1] >> (16 * (k & 1))) & 0xffffu);
             filled[k] = ((mfree[k >> 1] >> (16 * (k & 1))) & 1u) == 0u;
         }
-        if (__any(need)) {
+        if (any_need) {
             // exact 32-bit outward scan for the voxels the window did not decide (out of line)
             ExactScan<V> st;
 #pragma unroll
@@ -318,6 +343,8 @@ __global__ __launch_bounds__(kBlock) void k_sweep_x16(const SweepX16Args a) {
         while (pb < p1) { slow_batch(pb); pb += R; }
     }
 
+    mxF = max(mxF, (int)max(mxF16 & 0xffffu, mxF16 >> 16));
+    mxQ = max(mxQ, (int)max(mxQ16 & 0xffffu, mxQ16 >> 16));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         mxF = max(mxF, __shfl_xor(mxF, off));
