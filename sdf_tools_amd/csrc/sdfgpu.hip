@@ -286,6 +286,16 @@ int launch_sweep_y(sdfgpu_handle h, const int16_t* d_in, void* d_out, int32_t* d
     a.line_stride = nz;
     a.L = (int)ny; a.out_lo = 0; a.out_hi = (int)ny;
     a.T = pick_T(h->tune_ty, (int)ny);
+    if (h->tune_ty <= 0 && vec4 && d_side && h->y16_on) {
+        // K2/16: chunks of 16 batches of 7 rows while the launch still fills the device.  Measured at 512^3 (rocprofv3):
+        // 56 rows 131 us, 64 rows 138, 112 rows 122, 119 / 126 rows 123 - 125, 128 rows 132 -- with a power-of-two chunk the
+        // workgroups, which march in step, read addresses that differ by multiples of 64 KB only.
+        const int64_t nbx = (a.ncols + kBlock - 1) / kBlock;
+        for (int t : {112, 56, 28}) {
+            a.T = std::min(t, (int)ny);
+            if (nbx * ((ny + t - 1) / t) >= 1024) break;
+        }
+    }
     return launch_march<2, false>(h, a, vec4, s, force_window);
 }
 
