@@ -11,7 +11,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); exit(1); } } while (0)
 
 template <int NLN, int NT, int STORE>      // STORE 0: chunk mapping (lane = line, slot of 8 positions); 1: row mapping; 2: chunk mapping, input TILE-MAJOR (a tile's rows contiguous)
-__global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* __restrict__ out, int L, uint32_t ls, int xcd_order) {
+__global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* __restrict__ out, int L, uint32_t ls, int xcd_order, uint32_t pad_in = 0, uint32_t pad_out = 0) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int pitch = L + 2;
     const int t = threadIdx.x;
@@ -22,7 +22,8 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
     }
     const int64_t base = tile * NLN;
     const int* ip = STORE == 2 ? in + tile * (int64_t)NLN * L : in + base;
-    const uint32_t lsi = STORE == 2 ? (uint32_t)NLN : ls;
+    const uint32_t lsi = STORE == 2 ? (uint32_t)NLN : ls + pad_in;
+    const uint32_t lso = ls + pad_out;
     float* op = out + base;
     constexpr int LPR = NLN / 4;            // lanes per row
     constexpr int PP = NT / LPR;            // rows per load round
@@ -51,26 +52,26 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
         for (int i0 = 0; i0 < L / 8; i0 += S) {
             const int p0 = 8 * (i0 + slot);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) op[(uint32_t)line + (uint32_t)(p0 + k) * ls] = (float)smem[line * pitch + p0 + k] * 0.01f;
+            for (int k = 0; k < 8; ++k) op[(uint32_t)line + (uint32_t)(p0 + k) * lso] = (float)smem[line * pitch + p0 + k] * 0.01f;
         }
     } else {
         const int line = t % NLN, rr = t / NLN;
         constexpr int S = NT / NLN;
-        for (int p = rr; p < L; p += S) op[(uint32_t)line + (uint32_t)p * ls] = (float)smem[line * pitch + p] * 0.01f;
+        for (int p = rr; p < L; p += S) op[(uint32_t)line + (uint32_t)p * lso] = (float)smem[line * pitch + p] * 0.01f;
     }
 }
 
 template <int NLN, int NT, int STORE>
-float run(const int* in, float* out, int n, int xcd) {
+float run(const int* in, float* out, int n, int xcd, uint32_t pad_in = 0, uint32_t pad_out = 0) {
     const int L = n;
     const uint32_t ls = (uint32_t)n * n;
     const unsigned ntiles = (unsigned)((int64_t)n * n / NLN);
     const size_t lds = (size_t)NLN * (L + 2) * 4;
     CK(hipFuncSetAttribute((const void*)k_tile<NLN, NT, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd, pad_in, pad_out);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd, pad_in, pad_out);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / 10;
@@ -85,7 +86,7 @@ int main() {
     const int n = 512;
     const size_t N = (size_t)n * n * n;
     int* in; float* out;
-    CK(hipMalloc(&in, N * 4)); CK(hipMalloc(&out, N * 4));
+    CK(hipMalloc(&in, N * 4 + (64u << 20))); CK(hipMalloc(&out, N * 4 + (64u << 20)));
     CK(hipMemset(in, 1, N * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_copy, dim3((unsigned)(N / 4 / 256)), dim3(256), 0, 0, (const int4*)in, (float4*)out, N / 4);
@@ -94,7 +95,11 @@ int main() {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("linear copy 4+4 B/voxel: %.4f ms\n", ms / 10);
-    for (int xcd = 1; xcd >= 0; --xcd) {
+    // plane stride padded (the probe's question in round 3: do the rows of a tile, 1 MiB apart, camp on one HBM channel?)
+    for (uint32_t pad : {0u, 16u, 64u, 1024u, 4096u + 64u}) {
+        printf("pad %u elements: in only %.4f ms, in + out %.4f ms (16 lines x 256 lanes, chunk stores)\n", pad, run<16, 256, 0>(in, out, n, 1, pad, 0), run<16, 256, 0>(in, out, n, 1, pad, pad));
+    }
+    for (int xcd = 1; xcd >= 1; --xcd) {
         printf("xcd_order=%d\n", xcd);
         printf("  16 lines x 256 lanes, chunk stores: %.4f ms\n", run<16, 256, 0>(in, out, n, xcd));
         printf("  16 lines x 256 lanes, row stores:   %.4f ms\n", run<16, 256, 1>(in, out, n, xcd));
