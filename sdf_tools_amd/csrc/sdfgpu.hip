@@ -499,8 +499,10 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
                 pa.decide_mid_den = (dec->stage == 0 && dec->window_choice) ? h->mid_den_y : 0;
                 pa.decide_xden = h->far_den[1];
                 const unsigned nb = (pa.nsamples + 255u) / 256u;
-                if (stage == 2) hipLaunchKernelGGL(k_probe_window<2>, dim3(nb), dim3(256), 0, s, pa);
-                else hipLaunchKernelGGL(k_probe_window<3>, dim3(nb), dim3(256), 0, s, pa);
+                if (stage == 2 && W <= 3) hipLaunchKernelGGL((k_probe_window<2, 3>), dim3(nb), dim3(256), 0, s, pa);
+                else if (stage == 2) hipLaunchKernelGGL((k_probe_window<2, 8>), dim3(nb), dim3(256), 0, s, pa);
+                else if (W <= 3) hipLaunchKernelGGL((k_probe_window<3, 3>), dim3(nb), dim3(256), 0, s, pa);
+                else hipLaunchKernelGGL((k_probe_window<3, 8>), dim3(nb), dim3(256), 0, s, pa);
                 HIP_TRY(h, hipGetLastError());
                 return SDFGPU_OK;
             }
