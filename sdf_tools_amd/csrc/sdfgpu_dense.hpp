@@ -97,6 +97,7 @@ struct DenseArgs {
     int log2_ty;
     int inv_hy;             // ceil(65536 / (ty + 4)): row / hy = (row * inv_hy) >> 16 for row < 4096
     float mag[8];           // float(sqrt(double(level d^2)) * resolution) per level; [7] = 0 (not found)
+    float mag3[16];         // ... of the 13 levels of KD3 (sdfgpu_dense3.hpp); [13..15] = 0
     uint32_t* slots;        // [kSlots][kSlotWords]: per-slot {max d^2 free, max d^2 filled}, see slot_max2 / k_fold_slots
     uint32_t* uncertified;  // set to 1 if some voxel has no opposite-class voxel within d^2 <= 8
     // fix-up mode (k_ball_fixup runs behind this launch): instead of raising `uncertified`, a wave that holds
@@ -403,13 +404,21 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
 // the nearest in-grid voxel exactly as in KD); anything else -- or a tile with more than kFixCap undecided
 // voxels (p = 0.03 leaves 6 % undecided: KF would take 2.5 ms where the sweeps take 1.1) -- raises `uncertified` and the guarded general sweeps redo the grid, so results are exact for any input.
 // ---------------------------------------------------------------------------------------------
-constexpr int kFixR = 6;
+constexpr int kFixR = 8;                                      // (round 3: 6 -> 8.  At 512^3 the LARGEST distance of a Bernoulli p = 0.03 / 0.04
+                                                              //  scene is d^2 = 40 .. 41 on two seeds of three: one voxel beyond 36 sent the whole
+                                                              //  grid to the sweeps.  The rows go past sorted by dx^2 + dy^2 with an early exit, so
+                                                              //  the voxels that never needed the outer rows do not pay for them)
 constexpr int kFixCap = 512;                                  // undecided voxels a tile may hand to KF (round 3: 160 -> 512 with the
                                                               // early exit below: Bernoulli p = 0.05 leaves 0.9 % undecided -- ~280 per
                                                               // tile -- and took the marching sweeps at 0.84 ms instead; p = 0.03 leaves
                                                               // 6 %, ~2000 per tile: there the sweeps are cheaper and the cap sends it on)
 constexpr int kFixDirect = 24;                                // tiles with at most this many undecided voxels read the bit field directly
-constexpr int kFixRows = (2 * kFixR + 1) * (2 * kFixR + 1);   // 169 (dx, dy) rows
+constexpr int kFixTileR = 6;                                  // halo of the staged LDS tile; the rows beyond it (dx^2 + dy^2 >= 49: the last
+                                                              // two batches, reached by the few voxels still open then) come from the L2-resident
+                                                              // bit field -- a halo of 8 made the staging of every tile 1.56x larger (p = 0.05:
+                                                              // 0.46 -> 0.58 ms per build)
+constexpr int kFixRows = (2 * kFixR + 1) * (2 * kFixR + 1);   // 289 (dx, dy) rows
+constexpr int kFixOrderPad = (kFixRows + 7) & ~7;             // LDS words reserved for the row table
 
 struct FixArgs {
     const uint32_t* bits;   // [rows_x][ny][nzw]
@@ -438,9 +447,9 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     const int t = threadIdx.x;
     const int nzw = a.nzw, lg = a.log2_nzw;
     const int rw = nzw + 2;                                   // one replicated edge word on each side
-    const int hx = a.tx + 2 * kFixR, hy = a.ty + 2 * kFixR;
+    const int hx = a.tx + 2 * kFixTileR, hy = a.ty + 2 * kFixTileR;
     uint32_t* order = reinterpret_cast<uint32_t*>(fix_smem);  // [kFixRows] (+ pad)
-    uint32_t* list = order + 176;                             // [kFixCap] (tile row << 16) | z
+    uint32_t* list = order + kFixOrderPad;                    // [kFixCap] (tile row << 16) | z
     uint32_t* count = list + kFixCap;                         // [1] (+ pad to 4 words)
     uint32_t* tile = count + 4;                               // [hx][hy][rw]
     if (t == 0) { *count = 0u; a.tileflag[tile_id] = 0u; }
@@ -485,8 +494,8 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
                     for (int k = 0; k < 4; ++k) {
                         const int row = min(row0 + k * rpp, nrows - 1);
                         const int jx = row / hy, jy = row - jx * hy;
-                        const int gx = min(max(x0 + jx - kFixR, 0), a.rows_x - 1);
-                        const int gy = min(max(y0 + jy - kFixR, 0), a.ny - 1);
+                        const int gx = min(max(x0 + jx - kFixTileR, 0), a.rows_x - 1);
+                        const int gy = min(max(y0 + jy - kFixTileR, 0), a.ny - 1);
                         const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
                         v[k] = src[min(max(ws - 1, 0), nzw - 1)];
                     }
@@ -529,10 +538,10 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         const int r = (int)(e >> 16), z = (int)(e & 0xffffu);
         const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
         const int w = z >> 5, b = z & 31;
-        const uint32_t* c0 = tile + ((tx_ + kFixR) * hy + (ty_ + kFixR)) * rw + (w + 1);
+        const uint32_t* c0 = tile + ((tx_ + kFixTileR) * hy + (ty_ + kFixTileR)) * rw + (w + 1);
         // the three words around bit b of row (dx, dy); rows / edge words beyond the grid replicate the nearest in-grid voxel
         auto words = [&](int dx, int dy, uint32_t& prev, uint32_t& cur, uint32_t& next) {
-            if (!direct) {
+            if (!direct && dx >= -kFixTileR && dx <= kFixTileR && dy >= -kFixTileR && dy <= kFixTileR) {
                 const uint32_t* p = c0 + (dx * hy + dy) * rw;
                 prev = p[-1]; cur = p[0]; next = p[1];
             } else {

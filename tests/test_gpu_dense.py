@@ -79,6 +79,7 @@ def test_every_level_of_the_ball(gpu):
     _check(gpu, m, 0.25, expect_certified=True)
     m = np.zeros((9, 9, 32), np.uint8)
     m[::4, ::4, ::4] = 1                                # (2,2,2) away -> d^2 = 12 > 8: must fall back
+    gpu.set_option("policy_reset", 1)                   # (KD alone: the builds above have taught the handle to escalate)
     _check(gpu, m, 0.25, expect_certified=False)
 
 
@@ -172,15 +173,15 @@ def test_reference_grid_shapes_take_the_dense_tier(gpu, shape):
 
 
 def test_dense_retry_policy_skips_and_retries(gpu):
-    """An uncertified dense attempt is first retried with the fix-up kernel; if that cannot certify the scene
-    either, the dense kernels are left out of the next builds and tried again every dense_retry-th build.
-    Results stay exact all along."""
+    """An uncertified dense attempt is first retried with the fix-up stage (the wide ball kernel KD3 + the fix-up kernel);
+    if that cannot certify the scene either, the dense kernels are left out of the next builds and tried again every
+    dense_retry-th build.  Results stay exact all along."""
     gpu.set_option("dense_retry", 4)
     sparse = synth.bernoulli_mask((16, 16, 64), 0.002, 9)
     dense = synth.bernoulli_mask((16, 16, 64), 0.5, 9)
     ex_s, ext_s, _ = O.exact_sdf(sparse, 0.1)
     ex_d, ext_d, _ = O.exact_sdf(dense, 0.1)
-    for _ in range(2):                                   # plain attempt, then the attempt with the fix-up kernel
+    for _ in range(2):                                   # plain attempt, then the attempt with the fix-up stage
         sdf, ext = gpu.build(sparse, 0.1)
         assert np.array_equal(sdf, ex_s) and ext == ext_s
         assert gpu.last_build_info()["dense"] and not gpu.last_dense_certified()
@@ -240,6 +241,68 @@ def test_fixup_kernel_edges_and_every_shape(gpu):
             ex, ex_ext, _ = O.exact_sdf(m, 0.3)
             assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)), shape
             assert ext == ex_ext
+
+
+def test_wide_ball_kernel_every_level_edges_and_shapes(gpu):
+    """KD3 (|offset| <= 3, levels d^2 in {1..6, 8..14}) forced in KD's place: lattices that realise every level, a single
+    voxel (hand-over beyond the ball), grid faces / word boundaries / odd tile shapes, both classes."""
+    def run(m, res, expect_certified=None):
+        gpu.set_option("policy_reset", 1)
+        gpu.set_option("dense3_mode", 1)
+        return _check(gpu, m, res, expect_certified)
+    try:
+        m = np.zeros((9, 9, 32), np.uint8)
+        m[::4, ::4, ::4] = 1                                # (2,2,2) away -> d^2 = 12: inside the wide ball
+        run(m, 0.25, True)
+        run(1 - m, 0.25, True)
+        m = np.zeros((12, 12, 64), np.uint8)
+        m[::6, ::6, ::6] = 1                                # (3,3,3) away -> d^2 = 27 > 14 for a third of the voxels: too many for
+        run(m, 1.0, False)                                  # the fix-up kernel, the kernel says so itself (kBall3MaxUndecided per wave)
+        m = synth.bernoulli_mask((24, 24, 128), 0.08, 11)
+        m[8:14, 8:14, 40:46] = 0                            # a 6^3 cavity: d^2 up to 27 for a few voxels -> KF finishes them
+        run(m, 1.0, True)
+        m = np.zeros((11, 11, 64), np.uint8)
+        m[::5, ::5, ::5] = 1                                # up to (2,2,2) = 12 inside; (2,2,3) = 17 at z = 63: a few voxels for KF
+        run(m, 0.5, True)
+        for shape in ((9, 9, 32), (7, 7, 64)):
+            one = scenes.single_voxel(shape)                # every d^2 of the ball and everything beyond
+            run(one, 1.0, False)
+            run(1 - one, 1.0, False)
+        for shape in ((5, 7, 32), (9, 4, 128), (3, 5, 1024), (33, 21, 96), (1, 40, 64), (2, 3, 2048), (16, 16, 512)):
+            for p in (0.05, 0.03, 0.95):
+                m = synth.bernoulli_mask(shape, p, 7)
+                m[0, 0, 0] = 1 - m[0, 0, 0]
+                run(m, 0.3)
+    finally:
+        gpu.set_option("policy_reset", 1)
+
+
+def test_policy_escalates_to_the_wide_ball_kernel(gpu):
+    """Bernoulli p = 0.03: KD leaves 6 % of the voxels undecided (more than KF takes), KD3 leaves 2e-3: the handle goes
+    KD -> KD3 + KF and is certified from the second build on; exact at every step.  With the option off (KD + KF) it
+    backs off to the sweeps instead."""
+    shape = (64, 64, 128)
+    m = synth.bernoulli_mask(shape, 0.03, 3)
+    ex, ex_ext, _ = O.exact_sdf(m, 0.05)
+    gpu.set_option("policy_reset", 1)
+    certified = []
+    for _ in range(5):
+        sdf, ext = gpu.build(m, 0.05)
+        assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)) and ext == ex_ext
+        certified.append(gpu.last_dense_certified())
+    assert certified == [False, True, True, True, True], certified
+    gpu.set_option("dense3", 0)
+    try:
+        gpu.set_option("policy_reset", 1)
+        certified = []
+        for _ in range(4):
+            sdf, ext = gpu.build(m, 0.05)
+            assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)) and ext == ex_ext
+            certified.append(gpu.last_dense_certified())
+        assert not any(certified)
+    finally:
+        gpu.set_option("dense3", 1)
+        gpu.set_option("policy_reset", 1)
 
 
 def test_profiling_levels_and_stage_entry_points_fold(gpu):
