@@ -510,6 +510,11 @@ def main():
                 torch, capi, dev, shape, res, sparse, {}, leg_steps, 20,
                 "%dx%dx%d Bernoulli(p=0.01), 2 grids in rotation, default policy" % shape)
             del sparse
+            mid = [synth.bernoulli_mask_torch(shape, 0.03, 21 + k, device=dev) for k in range(2)]
+            legs["mid_bernoulli_p0.03"] = run_leg(
+                torch, capi, dev, shape, res, mid, {}, leg_steps, 20,
+                "%dx%dx%d Bernoulli(p=0.03), 2 grids in rotation, default policy (the dense tier's wide form KD3 + fix-up kernel)" % shape)
+            del mid
             if shape == (512, 512, 512):
                 legs["streaming_two_box"] = streaming_leg(torch, dev, 512, 0.01, 30)
         except Exception as e:                     # a leg must never take the contract line down with it
