@@ -31,7 +31,7 @@ while time.time() - t0 < budget:
         continue
     kind = rng.integers(0, 4)
     if kind == 0:
-        m = synth.bernoulli_mask(shape, float(rng.choice([0.5, 0.3, 0.1, 0.01, 0.001, 0.9, 0.99, 0.999])), int(rng.integers(1 << 30)))
+        m = synth.bernoulli_mask(shape, float(rng.choice([0.5, 0.3, 0.1, 0.05, 0.03, 0.02, 0.01, 0.001, 0.9, 0.96, 0.99, 0.999])), int(rng.integers(1 << 30)))
     elif kind == 1:
         m = synth.spheres_mask(shape, int(rng.integers(1, 5)), (1, 9), int(rng.integers(1 << 30)))
     elif kind == 2:
