@@ -2,7 +2,7 @@
 """One process per GPU over RCCL (torch.distributed backend "nccl"): the x-slab builder of sdf_tools_amd/slab.py on every
 tier -- dense (2 bit-plane halos), near-field general path (int32 halos), far-field (re-partition x slabs -> y slabs and
 back), virtual border -- each rank's slab compared bit for bit with the same rows of a single-GPU build of the whole grid
-made on that rank's own GPU through the C ABI.  Launched by tests/test_gpu_multi.py under torch.distributed.run when the
+made on that rank's own GPU through the C ABI.  Launched by tests/test_gpu_zz_multi_gpu_hardware.py under torch.distributed.run when the
 box has >= 2 GPUs; prints "SLAB_NCCL_OK world=<n>" from rank 0 on success, exits non-zero on the first mismatch."""
 import os
 import sys
