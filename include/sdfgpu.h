@@ -332,7 +332,8 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * default 16, 0 = always try), "fixup" (the fix-up kernel behind the dense ball kernel for almost-dense
  * scenes, default 1), "fixup_mode" (force the policy state that launches it with the next build), "dense3" (1 = the
  * fix-up stage starts with the wide ball kernel KD3, |offset| <= 3, in the dense kernel's place where the shape allows
- * it, default; 0 = the dense kernel + the fix-up kernel), "dense3_mode" (KD3 + the fix-up kernel with every dense build),
+ * it, default; 0 = the dense kernel + the fix-up kernel), "dense3_mode" (KD3 + the fix-up kernel with every dense build), "dense3_staged" (1 = a dense build that does not expect the
+ * dense kernel to decide the scene enqueues KD3 + the fix-up kernel behind it, guarded on its verdict, default),
  * "march_window" / "x16_window" = 8 (force the radius-8 register windows of the y / x marching sweeps;
  * the y window is otherwise chosen by the probe), "dense_generic" (1 = shapes the tuned dense kernels do not take -- nz not 32 * 2^k, virtual border -- use their
  * generic forms, default; 0 = such shapes skip the dense tier), "envelope_dc" (1 = the far-field kernel k_envelope_dc

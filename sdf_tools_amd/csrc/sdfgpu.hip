@@ -76,6 +76,8 @@ struct sdfgpu_context {
     int fix_clean = 0;            // consecutive fix-mode builds that needed no fix (the mode is left after 8)
     int dense3_on = 1;            // KD3 (ball kernel with |offset| <= 3) in KD's place whenever the fix-up kernel runs (option "dense3")
     bool dense3_mode = false;     // option "dense3_mode": KD3 + KF with every dense build (tests)
+    int dense3_staged = 1;        // a build that does not expect KD to decide the scene enqueues KD3 + KF behind KD, guarded on KD's verdict (option "dense3_staged")
+    bool prev_staged = false;
     int dense_retry = 16;         // after an uncertified dense attempt, try the dense kernels again every N-th build (0 = always)
     int dense_skip = 0;           // builds left that skip the dense kernels
     int dense_backoff = 0;        // current length of that pause: doubles while the attempts keep failing (a caller that
@@ -607,7 +609,8 @@ int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s, uint32_t* res
 
 int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int64_t rows_x, int64_t out_lo, int64_t out_hi,
                       int64_t ny, int64_t nz, double resolution, uint32_t* d_maxdsq, uint32_t* d_uncert, hipStream_t s,
-                      uint32_t* d_fix_needed = nullptr, bool early_out = false, int vb = 0, int64_t nx_glob = 0, int radius = 2) {
+                      uint32_t* d_fix_needed = nullptr, bool early_out = false, int vb = 0, int64_t nx_glob = 0, int radius = 2,
+                      const uint32_t* d_guard = nullptr) {
     const int R = radius == 3 ? kBall3R : kBallR;                   // 3: KD3 (sdfgpu_dense3.hpp; whole-grid builds without virtual border only)
     DenseArgs a{};
     a.early_out = early_out ? 1 : 0;
@@ -638,6 +641,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     for (int l = 0; l < 16; ++l) a.mag3[l] = l < 13 ? (float)(std::sqrt((double)level3_d2[l]) * resolution) : 0.0f;
     a.slots = h->d_slots; a.uncertified = d_uncert;
     a.nt_store = h->nt_store;
+    a.guard = d_guard;
     const int64_t gx = (ny + a.ty - 1) / a.ty, gy = (out_hi - out_lo + a.tx - 1) / a.tx;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
     const size_t pitch = a.nzw < 32 ? a.nzw + 32 : a.nzw + 2;        // must match k_ball_dense
@@ -755,14 +759,15 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         //   (the fix-up stage = KD3 + KF where the shape allows it -- the ball kernel with |offset| <= 3 costs what KD costs
         //   on the scenes KD decides and leaves KF 1/50 of the voxels: 0.20 instead of 0.47 ms at p = 0.05 -- else KD + KF)
         if (h->prev_dense && h->fixup_on && !h->prev_generic) {
-            if (!h->prev_fix_mode) { h->fix_mode = h->h_flags[3] != 0; h->fix_clean = 0; }   // uncertified without KF: try KF next
+            //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict in word 20)
+            if (!h->prev_fix_mode) { h->fix_mode = h->h_flags[h->prev_staged ? 20 : 3] != 0; h->fix_clean = 0; }   // KD alone could not: the fix-up stage next
             else if (h->h_flags[3] != 0) h->fix_mode = false;                      // KF could not certify it either
             else {                                                                 // keep KF while it is needed (left after
                 h->fix_clean = h->h_flags[6] != 0 ? 0 : h->fix_clean + 1;          // 8 clean builds in a row: a scene at the
                 if (h->fix_clean >= 8) { h->fix_mode = false; h->fix_clean = 0; }  // edge of the ball must not flap)
             }
         }
-        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || !h->fixup_on || h->prev_generic)) {
+        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || h->prev_staged || !h->fixup_on || h->prev_generic)) {
             h->dense_backoff = h->dense_backoff ? std::min(255, 2 * h->dense_backoff + 1) : h->dense_retry - 1;
             h->dense_skip = h->dense_backoff;
         }
@@ -827,7 +832,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     HIP_TRY(h, mark(0));
     // Dense path first: exact wherever the nearest opposite voxel is within d^2 <= 8; raises
     // d_small[3] otherwise, in which case (and only then) the general pipeline below does any work.
-    bool cur_fix_mode = false, cur_dense3 = false;
+    bool cur_fix_mode = false, cur_dense3 = false, cur_staged = false;
     h->last_dense = dense;
     h->guard = nullptr;
     if (dense && dense_generic) {
@@ -848,9 +853,17 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         // ... with KD3 (the wider ball, sdfgpu_dense3.hpp) in KD's place where the shape allows it
         const bool d3_ok = h->dense3_on && h->fixup_on && !vb && nz / 32 <= 256 && h->ball_block <= 256;
         cur_dense3 = d3_ok && (fix || h->dense3_mode);
+        // A build that has no reason to expect that KD decides the scene (a fresh context: the reference API is one-shot;
+        // or the build after a failure) enqueues the fix-up stage behind KD in the SAME build, guarded on KD's verdict
+        // (status word 20), so that an almost-dense or noise-like scene does not pay for the sweeps once before the
+        // handle has learned: first build at p = 0.05 0.85 -> 0.35 ms.  Two guarded launches; not in the steady dense state.
+        cur_staged = d3_ok && !cur_dense3 && !h->expect_dense && h->dense3_staged;
         if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
-                                       h->d_small + 3, s, (fix || cur_dense3) ? h->d_small + 6 : nullptr, true, vb, nx,
-                                       cur_dense3 ? 3 : 2)) return rc;
+                                       cur_staged ? h->d_small + 20 : h->d_small + 3, s,
+                                       (fix || cur_dense3) ? h->d_small + 6 : nullptr, true, vb, nx, cur_dense3 ? 3 : 2)) return rc;
+        if (cur_staged)
+            if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
+                                           h->d_small + 3, s, h->d_small + 6, true, 0, nx, 3, h->d_small + 20)) return rc;
         launched_since_mark = true;
         h->guard = h->d_small + 3;
         cur_fix_mode = fix || cur_dense3;
@@ -968,6 +981,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->prev_dense = dense;
         h->prev_generic = dense_generic;
         h->prev_fix_mode = cur_fix_mode;
+        h->prev_staged = cur_staged;
     }
     if (prof) {
         HIP_TRY(h, mark(7));
@@ -1191,7 +1205,7 @@ int sdfgpu_create(int device, sdfgpu_handle* out_handle) {
                     (int)ce, hipGetErrorString(ce));
     }
     ctx->d_result = ctx->d_small + 64;                       // second half of the same allocation
-    if (hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocMapped) != hipSuccess) ctx->h_flags = nullptr;
+    if (hipHostMalloc((void**)&ctx->h_flags, 128, hipHostMallocMapped) != hipSuccess) ctx->h_flags = nullptr;
     if (ctx->h_flags && hipHostGetDevicePointer((void**)&ctx->h_flags_dev, ctx->h_flags, 0) != hipSuccess) ctx->h_flags_dev = nullptr;
     if (ctx->h_flags && hipEventCreateWithFlags(&ctx->flags_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipHostFree(ctx->h_flags);
@@ -1775,6 +1789,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; h->dense3_mode = false; }
     else if (n == "dense3") { h->dense3_on = value != 0; h->dense3_mode = false; }
     else if (n == "dense3_mode") h->dense3_mode = value != 0;
+    else if (n == "dense3_staged") h->dense3_staged = value != 0;
     else if (n == "fixup_mode") h->fix_mode = value != 0;
     else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; h->dense_backoff = 0; }
     else if (n == "envelope_mode") { h->flags_pending = false; h->force_env = value != 0 ? 1 : -1; }

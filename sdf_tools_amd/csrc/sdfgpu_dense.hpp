@@ -114,6 +114,7 @@ struct DenseArgs {
     int nx_glob;            // x extent of the whole grid (buffer plane 0 = grid plane 0 in this mode)
     int checked;            // debugging: take the bounds-checked expansion even for interior tiles
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
+    const uint32_t* guard;  // KD3 only: non-null = run iff *guard != 0 (the staged fix-up stage behind KD in the same build)
 };
 
 constexpr int kBallR = 2;                                    // |dx|,|dy|,|dz| <= 2

@@ -55,6 +55,7 @@ __device__ __forceinline__ uint32_t ball3_level_pass(const uint32_t* c0, int hy,
 template <int BD, bool ZINV>
 __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (a.guard && __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // KD decided the scene
     // (block-uniform; an atomic load: a plain one may be served from a scalar / L1 cache line read before the flag went up)
     if (a.early_out && __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int nzw = a.nzw, lg = a.log2_nzw;

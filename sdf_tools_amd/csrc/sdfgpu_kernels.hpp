@@ -65,6 +65,7 @@ __device__ __forceinline__ void raise_flag(uint32_t* p) {
 // channels, ~16 first-generation waves per slot), and the one-block k_fold_slots launched at the end of every
 // ABI call folds the slots into the caller's {max free, max filled} words and clears them again.
 constexpr int kSlots = 512;
+constexpr int kStatusWords = 24;      // words of the status block that the end-of-build fold publishes and clears
 constexpr int kSlotWords = 32;
 __device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mxF, int mxQ) {
     uint32_t* p = slots + (size_t)(wave & (kSlots - 1)) * kSlotWords;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ sl
     uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
     uint32_t f = p[0], q = p[1];
     uint32_t st = 0;
-    if (result && threadIdx.x < 8) st = __hip_atomic_load(maxdsq + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (result && threadIdx.x < kStatusWords) st = __hip_atomic_load(maxdsq + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f) p[0] = 0;
     if (q) p[1] = 0;
 #pragma unroll
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ sl
     }
     if ((threadIdx.x & 63) == 0) { part[2 * (threadIdx.x >> 6)] = f; part[2 * (threadIdx.x >> 6) + 1] = q; }
     __syncthreads();
-    if (threadIdx.x < 8) {                                     // lanes 0..7 of wave 0: one status word each
+    if (threadIdx.x < kStatusWords) {                          // lanes 0..23 of wave 0: one status word each
 #pragma unroll
         for (int w = 0; w < kSlots / 64; ++w) { f = max(f, part[2 * w]); q = max(q, part[2 * w + 1]); }
         if (!result) {

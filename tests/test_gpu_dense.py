@@ -79,8 +79,14 @@ def test_every_level_of_the_ball(gpu):
     _check(gpu, m, 0.25, expect_certified=True)
     m = np.zeros((9, 9, 32), np.uint8)
     m[::4, ::4, ::4] = 1                                # (2,2,2) away -> d^2 = 12 > 8: must fall back
-    gpu.set_option("policy_reset", 1)                   # (KD alone: the builds above have taught the handle to escalate)
-    _check(gpu, m, 0.25, expect_certified=False)
+    gpu.set_option("policy_reset", 1)
+    gpu.set_option("dense3", 0)                         # (KD alone: with the wide ball kernel behind it the scene is certified)
+    try:
+        _check(gpu, m, 0.25, expect_certified=False)
+    finally:
+        gpu.set_option("dense3", 1)
+    gpu.set_option("policy_reset", 1)
+    _check(gpu, m, 0.25, expect_certified=True)         # ... by KD3, staged behind KD in the same build
 
 
 def test_grid_edges_replicate_correctly(gpu):
@@ -173,15 +179,15 @@ def test_reference_grid_shapes_take_the_dense_tier(gpu, shape):
 
 
 def test_dense_retry_policy_skips_and_retries(gpu):
-    """An uncertified dense attempt is first retried with the fix-up stage (the wide ball kernel KD3 + the fix-up kernel);
-    if that cannot certify the scene either, the dense kernels are left out of the next builds and tried again every
-    dense_retry-th build.  Results stay exact all along."""
+    """A dense attempt that does not expect to succeed carries the fix-up stage (the wide ball kernel KD3 + the fix-up
+    kernel) behind KD in the same build; if that cannot certify the scene either, the dense kernels are left out of the
+    next builds and tried again every dense_retry-th build.  Results stay exact all along."""
     gpu.set_option("dense_retry", 4)
     sparse = synth.bernoulli_mask((16, 16, 64), 0.002, 9)
     dense = synth.bernoulli_mask((16, 16, 64), 0.5, 9)
     ex_s, ext_s, _ = O.exact_sdf(sparse, 0.1)
     ex_d, ext_d, _ = O.exact_sdf(dense, 0.1)
-    for _ in range(2):                                   # plain attempt, then the attempt with the fix-up stage
+    for _ in range(1):                                   # one attempt: KD and, staged behind it, KD3 + KF
         sdf, ext = gpu.build(sparse, 0.1)
         assert np.array_equal(sdf, ex_s) and ext == ext_s
         assert gpu.last_build_info()["dense"] and not gpu.last_dense_certified()
@@ -196,18 +202,18 @@ def test_dense_retry_policy_skips_and_retries(gpu):
     gpu.set_option("policy_reset", 1)
     gpu.set_option("dense_retry", 4)
     used = []
-    for _ in range(2 + 3 + 2 + 7 + 2 + 15 + 1):
+    for _ in range(1 + 3 + 1 + 7 + 1 + 15 + 1):
         sdf, ext = gpu.build(sparse, 0.1)
         assert np.array_equal(sdf, ex_s) and ext == ext_s
         used.append(int(gpu.last_build_info()["dense"]))
-    assert used == [1, 1] + [0] * 3 + [1, 1] + [0] * 7 + [1, 1] + [0] * 15 + [1]
+    assert used == [1] + [0] * 3 + [1] + [0] * 7 + [1] + [0] * 15 + [1]
     gpu.set_option("dense_retry", 0)
 
 
 @pytest.mark.parametrize("p", [0.1, 0.07, 0.9, 0.93])
 def test_almost_dense_scenes_are_finished_by_the_fixup_kernel(gpu, p):
-    """A handful of voxels beyond the d^2 <= 8 ball: the first build falls back to the general sweeps, the policy
-    then puts the fix-up kernel behind the ball kernel and the scene is certified without them -- exact both ways."""
+    """A handful of voxels beyond the d^2 <= 8 ball: the fix-up stage (staged behind KD in a first build, in KD's place
+    afterwards) certifies the scene without the general sweeps -- exact every time."""
     shape = (48, 40, 64)
     m = synth.bernoulli_mask(shape, p, 21)
     ex, ex_ext, dsq = O.exact_sdf(m, 0.05)
@@ -217,7 +223,7 @@ def test_almost_dense_scenes_are_finished_by_the_fixup_kernel(gpu, p):
         sdf, ext = gpu.build(m, 0.05)
         assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)) and ext == ex_ext
         certified.append(gpu.last_dense_certified())
-    assert certified == [False, True, True]
+    assert certified == [True, True, True]                 # (the first build already: the fix-up stage is staged behind KD)
     # forced fix-up mode on a scene that needs distances beyond its cube: it must hand over, not guess
     gpu.set_option("policy_reset", 1)
     gpu.set_option("fixup_mode", 1)
@@ -278,8 +284,8 @@ def test_wide_ball_kernel_every_level_edges_and_shapes(gpu):
 
 
 def test_policy_escalates_to_the_wide_ball_kernel(gpu):
-    """Bernoulli p = 0.03: KD leaves 6 % of the voxels undecided (more than KF takes), KD3 leaves 2e-3: the handle goes
-    KD -> KD3 + KF and is certified from the second build on; exact at every step.  With the option off (KD + KF) it
+    """Bernoulli p = 0.03: KD leaves 6 % of the voxels undecided (more than KF takes), KD3 leaves 2e-3: the first build runs
+    KD, then KD3 + KF on KD's verdict, the later ones KD3 + KF alone; certified and exact every time.  With the option off (KD + KF) it
     backs off to the sweeps instead."""
     shape = (64, 64, 128)
     m = synth.bernoulli_mask(shape, 0.03, 3)
@@ -290,7 +296,7 @@ def test_policy_escalates_to_the_wide_ball_kernel(gpu):
         sdf, ext = gpu.build(m, 0.05)
         assert np.array_equal(sdf.view(np.uint32), ex.view(np.uint32)) and ext == ex_ext
         certified.append(gpu.last_dense_certified())
-    assert certified == [False, True, True, True, True], certified
+    assert certified == [True, True, True, True, True], certified
     gpu.set_option("dense3", 0)
     try:
         gpu.set_option("policy_reset", 1)
