@@ -78,6 +78,7 @@ struct sdfgpu_context {
     bool dense3_mode = false;     // option "dense3_mode": KD3 + KF with every dense build (tests)
     int dense3_staged = 1;        // a build that does not expect KD to decide the scene enqueues KD3 + KF behind KD, guarded on KD's verdict (option "dense3_staged")
     bool prev_staged = false;
+    uint32_t* unc_override = nullptr;   // set around the staged KD3 launch: undecided bits in the z field's storage
     int dense_retry = 16;         // after an uncertified dense attempt, try the dense kernels again every N-th build (0 = always)
     int dense_skip = 0;           // builds left that skip the dense kernels
     int dense_backoff = 0;        // current length of that pause: doubles while the attempts keep failing (a caller that
@@ -650,12 +651,15 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     const dim3 grid((unsigned)gx, (unsigned)gy);
     if (d_fix_needed) {                                              // fix-up mode: hand the undecided voxels to KF
         const size_t tiles = (size_t)gx * gy;
-        if (int rc = ensure(h, h->unc, (size_t)(out_hi - out_lo) * ny * a.nzw * 4)) return rc;
+        // (the undecided bits of a STAGED fix-up stage live in the z field's storage, which the general pipeline only writes
+        //  after KF has consumed them: a fresh context's first build does not pay a 17 MB allocation for a stage that a
+        //  far-field scene leaves at once)
+        if (!h->unc_override) if (int rc = ensure(h, h->unc, (size_t)(out_hi - out_lo) * ny * a.nzw * 4)) return rc;
         if (h->tileflag.bytes < tiles * 4 || !h->tileflag.ptr) {
             if (int rc = ensure(h, h->tileflag, tiles * 4)) return rc;
             HIP_TRY(h, hipMemsetAsync(h->tileflag.ptr, 0, h->tileflag.bytes, s));     // afterwards KF keeps it zero
         }
-        a.unc = (uint32_t*)h->unc.ptr; a.tileflag = (uint32_t*)h->tileflag.ptr; a.fix_needed = d_fix_needed;
+        a.unc = h->unc_override ? h->unc_override : (uint32_t*)h->unc.ptr; a.tileflag = (uint32_t*)h->tileflag.ptr; a.fix_needed = d_fix_needed;
     }
     const bool zinv = nz <= (int64_t)bd * 4 && !(h->ball_variant & 2);   // an expansion pass covers whole z-rows
     a.checked = h->ball_variant & 1;
@@ -759,8 +763,8 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         //   (the fix-up stage = KD3 + KF where the shape allows it -- the ball kernel with |offset| <= 3 costs what KD costs
         //   on the scenes KD decides and leaves KF 1/50 of the voxels: 0.20 instead of 0.47 ms at p = 0.05 -- else KD + KF)
         if (h->prev_dense && h->fixup_on && !h->prev_generic) {
-            //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict in word 20)
-            if (!h->prev_fix_mode) { h->fix_mode = h->h_flags[h->prev_staged ? 20 : 3] != 0; h->fix_clean = 0; }   // KD alone could not: the fix-up stage next
+            //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict, status word 20, as word 8)
+            if (!h->prev_fix_mode) { h->fix_mode = h->h_flags[h->prev_staged ? 8 : 3] != 0; h->fix_clean = 0; }   // KD alone could not: the fix-up stage next
             else if (h->h_flags[3] != 0) h->fix_mode = false;                      // KF could not certify it either
             else {                                                                 // keep KF while it is needed (left after
                 h->fix_clean = h->h_flags[6] != 0 ? 0 : h->fix_clean + 1;          // 8 clean builds in a row: a scene at the
@@ -861,9 +865,13 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
                                        cur_staged ? h->d_small + 20 : h->d_small + 3, s,
                                        (fix || cur_dense3) ? h->d_small + 6 : nullptr, true, vb, nx, cur_dense3 ? 3 : 2)) return rc;
-        if (cur_staged)
-            if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
-                                           h->d_small + 3, s, h->d_small + 6, true, 0, nx, 3, h->d_small + 20)) return rc;
+        if (cur_staged) {
+            h->unc_override = (!fused && h->zfield.ptr && h->zfield.bytes >= (size_t)n / 8) ? (uint32_t*)h->zfield.ptr : nullptr;
+            const int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
+                                             h->d_small + 3, s, h->d_small + 6, true, 0, nx, 3, h->d_small + 20);
+            h->unc_override = nullptr;
+            if (rc) return rc;
+        }
         launched_since_mark = true;
         h->guard = h->d_small + 3;
         cur_fix_mode = fix || cur_dense3;
