@@ -2,12 +2,15 @@
 //
 // The second dense stage for the density band between "almost dense" and far-field (Bernoulli p = 0.02 .. 0.045): KD with
 // d^2 <= 8 leaves 0.96^92 = 2.3 % of the voxels undecided at p = 0.04 and 6 % at p = 0.03, more than the fix-up kernel can
-// take (it is exact up to d^2 = 36 but costs a wave per voxel); d^2 <= 14 leaves 0.96^250 = 4e-5 and 0.97^250 = 5e-4.
+// take (exact up to d^2 = 64, but a 16-lane row per voxel); d^2 <= 14 leaves 0.96^250 = 4e-5 and 0.97^250 = 5e-4 .. 2e-3.
+// Evaluated level by level with the wave-uniform early stop it costs what KD costs on the scenes KD decides.
 // Same structure as KD (sdfgpu_dense.hpp: staged bit tile with halo, levels in increasing d^2, cumulative, wave-uniform
 // early stop; level index per voxel as bit-planes; signed pair table; 4 voxels per lane and store), with a halo of 3,
 // 4 level bit-planes, a 1024-entry pair table, no virtual border (b = 3 would bind inside the ball: such scenes keep
 // the other tiers) and one more way to give up: a wave with more than kBall3MaxUndecided undecided voxels raises
-// `uncertified` at once (the fix-up kernel's per-tile cap would do the same one launch later).  The host policy (sdfgpu.hip) puts it in KD's place after KD + KF failed on a handle.
+// `uncertified` at once (the fix-up kernel's per-tile cap would do the same one launch later).
+// Where it runs (sdfgpu.hip): in KD's place, with KF behind it, whenever the host policy enqueues the fix-up stage; and behind
+// KD in the same build, guarded on KD's verdict (DenseArgs::guard), when a build does not expect KD to decide the scene.
 #pragma once
 #include "sdfgpu_dense.hpp"
 
