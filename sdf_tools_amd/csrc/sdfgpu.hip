@@ -79,6 +79,7 @@ struct sdfgpu_context {
     int dense3_staged = 1;        // a build that does not expect KD to decide the scene enqueues KD3 + KF behind KD, guarded on KD's verdict (option "dense3_staged")
     bool prev_staged = false;
     uint32_t* unc_override = nullptr;   // set around the staged KD3 launch: undecided bits in the z field's storage
+    size_t unc_override_bytes = 0;
     int dense_retry = 16;         // after an uncertified dense attempt, try the dense kernels again every N-th build (0 = always)
     int dense_skip = 0;           // builds left that skip the dense kernels
     int dense_backoff = 0;        // current length of that pause: doubles while the attempts keep failing (a caller that
@@ -647,7 +648,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     if (gx > 0x7fffffffLL || gy > 65535) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
     const size_t pitch = a.nzw < 32 ? a.nzw + 32 : a.nzw + 2;        // must match k_ball_dense
     const size_t tile_words = ((size_t)(a.tx + 2 * R) * (a.ty + 2 * R) * pitch + 3) & ~(size_t)3;
-    const size_t lds = radius == 3 ? tile_words * 4 + (size_t)bd * 20 + 1024 * 8 + 64 : tile_words * 4 + (size_t)bd * 16 + 256 * 8 + 64;
+    const size_t lds = radius == 3 ? tile_words * 4 + (size_t)bd * 20 + 1024 * 8 + 128 : tile_words * 4 + (size_t)bd * 16 + 256 * 8 + 64;
     const dim3 grid((unsigned)gx, (unsigned)gy);
     if (d_fix_needed) {                                              // fix-up mode: hand the undecided voxels to KF
         const size_t tiles = (size_t)gx * gy;
@@ -655,11 +656,19 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
         //  after KF has consumed them: a fresh context's first build does not pay a 17 MB allocation for a stage that a
         //  far-field scene leaves at once)
         if (!h->unc_override) if (int rc = ensure(h, h->unc, (size_t)(out_hi - out_lo) * ny * a.nzw * 4)) return rc;
-        if (h->tileflag.bytes < tiles * 4 || !h->tileflag.ptr) {
-            if (int rc = ensure(h, h->tileflag, tiles * 4)) return rc;
-            HIP_TRY(h, hipMemsetAsync(h->tileflag.ptr, 0, h->tileflag.bytes, s));     // afterwards KF keeps it zero
+        uint32_t* tileflag = nullptr;
+        if (h->unc_override && h->unc_override_bytes >= (size_t)(out_hi - out_lo) * ny * a.nzw * 4 + 256 + tiles * 4) {
+            // ... and so do its tile flags (behind the bits; cleared here: the storage is not ours between builds)
+            tileflag = h->unc_override + ((size_t)(out_hi - out_lo) * ny * a.nzw + 63) / 64 * 64;
+            HIP_TRY(h, hipMemsetAsync(tileflag, 0, tiles * 4, s));
+        } else {
+            if (h->tileflag.bytes < tiles * 4 || !h->tileflag.ptr) {
+                if (int rc = ensure(h, h->tileflag, tiles * 4)) return rc;
+                HIP_TRY(h, hipMemsetAsync(h->tileflag.ptr, 0, h->tileflag.bytes, s));     // afterwards KF keeps it zero
+            }
+            tileflag = (uint32_t*)h->tileflag.ptr;
         }
-        a.unc = h->unc_override ? h->unc_override : (uint32_t*)h->unc.ptr; a.tileflag = (uint32_t*)h->tileflag.ptr; a.fix_needed = d_fix_needed;
+        a.unc = h->unc_override ? h->unc_override : (uint32_t*)h->unc.ptr; a.tileflag = tileflag; a.fix_needed = d_fix_needed;
     }
     const bool zinv = nz <= (int64_t)bd * 4 && !(h->ball_variant & 2);   // an expansion pass covers whole z-rows
     a.checked = h->ball_variant & 1;
@@ -867,6 +876,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                        (fix || cur_dense3) ? h->d_small + 6 : nullptr, true, vb, nx, cur_dense3 ? 3 : 2)) return rc;
         if (cur_staged) {
             h->unc_override = (!fused && h->zfield.ptr && h->zfield.bytes >= (size_t)n / 8) ? (uint32_t*)h->zfield.ptr : nullptr;
+            h->unc_override_bytes = h->unc_override ? h->zfield.bytes : 0;
             const int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
                                              h->d_small + 3, s, h->d_small + 6, true, 0, nx, 3, h->d_small + 20);
             h->unc_override = nullptr;
