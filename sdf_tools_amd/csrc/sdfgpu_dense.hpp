@@ -398,7 +398,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
 // At Bernoulli p = 0.1 the ball of d^2 <= 8 leaves 0.9^92 = 6e-5 of the free voxels undecided -- 7 000 of 134 M
 // -- and recomputing the whole grid with the general sweeps for them costs 5x the dense kernels.  KF visits only
 // those voxels: the tiles whose flag word KD set stage their bit rows again with a halo of kFixR planes / rows, the
-// undecided voxels of the tile are compacted into an LDS list, and one wave per voxel scans the 169 (dx, dy) rows
+// undecided voxels of the tile are compacted into an LDS list, and one wave per voxel scans the (2 kFixR + 1)^2 (dx, dy) rows
 // (3 per lane), taking the nearest opposite bit within |dz| <= kFixR of each row with two bit scans, and
 // min-reduces the candidates.  A candidate <= kFixR^2 is the exact squared
 // distance (every offset that could beat it lies inside the scanned cube; rows / bits beyond the grid replicate
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         return;
     }
     // A tile with a handful of undecided voxels (Bernoulli p = 0.1: two per tile, in nearly every tile) reads the rows it
-    // needs straight from the L2-resident bit field -- 64 .. 169 rows of 3 words per voxel -- instead of staging the whole
+    // needs straight from the L2-resident bit field -- 64 .. 289 rows of 3 words per voxel -- instead of staging the whole
     // halo tile in LDS ((tx + 12) x (ty + 12) rows for two voxels was most of this kernel's time there).
     const bool direct = n <= (uint32_t)kFixDirect;            // (block-uniform)
     if (!direct) {
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     int mxF = 0, mxQ = 0;
     bool failed = false;
     const int nz = nzw << 5;
-    // one 16-lane ROW per voxel (4 voxels per wave): the 169 (dx, dy) rows, sorted by dx^2 + dy^2, go past in batches of
+    // one 16-lane ROW per voxel (4 voxels per wave): the 289 (dx, dy) rows, sorted by dx^2 + dy^2, go past in batches of
     // 64 (4 per lane, no dependence between them), the candidates are min-reduced over the DPP row, and a voxel stops as
     // soon as its best candidate is no larger than the smallest in-plane offset still to come -- the usual case after the
     // first batch (it covers dx^2 + dy^2 <= 18; at p = 0.05 the nearest opposite voxel lies at d^2 ~ 9 .. 14).
