@@ -118,3 +118,39 @@ def test_far_field_schedule_model_is_exact():
         got, _ = model.dc_line(F, finf)
         assert got == model.brute(F), (trial, L, kind)
         model.check_line(rng, F)                                    # again with a looser span / bound and a forced level-A form
+
+
+def test_wide_ball_level_tables_and_plane_encoding():
+    """The arithmetic KD3 (sdf_tools_amd/csrc/sdfgpu_dense3.hpp) rests on, restated: (1) the levels of the 7^3 cube are
+    exactly the d^2 <= 14 that are sums of three squares, and every lattice point with such a d^2 lies inside the cube
+    (a level is COMPLETE: no offset of that length is missing); 15 is not a sum of three squares and 16 = 4^2 leaves the
+    cube, so 14 is where completeness ends; (2) ball3_level's closed form enumerates them in order; (3) the "not found
+    at level l" sets are nested, and bit k of their count is the parity of every 2^(k+1)-th of them starting at 2^k - 1 --
+    the four bit-planes the kernel stores."""
+    import re
+    R = 3
+    sums = sorted({x * x + y * y + z * z for x in range(-6, 7) for y in range(-6, 7) for z in range(-6, 7)} - {0})
+    levels = [d for d in sums if d <= 14]
+    assert levels == [1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14] and 15 not in sums
+    for d2 in levels:                                         # complete: every offset of that length is inside the cube
+        pts = [(x, y, z) for x in range(-6, 7) for y in range(-6, 7) for z in range(-6, 7) if x * x + y * y + z * z == d2]
+        assert all(max(abs(c) for c in p) <= R for p in pts)
+    assert any(max(abs(c) for c in (4, 0, 0)) > R for _ in [0])   # d^2 = 16 is the first level the cube would miss
+
+    def ball3_level(d2):                                      # the header's closed form
+        return d2 - 1 if 1 <= d2 <= 6 else d2 - 2 if 8 <= d2 <= 14 else -1
+    assert [ball3_level(d) for d in levels] == list(range(13))
+    assert all(ball3_level(d) == -1 for d in (0, 7, 15, 16, 27))
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                            "sdf_tools_amd", "csrc", "sdfgpu_dense3.hpp")).read()
+    m = re.search(r"kBall3D2\[kBall3Levels\] = \{([^}]*)\}", src)
+    assert m and [int(v) for v in m.group(1).split(",")] == levels   # the kernel's table is this list
+    NL = 13
+    for c in range(NL + 1):                                   # c = level index of a voxel = number of levels it was NOT found at
+        U = [1 if l < c else 0 for l in range(NL)]            # nested sets
+        planes = [0, 0, 0, 0]
+        planes[0] = sum(U[l] for l in range(0, NL)) & 1       # the XOR chains written out in the kernel
+        planes[1] = sum(U[l] for l in (1, 3, 5, 7, 9, 11)) & 1
+        planes[2] = sum(U[l] for l in (3, 7, 11)) & 1
+        planes[3] = U[7]
+        assert planes[0] | planes[1] << 1 | planes[2] << 2 | planes[3] << 3 == c
