@@ -26,7 +26,7 @@ inline uint64_t SerializeFixedSizePOD(const T& item, std::vector<uint8_t>& buffe
 
 template <typename T>
 inline std::pair<T, uint64_t> DeserializeFixedSizePOD(const std::vector<uint8_t>& buffer, const uint64_t current) {
-    if (current + sizeof(T) > buffer.size()) throw std::invalid_argument("Not enough room in the provided buffer");
+    if (current > buffer.size() || sizeof(T) > buffer.size() - current) throw std::invalid_argument("Not enough room in the provided buffer");
     T item;
     std::memcpy(&item, buffer.data() + current, sizeof(T));
     return std::make_pair(item, (uint64_t)sizeof(T));
@@ -48,6 +48,7 @@ inline std::pair<std::vector<T>, uint64_t> DeserializeVector(
     uint64_t pos = current;
     const auto n = DeserializeFixedSizePOD<uint64_t>(buffer, pos);
     pos += n.second;
+    if (pos > buffer.size() || n.first > (uint64_t)(buffer.size() - pos)) throw std::invalid_argument("Not enough room in the provided buffer");
     std::vector<T> out;
     out.reserve((size_t)n.first);
     for (uint64_t i = 0; i < n.first; i++) {
@@ -66,7 +67,7 @@ inline uint64_t SerializeString(const std::string& s, std::vector<uint8_t>& buff
 
 inline std::pair<std::string, uint64_t> DeserializeString(const std::vector<uint8_t>& buffer, const uint64_t current) {
     const auto n = DeserializeFixedSizePOD<uint64_t>(buffer, current);
-    if (current + n.second + n.first > buffer.size()) throw std::invalid_argument("Not enough room in the provided buffer");
+    if (current + n.second > buffer.size() || n.first > (uint64_t)(buffer.size() - current - n.second)) throw std::invalid_argument("Not enough room in the provided buffer");
     std::string s(reinterpret_cast<const char*>(buffer.data() + current + n.second), (size_t)n.first);
     return std::make_pair(s, n.second + n.first);
 }

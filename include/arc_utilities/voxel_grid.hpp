@@ -225,6 +225,9 @@ public:
         const auto t0 = DeserializeIsometry3d(buffer, pos); pos += t0.second;
         const auto t1 = DeserializeIsometry3d(buffer, pos); pos += t1.second;
         const auto n = DeserializeFixedSizePOD<uint64_t>(buffer, pos); pos += n.second;
+        // (untrusted bytes: every element takes at least one byte of the buffer, so a count beyond what is left is a
+        //  corrupt or hostile header -- refuse it before reserving memory for it)
+        if (pos > buffer.size() || n.first > (uint64_t)(buffer.size() - pos)) throw std::invalid_argument("serialized grid is inconsistent (element count exceeds the buffer)");
         BackingStore data;
         data.reserve((size_t)n.first);
         for (uint64_t i = 0; i < n.first; i++) { const auto v = value_deserializer(buffer, pos); data.push_back(v.first); pos += v.second; }
@@ -234,7 +237,19 @@ public:
         for (int64_t& x : k) { const auto r = DeserializeFixedSizePOD<int64_t>(buffer, pos); x = r.first; pos += r.second; }
         const auto dv = value_deserializer(buffer, pos); pos += dv.second;
         const auto ov = value_deserializer(buffer, pos); pos += ov.second;
-        if ((int64_t)data.size() != k[2] * k[3] * k[4]) throw std::invalid_argument("serialized grid is inconsistent");
+        {   // dims >= 0 (the reference's default-constructed, uninitialised grid serialises 0 x 0 x 0), overflow-safe product
+            typedef unsigned __int128 u128;
+            const uint64_t sz = (uint64_t)data.size();
+            bool ok = k[2] >= 0 && k[3] >= 0 && k[4] >= 0;
+            if (ok && sz == 0) ok = k[2] == 0 || k[3] == 0 || k[4] == 0;
+            else if (ok) {
+                ok = (uint64_t)k[2] <= sz && (uint64_t)k[3] <= sz && (uint64_t)k[4] <= sz;
+                const u128 p2 = (u128)(uint64_t)k[3] * (u128)(uint64_t)k[4];
+                ok = ok && p2 <= (u128)sz && p2 * (u128)(uint64_t)k[2] == (u128)sz;
+                ok = ok && k[0] == k[3] * k[4] && k[1] == k[4];                  // strides of the z-fastest layout
+            }
+            if (!ok) throw std::invalid_argument("serialized grid is inconsistent");
+        }
         initialized_ = (bool)init.first;
         origin_transform_ = t0.first; inverse_origin_transform_ = t1.first;
         data_ = std::move(data);

@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <fstream>
+#include <functional>
 #include <iterator>
 #include <stdexcept>
 #include <string>
@@ -93,6 +94,15 @@ public:
     std::pair<SignedDistanceField, std::pair<double, double>> ExtractSignedDistanceField(
         const float oob_value, const bool unknown_is_filled, const bool add_virtual_border) const {
         return sdf_generation::ExtractSignedDistanceFieldFromCells(
+            GetOriginTransform(), GetCellSizes(), GetNumXCells(), GetNumYCells(), GetNumZCells(), data_.data(),
+            sizeof(COLLISION_CELL), offsetof(COLLISION_CELL, occupancy), unknown_is_filled, oob_value, GetFrame(), add_virtual_border);
+    }
+
+    // The same build with the field left in HBM (round 4): batched EstimateDistance / GetGradient queries run on the
+    // device, Host() downloads the reference's container lazily (include/sdf_tools/device_sdf.hpp).
+    std::pair<DeviceSignedDistanceField, std::pair<double, double>> ExtractSignedDistanceFieldDevice(
+        const float oob_value, const bool unknown_is_filled, const bool add_virtual_border) const {
+        return sdf_generation::ExtractSignedDistanceFieldDeviceFromCells(
             GetOriginTransform(), GetCellSizes(), GetNumXCells(), GetNumYCells(), GetNumZCells(), data_.data(),
             sizeof(COLLISION_CELL), offsetof(COLLISION_CELL, occupancy), unknown_is_filled, oob_value, GetFrame(), add_virtual_border);
     }

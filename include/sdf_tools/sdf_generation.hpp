@@ -17,6 +17,7 @@
 
 #include "arc_utilities/voxel_grid.hpp"
 #include "sdf_tools/gpu_context.hpp"
+#include "sdf_tools/device_sdf.hpp"
 #include "sdf_tools/sdf.hpp"
 #include "sdfgpu.h"
 
@@ -101,6 +102,59 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
                                         cell_sizes.x(), add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(),
                                         &max_distance, &min_distance));
     return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+}
+
+// ---- device-resident results (round 4; no counterpart in the reference: its result is always a host container) -----------
+// The same builds, but the field stays in HBM behind a sdf_tools::DeviceSignedDistanceField: batched EstimateDistance /
+// GetGradient queries run there (one kernel for n points), and Host() downloads the reference's container only if asked.
+// Same predicate order, same exceptions, same (max, min) extrema as the overloads above.  One GPU (the multi-GPU seam
+// returns host fields).
+template <typename T>
+inline std::pair<sdf_tools::DeviceSignedDistanceField, std::pair<double, double>> ExtractSignedDistanceFieldDevice(
+    const Eigen::Isometry3d& grid_origin_tranform, const double grid_resolution, const int64_t grid_num_x_cells,
+    const int64_t grid_num_y_cells, const int64_t grid_num_z_cells,
+    const std::function<bool(const VoxelGrid::GRID_INDEX&)>& is_filled_fn, const float oob_value, const std::string& frame,
+    const bool add_virtual_border = false) {
+    std::vector<uint8_t> filled((size_t)(grid_num_x_cells * grid_num_y_cells * grid_num_z_cells));
+    size_t i = 0;
+    for (int64_t x = 0; x < grid_num_x_cells; x++)
+        for (int64_t y = 0; y < grid_num_y_cells; y++)
+            for (int64_t z = 0; z < grid_num_z_cells; z++) filled[i++] = is_filled_fn(VoxelGrid::GRID_INDEX(x, y, z)) ? 1 : 0;
+    sdf_tools::DeviceSignedDistanceField new_sdf(grid_origin_tranform, frame, grid_resolution, grid_num_x_cells, grid_num_y_cells,
+                                                 grid_num_z_cells, oob_value);
+    double max_distance = 0.0, min_distance = 0.0;
+    sdfgpu_handle h = new_sdf.Handle();
+    ThrowOnStatus(h, sdfgpu_build_to_device(h, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells, grid_resolution,
+                                            add_virtual_border ? 1 : 0, new_sdf.DevicePointer(), &max_distance, &min_distance));
+    new_sdf.SetExtrema(std::make_pair(max_distance, min_distance));
+    return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));
+}
+
+template <typename T, typename BackingStore = std::vector<T>>
+inline std::pair<sdf_tools::DeviceSignedDistanceField, std::pair<double, double>> ExtractSignedDistanceFieldDevice(
+    const VoxelGrid::VoxelGrid<T, BackingStore>& grid, const std::function<bool(const VoxelGrid::GRID_INDEX&)>& is_filled_fn,
+    const float oob_value, const std::string& frame, const bool add_virtual_border) {
+    const Eigen::Vector3d cell_sizes = grid.GetCellSizes();
+    if ((cell_sizes.x() != cell_sizes.y()) || (cell_sizes.x() != cell_sizes.z()))
+        throw std::invalid_argument("Grid must have uniform resolution");
+    return ExtractSignedDistanceFieldDevice<T>(grid.GetOriginTransform(), cell_sizes.x(), grid.GetNumXCells(), grid.GetNumYCells(),
+                                               grid.GetNumZCells(), is_filled_fn, oob_value, frame, add_virtual_border);
+}
+
+inline std::pair<sdf_tools::DeviceSignedDistanceField, std::pair<double, double>> ExtractSignedDistanceFieldDeviceFromCells(
+    const Eigen::Isometry3d& origin, const Eigen::Vector3d& cell_sizes, const int64_t nx, const int64_t ny, const int64_t nz,
+    const void* cells, const size_t cell_stride, const size_t occupancy_offset, const bool unknown_is_filled,
+    const float oob_value, const std::string& frame, const bool add_virtual_border) {
+    if ((cell_sizes.x() != cell_sizes.y()) || (cell_sizes.x() != cell_sizes.z()))
+        throw std::invalid_argument("Grid must have uniform resolution");
+    sdf_tools::DeviceSignedDistanceField new_sdf(origin, frame, cell_sizes.x(), nx, ny, nz, oob_value);
+    double max_distance = 0.0, min_distance = 0.0;
+    sdfgpu_handle h = new_sdf.Handle();
+    ThrowOnStatus(h, sdfgpu_build_cells_to_device(h, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny, nz,
+                                                  cell_sizes.x(), add_virtual_border ? 1 : 0, new_sdf.DevicePointer(),
+                                                  &max_distance, &min_distance));
+    new_sdf.SetExtrema(std::make_pair(max_distance, min_distance));
+    return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));
 }
 
 }  // namespace sdf_generation

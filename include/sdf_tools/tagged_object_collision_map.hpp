@@ -3,22 +3,38 @@
 // constructor, SetValue, and the four callers of the SDF hot path
 //   ExtractFreeAndNamedObjectsSignedDistanceField (:730-811), ExtractSignedDistanceField(objects_to_use)
 //   (:813-856), MakeObjectSDFs (:875-891), MakeAllObjectSDFs (:893-915).
+// plus (round 4) its wire type: SerializeSelf / DeserializeSelf in the reference's field order
+// (src/sdf_tools/tagged_object_collision_map.cpp:23-75, :77-240), TCMZ / TCMR files (:242-307) and the
+// TaggedObjectCollisionMap message pair (:309-339, msg/TaggedObjectCollisionMap.msg) -- byte format of the un-vendored
+// arc_utilities serialisers: "wire-format parity unpinned", like the other two containers.
 // Connected components, convex segmentation, topology and RViz export are out of scope (SURVEY.md section 2,
 // rows 7/8).  Every SDF is built on the GPU through sdfgpu_build_tagged_cells (device-side predicate).
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <fstream>
+#include <functional>
+#include <iterator>
 #include <limits>
 #include <map>
 #include <string>
 #include <utility>
 #include <vector>
 
+#include "arc_utilities/serialization.hpp"
 #include "arc_utilities/voxel_grid.hpp"
+#include "arc_utilities/zlib_helpers.hpp"
 #include "sdf_tools/sdf.hpp"
 #include "sdf_tools/sdf_generation.hpp"
 
 namespace sdf_tools {
+
+// Plain mirror of msg/TaggedObjectCollisionMap.msg for builds without ROS (field names kept).
+struct TaggedObjectCollisionMap {
+    struct Header { uint32_t seq = 0; double stamp = 0.0; std::string frame_id; } header;
+    std::vector<uint8_t> serialized_map;
+    bool is_compressed = false;
+};
 
 struct TAGGED_OBJECT_COLLISION_CELL {
     float occupancy;
@@ -93,6 +109,77 @@ public:
         return true;
     }
     bool SetValue(const GRID_INDEX& i, const TAGGED_OBJECT_COLLISION_CELL& v) override { return SetValue(i.x, i.y, i.z, v); }
+
+    // ---- wire formats: tagged_object_collision_map.cpp:23-75 (fields), :242-307 (files), :309-339 (messages) ------------
+    using CellSerializer = std::function<uint64_t(const TAGGED_OBJECT_COLLISION_CELL&, std::vector<uint8_t>&)>;
+    using CellDeserializer = std::function<std::pair<TAGGED_OBJECT_COLLISION_CELL, uint64_t>(const std::vector<uint8_t>&, const uint64_t)>;
+
+    uint64_t SerializeSelf(std::vector<uint8_t>& buffer,
+                           const CellSerializer& value_serializer = arc_utilities::SerializeFixedSizePOD<TAGGED_OBJECT_COLLISION_CELL>) const override {
+        (void)value_serializer;                                   // (ignored by the reference too: cells are fixed-size PODs, :29)
+        const uint64_t start = buffer.size();
+        BaseSerializeSelf(buffer, arc_utilities::SerializeFixedSizePOD<TAGGED_OBJECT_COLLISION_CELL>);   // initialized .. OOB value (:31-63)
+        arc_utilities::SerializeFixedSizePOD<uint32_t>(number_of_components_, buffer);                   // (:65)
+        arc_utilities::SerializeFixedSizePOD<uint32_t>(number_of_convex_segments_, buffer);              // (:66)
+        arc_utilities::SerializeString(frame_, buffer);                                                  // (:67)
+        arc_utilities::SerializeFixedSizePOD<uint8_t>((uint8_t)components_valid_, buffer);               // (:68)
+        arc_utilities::SerializeFixedSizePOD<uint8_t>((uint8_t)convex_segments_valid_, buffer);          // (:70)
+        return buffer.size() - start;
+    }
+    uint64_t DeserializeSelf(const std::vector<uint8_t>& buffer, const uint64_t current,
+                             const CellDeserializer& value_deserializer = arc_utilities::DeserializeFixedSizePOD<TAGGED_OBJECT_COLLISION_CELL>) override {
+        (void)value_deserializer;
+        uint64_t pos = current;
+        pos += BaseDeserializeSelf(buffer, pos, arc_utilities::DeserializeFixedSizePOD<TAGGED_OBJECT_COLLISION_CELL>);
+        const auto nc = arc_utilities::DeserializeFixedSizePOD<uint32_t>(buffer, pos); pos += nc.second;
+        const auto ns = arc_utilities::DeserializeFixedSizePOD<uint32_t>(buffer, pos); pos += ns.second;
+        const auto fr = arc_utilities::DeserializeString(buffer, pos); pos += fr.second;
+        const auto cv = arc_utilities::DeserializeFixedSizePOD<uint8_t>(buffer, pos); pos += cv.second;
+        const auto sv = arc_utilities::DeserializeFixedSizePOD<uint8_t>(buffer, pos); pos += sv.second;
+        number_of_components_ = nc.first;
+        number_of_convex_segments_ = ns.first;
+        frame_ = fr.first;
+        components_valid_ = (bool)cv.first;
+        convex_segments_valid_ = (bool)sv.first;
+        return pos - current;
+    }
+
+    static void SaveToFile(const TaggedObjectCollisionMapGrid& map, const std::string& filepath, const bool compress) {
+        std::vector<uint8_t> buffer;
+        map.SerializeSelf(buffer);
+        std::ofstream out(filepath, std::ios::out | std::ios::binary);
+        const std::vector<uint8_t> body = compress ? ZlibHelpers::CompressBytes(buffer) : buffer;
+        out.write(compress ? "TCMZ" : "TCMR", 4);                 // 4-byte magic (:251-263)
+        out.write(reinterpret_cast<const char*>(body.data()), (std::streamsize)body.size());
+    }
+    static TaggedObjectCollisionMapGrid LoadFromFile(const std::string& filepath) {
+        std::ifstream in(filepath, std::ios::in | std::ios::binary);
+        if (!in.good()) throw std::invalid_argument("File does not exist");
+        std::vector<uint8_t> all((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        if (all.size() < 4) throw std::invalid_argument("File is too small");
+        const std::string magic(all.begin(), all.begin() + 4);
+        const std::vector<uint8_t> body(all.begin() + 4, all.end());
+        TaggedObjectCollisionMapGrid map;
+        if (magic == "TCMZ") map.DeserializeSelf(ZlibHelpers::DecompressBytes(body), 0);
+        else if (magic == "TCMR") map.DeserializeSelf(body, 0);
+        else throw std::invalid_argument("File has invalid header [" + magic + "]");
+        return map;
+    }
+    static TaggedObjectCollisionMap GetMessageRepresentation(const TaggedObjectCollisionMapGrid& map) {
+        TaggedObjectCollisionMap msg;                             // always zlib-compressed (:312-321); no ROS clock here: stamp stays 0
+        msg.header.frame_id = map.GetFrame();
+        std::vector<uint8_t> buffer;
+        map.SerializeSelf(buffer);
+        msg.serialized_map = ZlibHelpers::CompressBytes(buffer);
+        msg.is_compressed = true;
+        return msg;
+    }
+    static TaggedObjectCollisionMapGrid LoadFromMessageRepresentation(const TaggedObjectCollisionMap& message) {
+        TaggedObjectCollisionMapGrid map;
+        if (message.is_compressed) map.DeserializeSelf(ZlibHelpers::DecompressBytes(message.serialized_map), 0);
+        else map.DeserializeSelf(message.serialized_map, 0);
+        return map;
+    }
 
     // Filled = occupied cell whose object id is in objects_to_use (any object if the list is empty), :813-856.
     std::pair<SignedDistanceField, std::pair<double, double>> ExtractSignedDistanceField(

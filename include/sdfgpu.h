@@ -285,6 +285,33 @@ int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf,
                                int enable_edge_gradients,
                                double* d_distance, double* d_gradient, uint8_t* d_flags, void* stream);
 
+/* Host-buffer form of the query above against a field that LIVES IN HBM (round 4; what the C++ mirror's
+ * sdf_tools::DeviceSignedDistanceField::EstimateDistanceBatch / GetGradientBatch call, i.e. N1 for callers of the
+ * reference's host-side SignedDistanceField::EstimateDistance* / GetGradient*, sdf.hpp:922-961, :383-430): points
+ * (n x 3 doubles) and the three outputs are HOST arrays (any output may be NULL); d_sdf is a device pointer, e.g.
+ * one filled by sdfgpu_build_device into memory from sdfgpu_device_malloc.  A caller that only needs answers at its
+ * points never downloads the field (512 MiB at 512^3, ~10 ms of PCIe).  Synchronous. */
+int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf,
+                        int64_t nx, int64_t ny, int64_t nz, double resolution,
+                        const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
+                        const double* points, int64_t n_points, int enable_edge_gradients,
+                        double* out_distance, double* out_gradient, uint8_t* out_flags);
+
+/* Host input -> DEVICE-RESIDENT result (round 4): sdfgpu_build / sdfgpu_build_cells without the download of the field.
+ * d_out_sdf is device memory for nx*ny*nz floats (sdfgpu_device_malloc); the extrema come back as in sdfgpu_build.
+ * What sdf_generation::ExtractSignedDistanceFieldDevice and CollisionMapGrid::ExtractSignedDistanceFieldDevice call. */
+int sdfgpu_build_to_device(sdfgpu_handle h, const uint8_t* filled,
+                           int64_t nx, int64_t ny, int64_t nz, double resolution, int add_virtual_border,
+                           float* d_out_sdf, double* out_max, double* out_min);
+int sdfgpu_build_cells_to_device(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                                 int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                 int add_virtual_border, float* d_out_sdf, double* out_max, double* out_min);
+
+/* Device memory for callers without a HIP runtime of their own (the C++ mirror is plain host C++): memory on the
+ * handle's device, usable with every *_device entry point and with sdfgpu_copy_to_host / sdfgpu_copy_from_host. */
+int sdfgpu_device_malloc(sdfgpu_handle h, size_t bytes, void** out_ptr);
+int sdfgpu_device_free(sdfgpu_handle h, void* ptr);
+
 /* CollisionMapGrid predicate (collision_map.hpp:689-704) on raw cell records -> byte mask (1 = filled), for callers
  * of the slab stages, which take masks: occupancy > 0.5f || (unknown_is_filled && occupancy == 0.5f). */
 int sdfgpu_classify_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
@@ -351,12 +378,15 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),
- * bit 1 = 16-bit plane field (K3/16), bit 2 = dense kernel (K0 + KD) enqueued in front. */
+ * bit 1 = 16-bit plane field (K3/16), bit 2 = dense kernel (K0 + KD) enqueued in front, bit 3 = the guarded
+ * stand-by behind a trusted dense tier was the far-field pair (K1 -> KE2 -> KE3, bounded on any scene), bit 4 = the
+ * dense stage was its wide form (KD3 + fix-up kernel in KD's place), bit 5 = that form was enqueued BEHIND KD, guarded on
+ * KD's verdict (a build that had no reason to expect that KD decides the scene). */
 int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy);
 
 /* Which path did the work of the last build (synchronises): bit 0 = the dense kernel decided every voxel
- * (the general pipeline behind it exited immediately); bit 1 / bit 2 = the y / x sweep hit its scan bound
- * and was redone by the lower-envelope kernel (far-field scene). */
+ * (the general pipeline behind it exited immediately); bit 1 / bit 2 = the y / x sweep was done by the far-field
+ * kernel (chosen by the probe, after a marching sweep hit its scan bound, or as the stand-by pair). */
 int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified);
 
 /* Tuning hook (benchmarks): rows marched per thread in the y / x sweeps

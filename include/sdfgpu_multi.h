@@ -67,8 +67,14 @@ int sdfgpu_multi_build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mas
  * i.e. several ranks share a GPU). */
 int sdfgpu_multi_last_path(sdfgpu_multi_handle h, int* out_bits);
 
+/* Host round trips (status-block reads with every GPU drained) of the last build, and the number of general builds since
+ * creation whose predicted x sweep had to be redone.  A build needs ONE read (maxima + completion; the API is
+ * synchronous); an uncertified dense attempt adds one, a wrong "near-field" prediction adds one. */
+int sdfgpu_multi_last_stats(sdfgpu_multi_handle h, int* out_host_reads, int* out_mispredictions);
+
 /* Option passed to every rank's sdfgpu context (sdfgpu_set_option), plus "halo" (int32 planes exchanged per side on
- * the near-field general path, default 3) and "dense" (0 = skip the dense tier). */
+ * the near-field general path, default 3), "dense" (0 = skip the dense tier) and "predict_far" (the general path's
+ * prediction of its x sweep: 1 = complete lines, 0 = halo; normally learned from the previous general build). */
 int sdfgpu_multi_set_option(sdfgpu_multi_handle h, const char* name, int value);
 
 #ifdef __cplusplus

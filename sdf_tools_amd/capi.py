@@ -24,7 +24,8 @@ EXPORTS = [
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
     "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
     "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
-    "sdfgpu_copy_to_host", "sdfgpu_copy_from_host",
+    "sdfgpu_copy_to_host", "sdfgpu_copy_from_host", "sdfgpu_query_points", "sdfgpu_device_malloc", "sdfgpu_device_free",
+    "sdfgpu_build_to_device", "sdfgpu_build_cells_to_device",
 ]
 
 
@@ -67,6 +68,11 @@ def load_library():
     L.sdfgpu_build_tagged_cells.argtypes = [vp, vp, sz, sz, sz, ci, vp, i64, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_query_points_device.argtypes = [vp, vp, i64, i64, i64, dbl, vp, vp, ctypes.c_float, vp, i64, ci, vp, vp, vp, vp]
     L.sdfgpu_fold_extrema_device.argtypes = [vp, vp, vp]
+    L.sdfgpu_query_points.argtypes = [vp, vp, i64, i64, i64, dbl, vp, vp, ctypes.c_float, vp, i64, ci, vp, vp, vp]
+    L.sdfgpu_device_malloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    L.sdfgpu_device_free.argtypes = [vp, vp]
+    L.sdfgpu_build_to_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_build_cells_to_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_slab_dense_phase.argtypes = [vp, ci, vp, i64, i64, i64, vp, i64, i64, dbl, vp, vp, vp]
     L.sdfgpu_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
@@ -197,6 +203,39 @@ class SdfGpu:
             self._h, d_sdf, nx, ny, nz, float(resolution), w, r, float(oob_value), d_points, int(n_points),
             int(bool(enable_edge_gradients)), d_distance or None, d_gradient or None, d_flags or None, stream or None))
 
+    # ---- host input -> device-resident field; host points -> host answers (what the C++ mirror's DeviceSignedDistanceField uses)
+    def device_malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self._lib.sdfgpu_device_malloc(self._h, int(nbytes), ctypes.byref(p)))
+        return int(p.value)
+
+    def device_free(self, ptr):
+        self._check(self._lib.sdfgpu_device_free(self._h, ctypes.c_void_p(int(ptr))))
+
+    def build_to_device(self, filled, d_out, resolution=1.0, add_virtual_border=False):
+        """Host mask [nx, ny, nz] -> fp32 field at device address d_out (no download).  Returns (max, min)."""
+        m = np.ascontiguousarray(filled, dtype=np.uint8)
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_build_to_device(self._h, m.ctypes.data, *m.shape, float(resolution),
+                                                     int(bool(add_virtual_border)), ctypes.c_void_p(int(d_out)),
+                                                     ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return float(ext[0]), float(ext[1])
+
+    def query_points(self, d_sdf, shape, resolution, points, world_to_grid=None, rotation=None, oob_value=float("inf"),
+                     enable_edge_gradients=False):
+        """Batched EstimateDistance + GetGradient at host points [n, 3] float64 against a field in HBM.
+        Returns (distance [n], gradient [n, 3], flags [n]) as numpy arrays."""
+        nx, ny, nz = (int(v) for v in shape)
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        n = pts.shape[0]
+        dist, grad, flags = np.empty(n, np.float64), np.empty((n, 3), np.float64), np.empty(n, np.uint8)
+        w = None if world_to_grid is None else (ctypes.c_double * 12)(*np.asarray(world_to_grid, np.float64).reshape(-1)[:12])
+        r = None if rotation is None else (ctypes.c_double * 9)(*np.asarray(rotation, np.float64).reshape(-1)[:9])
+        self._check(self._lib.sdfgpu_query_points(self._h, ctypes.c_void_p(int(d_sdf)), nx, ny, nz, float(resolution), w, r,
+                                                  float(oob_value), pts.ctypes.data, n, int(bool(enable_edge_gradients)),
+                                                  dist.ctypes.data, grad.ctypes.data, flags.ctypes.data))
+        return dist, grad, flags
+
     def slab_dense_phase(self, phase, d_mask_slab, nxs, ny, nz, d_bits_ext, halo_lo, halo_hi, resolution, d_out, d_small,
                          stream=0):
         self._check(self._lib.sdfgpu_slab_dense_phase(self._h, int(phase), d_mask_slab, int(nxs), int(ny), int(nz), d_bits_ext,
@@ -303,7 +342,8 @@ class SdfGpu:
     def last_build_info(self):
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_last_build_info(self._h, ctypes.byref(v)))
-        return {"fused_zy": bool(v.value & 1), "plane16": bool(v.value & 2), "dense": bool(v.value & 4)}
+        return {"fused_zy": bool(v.value & 1), "plane16": bool(v.value & 2), "dense": bool(v.value & 4),
+                "standby_far": bool(v.value & 8), "dense3": bool(v.value & 16), "dense3_staged": bool(v.value & 32)}
 
     def last_path(self):
         """{'dense_certified', 'far_y', 'far_x'} of the last build (synchronises)."""
@@ -338,7 +378,7 @@ class SdfGpu:
 MULTI_EXPORTS = [
     "sdfgpu_multi_create", "sdfgpu_multi_destroy", "sdfgpu_multi_last_error", "sdfgpu_multi_ranks",
     "sdfgpu_multi_slab_range", "sdfgpu_multi_build", "sdfgpu_multi_build_cells", "sdfgpu_multi_build_device",
-    "sdfgpu_multi_last_path", "sdfgpu_multi_set_option",
+    "sdfgpu_multi_last_path", "sdfgpu_multi_set_option", "sdfgpu_multi_last_stats",
 ]
 _multi_lib = None
 
@@ -364,6 +404,7 @@ def load_multi_library():
     L.sdfgpu_multi_build_cells.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_multi_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_multi_last_path.argtypes = [vp, vp]
+    L.sdfgpu_multi_last_stats.argtypes = [vp, vp, vp]
     L.sdfgpu_multi_set_option.argtypes = [vp, ctypes.c_char_p, ci]
     for name in MULTI_EXPORTS:
         if name != "sdfgpu_multi_last_error":
@@ -414,6 +455,13 @@ class MultiSdfGpu:
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_multi_last_path(self._h, ctypes.byref(v)))
         return {"dense_certified": bool(v.value & 1), "whole_lines": bool(v.value & 2), "rccl": bool(v.value & 4)}
+
+    def last_stats(self):
+        """{'host_reads': status-block round trips of the last build, 'mispredictions': general builds since creation
+        whose predicted x sweep had to be redone}."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.sdfgpu_multi_last_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return {"host_reads": int(a.value), "mispredictions": int(b.value)}
 
     def build(self, filled, resolution=1.0, add_virtual_border=False):
         m = np.ascontiguousarray(filled, dtype=np.uint8)

@@ -14,6 +14,8 @@
 
 #include "arc_utilities/zlib_helpers.hpp"
 #include "sdf_tools/collision_map.hpp"
+#include "sdf_tools/device_sdf.hpp"
+#include "sdf_tools/tagged_object_collision_map.hpp"
 
 namespace py = pybind11;
 using namespace sdf_tools;
@@ -68,6 +70,43 @@ PYBIND11_MODULE(pysdf_tools, m) {
         .def_readwrite("serialized_map", &CollisionMap::serialized_map)
         .def_readwrite("is_compressed", &CollisionMap::is_compressed)
         .def_property("frame_id", [](const CollisionMap& s) { return s.header.frame_id; }, [](CollisionMap& s, const std::string& f) { s.header.frame_id = f; });
+
+    // The tagged-object map (not in the reference's pybind surface, bindings.cpp:15-106; bound here beside it so that its wire
+    // type and its SDF callers -- tagged_object_collision_map.hpp:730-915, .cpp:23-339 -- can be driven from Python tests)
+    py::class_<TAGGED_OBJECT_COLLISION_CELL>(m, "TAGGED_OBJECT_COLLISION_CELL")
+        .def(py::init<>())
+        .def(py::init<float, uint32_t>())
+        .def(py::init<float, uint32_t, uint32_t, uint32_t>())
+        .def_readwrite("occupancy", &TAGGED_OBJECT_COLLISION_CELL::occupancy)
+        .def_readwrite("component", &TAGGED_OBJECT_COLLISION_CELL::component)
+        .def_readwrite("object_id", &TAGGED_OBJECT_COLLISION_CELL::object_id)
+        .def_readwrite("convex_segment", &TAGGED_OBJECT_COLLISION_CELL::convex_segment);
+    py::class_<TaggedObjectCollisionMap>(m, "TaggedObjectCollisionMap")   // plain mirror of msg/TaggedObjectCollisionMap.msg
+        .def(py::init<>())
+        .def_readwrite("serialized_map", &TaggedObjectCollisionMap::serialized_map)
+        .def_readwrite("is_compressed", &TaggedObjectCollisionMap::is_compressed)
+        .def_property("frame_id", [](const TaggedObjectCollisionMap& s) { return s.header.frame_id; },
+                      [](TaggedObjectCollisionMap& s, const std::string& f) { s.header.frame_id = f; });
+    py::class_<TaggedObjectCollisionMapGrid>(m, "TaggedObjectCollisionMapGrid")
+        .def(py::init<Isometry3d const&, std::string, double, int64_t, int64_t, int64_t, TAGGED_OBJECT_COLLISION_CELL const&>())
+        .def(py::init<>())
+        .def("SetValue", [](TaggedObjectCollisionMapGrid& g, int64_t x, int64_t y, int64_t z, const TAGGED_OBJECT_COLLISION_CELL& c) { return g.SetValue(x, y, z, c); })
+        .def("GetValueByIndex", [](const TaggedObjectCollisionMapGrid& g, int64_t x, int64_t y, int64_t z) { const auto q = g.GetImmutable(x, y, z); return std::make_pair(q.first, q.second); })
+        .def("GetNumXCells", &TaggedObjectCollisionMapGrid::GetNumXCells)
+        .def("GetNumYCells", &TaggedObjectCollisionMapGrid::GetNumYCells)
+        .def("GetNumZCells", &TaggedObjectCollisionMapGrid::GetNumZCells)
+        .def("GetFrame", &TaggedObjectCollisionMapGrid::GetFrame)
+        .def("GetResolution", &TaggedObjectCollisionMapGrid::GetResolution)
+        .def("SerializeSelf", [](const TaggedObjectCollisionMapGrid& g) { std::vector<uint8_t> b; g.SerializeSelf(b); return py::bytes(reinterpret_cast<const char*>(b.data()), b.size()); })
+        .def_static("Deserialize", [](const py::bytes& data) { const std::string s = data; TaggedObjectCollisionMapGrid g; g.DeserializeSelf(std::vector<uint8_t>(s.begin(), s.end()), 0); return g; })
+        .def("SaveToFile", [](const TaggedObjectCollisionMapGrid& g, const std::string& path, bool compress) { TaggedObjectCollisionMapGrid::SaveToFile(g, path, compress); })
+        .def_static("LoadFromFile", &TaggedObjectCollisionMapGrid::LoadFromFile)
+        .def("GetMessageRepresentation", [](const TaggedObjectCollisionMapGrid& g) { return TaggedObjectCollisionMapGrid::GetMessageRepresentation(g); })
+        .def_static("LoadFromMessageRepresentation", &TaggedObjectCollisionMapGrid::LoadFromMessageRepresentation)
+        .def("ExtractSignedDistanceField", [](const TaggedObjectCollisionMapGrid& g, float oob_value, const std::vector<uint32_t>& objects_to_use,
+                                               bool unknown_is_filled, bool add_virtual_border) {
+            return g.ExtractSignedDistanceField(oob_value, objects_to_use, unknown_is_filled, add_virtual_border);
+        }, py::call_guard<py::gil_scoped_release>());
 
     using VoxelGridVecd = VoxelGrid::VoxelGrid<std::vector<double>>;
 
@@ -131,6 +170,34 @@ PYBIND11_MODULE(pysdf_tools, m) {
             return out;
         }, py::arg("enable_edge_gradients") = true);
 
+    // the field left in HBM (include/sdf_tools/device_sdf.hpp): batched queries without the download.  A pybind thread is the
+    // thread that owns the libsdfgpu context, so build, query and drop the object from the same Python thread.
+    py::class_<sdf_tools::DeviceSignedDistanceField>(m, "DeviceSignedDistanceField")
+        .def("GetResolution", &sdf_tools::DeviceSignedDistanceField::GetResolution)
+        .def("GetFrame", &sdf_tools::DeviceSignedDistanceField::GetFrame)
+        .def("GetNumXCells", &sdf_tools::DeviceSignedDistanceField::GetNumXCells)
+        .def("GetNumYCells", &sdf_tools::DeviceSignedDistanceField::GetNumYCells)
+        .def("GetNumZCells", &sdf_tools::DeviceSignedDistanceField::GetNumZCells)
+        .def("GetExtrema", &sdf_tools::DeviceSignedDistanceField::GetExtrema)
+        .def("HostCopyExists", &sdf_tools::DeviceSignedDistanceField::HostCopyExists)
+        .def("DevicePointer", [](sdf_tools::DeviceSignedDistanceField& d) { return (uintptr_t)d.DevicePointer(); },
+             "address of the [x][y][z] fp32 field in HBM (e.g. for torch / the *_device ABI)")
+        .def("Host", [](const sdf_tools::DeviceSignedDistanceField& d) { return d.Host(); }, "the reference's container (downloads once)")
+        .def("QueryBatch", [](const sdf_tools::DeviceSignedDistanceField& d,
+                              const py::array_t<double, py::array::c_style | py::array::forcecast>& points, bool enable_edge_gradients) {
+            if (points.ndim() != 2 || points.shape(1) != 3) throw std::invalid_argument("points must be [n, 3] float64 (world frame)");
+            const int64_t n = points.shape(0);
+            py::array_t<double> dist({n}), grad({n, (int64_t)3});
+            py::array_t<uint8_t> flags({n});
+            {
+                py::gil_scoped_release release;
+                d.QueryBatch(points.data(), n, enable_edge_gradients, dist.mutable_data(), grad.mutable_data(), flags.mutable_data());
+            }
+            return py::make_tuple(dist, grad, flags);
+        }, py::arg("points"), py::arg("enable_edge_gradients") = false,
+           "n x EstimateDistance3d + GetGradient3d (sdf.hpp:947-953, :395-403) in one kernel: (distance [n], gradient [n, 3], flags [n]: "
+           "bit 0 inside the grid, bit 1 gradient available)");
+
     py::class_<CollisionMapGrid>(m, "CollisionMapGrid")
         .def(py::init<Isometry3d const&, std::string, double, int64_t, int64_t, int64_t, COLLISION_CELL const&>())
         .def("SetValue", [](CollisionMapGrid& g, int64_t x, int64_t y, int64_t z, const COLLISION_CELL& c) { return g.SetValue(x, y, z, c); })
@@ -154,6 +221,11 @@ PYBIND11_MODULE(pysdf_tools, m) {
         .def("GetNumYCells", &CollisionMapGrid::GetNumYCells)
         .def("GetNumZCells", &CollisionMapGrid::GetNumZCells)
         .def("ExtractSignedDistanceField", &CollisionMapGrid::ExtractSignedDistanceField, py::call_guard<py::gil_scoped_release>())
+        .def("ExtractSignedDistanceFieldDevice", [](const CollisionMapGrid& g, float oob_value, bool unknown_is_filled, bool add_virtual_border) {
+                 auto r = g.ExtractSignedDistanceFieldDevice(oob_value, unknown_is_filled, add_virtual_border);
+                 std::unique_ptr<sdf_tools::DeviceSignedDistanceField> field(new sdf_tools::DeviceSignedDistanceField(std::move(r.first)));
+                 return py::make_tuple(py::cast(std::move(field)), r.second);
+             }, "ExtractSignedDistanceField with the field left in HBM -> (DeviceSignedDistanceField, (max, min))")
         .def("ExtractSignedDistanceFieldViaPredicate", &CollisionMapGrid::ExtractSignedDistanceFieldViaPredicate,
              py::call_guard<py::gil_scoped_release>())
         // the reference's cell-predicate overload (sdf_generation.hpp:422-441) with a Python predicate on the cell

@@ -56,6 +56,7 @@ struct sdfgpu_context {
     DeviceBuffer tagids;     // uint32 object id filter
     DeviceBuffer stage_in;   // host-API staging: mask / cells
     DeviceBuffer stage_out;  // host-API staging: sdf
+    DeviceBuffer query_stage;   // host-API staging of sdfgpu_query_points: points | distance | gradient | flags
     size_t tag_cached_bytes = 0;            // stage_in holds the tagged cell records of the last sdfgpu_build_tagged_cells call
     void* pin[2] = {nullptr, nullptr};      // pinned host staging of copy_to_host (two chunks in flight)
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
@@ -65,6 +66,8 @@ struct sdfgpu_context {
     int64_t last_n = 0;
     bool have_result = false;
     bool last_fused = false;
+    bool last_standby = false;       // the last build carried the far-field stand-by pair behind a trusted dense tier
+    bool last_dense3 = false, last_staged = false;   // ... ran KD3 + KF in KD's place / carried them behind KD, guarded on its verdict
     int tune_ty = 0, tune_tx = 0, tune_tzy = 0, fused_h = 0;
     bool fused_zy = true;            // use K12 (z sweep fused into the y sweep) when the shape allows
     bool dense_on = true;            // try the bit-parallel dense kernel first when the shape allows
@@ -105,6 +108,10 @@ struct sdfgpu_context {
     int far_thr[2] = {16, 9};
     int far_den[2] = {5, 24};
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
+    bool standby_far = true;         // stand-by pipeline behind a trusted dense tier = the far-field pair (bounded whatever the scene
+                                     // turns into), not fused K12 + K3/16 with unbounded scans (option "standby_far")
+    bool standby_launch = false;     // set while a build enqueues that stand-by: small grids (what a guarded exit costs grows with the grid)
+    bool dc_attr_set[8] = {false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
@@ -227,7 +234,7 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
         // at 512^3: 8 per CU 0.099 ms, 16 0.093, 32 0.088, one step per wave 0.100)
         const int rw = 1024 / (int)nz;                                  // rows per wave step
         const int64_t ngroups = (nrows + rw - 1) / rw;
-        dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), 8192));
+        dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), h->standby_launch ? 2048 : 8192));
         switch ((int)nz) {
             case 64: hipLaunchKernelGGL(k_sweep_z_wave16<4>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
             case 128: hipLaunchKernelGGL(k_sweep_z_wave16<8>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
@@ -424,6 +431,8 @@ struct DcExtra {                 // int32 plane fields instead of p16 + side tab
     int32_t* out_i32 = nullptr;
     int64_t y_off = 0, ny_glob = -1;
     const uint32_t* i32_flag = nullptr;     // device word: use the int32 fields only when it is non-zero (nullptr: always)
+    bool loop = false;                      // LOOP form of the kernel: a small grid whose workgroups walk the tiles (stand-by launches)
+    uint32_t* ran_flag = nullptr;           // status word raised by a launch that does work
 };
 struct DcDecide {                // a probe launch turns its counters into the tier decision itself (last workgroup)
     int stage = 0; bool dense_tried = false, handoff = false, window_choice = false;
@@ -474,7 +483,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         if (ex) {
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
+            a.ran_flag = ex->ran_flag;
         }
+        const bool loop = ex && ex->loop && !probe_out;
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
 #ifdef SDFGPU_DEBUG_HOOKS
         a.dbg = h->dc_debug;
@@ -543,17 +554,30 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         //  workgroups per CU -- with 128 or 256 lanes are 12 - 25 % slower than 16 lines x 256 lanes, 16 lines x 512 lanes
         //  +-5 %, 32 lines x 512 lanes +-3 %; 2 instead of 4 workgroups per CU is 1.55x slower)
         constexpr int NT = 256;
+        a.ntiles = ntiles;
+        // LOOP form: at most 2048 workgroups (a guarded exit costs 1.7 us up to there and grows with the grid), a multiple of 8
+        // so that a workgroup's tiles stay on its XCD
+        const int64_t nwg = loop ? std::min<int64_t>(ntiles, 2048) : ntiles;
+        const int which = (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0);
         auto launch = [&](auto kern) -> int {
-            if (lds > 64 * 1024) HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3((unsigned)NT), lds, s, a);
+            // (the attribute is per kernel: raised once per instantiation, not on every launch -- ADVICE r3)
+            if (lds > 64 * 1024 && !h->dc_attr_set[which]) {
+                HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                h->dc_attr_set[which] = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((unsigned)NT), lds, s, a);
             return SDFGPU_OK;
         };
         int rc;
-        switch ((stage == 3 ? 1 : 0) + (vec ? 2 : 0)) {
+        switch (which) {
             case 0: rc = launch(k_envelope_dc<2, false, 256, 16>); break;
             case 1: rc = launch(k_envelope_dc<3, false, 256, 16>); break;
             case 2: rc = launch(k_envelope_dc<2, true, 256, 16>); break;
-            default: rc = launch(k_envelope_dc<3, true, 256, 16>); break;
+            case 3: rc = launch(k_envelope_dc<3, true, 256, 16>); break;
+            case 4: rc = launch(k_envelope_dc<2, false, 256, 16, true>); break;
+            case 5: rc = launch(k_envelope_dc<3, false, 256, 16, true>); break;
+            case 6: rc = launch(k_envelope_dc<2, true, 256, 16, true>); break;
+            default: rc = launch(k_envelope_dc<3, true, 256, 16, true>); break;
         }
         if (rc) return rc;
         HIP_TRY(h, hipGetLastError());
@@ -770,8 +794,11 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         // seeds of three certify) every failed build ran those scans over a sparse grid -- 4.6 ms, 1.94 ms per build over
         // the rotation.  A handle in fix-up mode earns the cheap stand-by with 4 certified reports in a row and loses it
         // with the first failure; until then the stand-by is the full pipeline (bounded scans, probes, far-field kernels).
-        if (h->prev_dense && h->prev_fix_mode) h->fix_trust = general_ran ? 0 : std::min(255, h->fix_trust + 1);
-        h->expect_dense = !general_ran && (!h->prev_fix_mode || h->fix_trust >= 4);
+        // (a STAGED build that KD failed and the fix-up stage certified -- status word 8 = KD's own verdict -- is a fix-up-mode
+        //  report like any other: it counts toward the trust and is held to it)
+        const bool via_fix = h->prev_fix_mode || (h->prev_staged && h->h_flags[8] != 0);
+        if (h->prev_dense && via_fix) h->fix_trust = general_ran ? 0 : std::min(255, h->fix_trust + 1);
+        h->expect_dense = !general_ran && (!via_fix || h->fix_trust >= 4);
         //   dense attempted but not certified -> pack + ball were wasted (0.13 ms at 512^3): leave them out of the
         //                       next dense_retry - 1 builds, then try once more
         //   almost dense (the ball kernel left voxels undecided): first try the fix-up kernel behind it; only if that
@@ -797,8 +824,15 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // bounded marching scans + the far-field kernel behind them, on every shape that kernel takes; other shapes (lines beyond
     // 2048, keys beyond 32 bits) keep unbounded marching scans.  Shapes without the 16-bit plane field (nz % 4 != 0) hand
     // exact int32 plane values from the y to the x sweep.
-    const bool envelope = h->envelope_on && !(h->expect_dense && dense) &&
-                          far_geometry_ok(h, 2, nx, ny, nz) && far_geometry_ok(h, 3, nx, ny, nz);
+    const bool far_ok = h->envelope_on && far_geometry_ok(h, 2, nx, ny, nz) && far_geometry_ok(h, 3, nx, ny, nz);
+    const bool envelope = far_ok && !(h->expect_dense && dense);
+    // Stand-by behind a TRUSTED dense tier (round 4).  It nearly always exits on its guard, so it must be
+    // few launches with small grids -- and since the scene of a stream can change under the handle (dense -> far-field), it
+    // must be BOUNDED whatever the scene turns into.  That is the far-field pair with no probes and no marching sweeps:
+    // K1 [guard] -> KE2 [guard] -> KE3 [guard], int32 hand-off, LOOP form (<= 2048 workgroups each): three guarded launches
+    // like the K12 + K3/16 pair it replaces, O(L log L) per line on any input (the old pair ran unbounded outward scans:
+    // tens of ms on the build in which a dense scene turned into the two-box cloud).
+    const bool standby = far_ok && h->standby_far && h->expect_dense && dense && !h->fused_always;
     // Device-side tier selection: the marching-vs-far-field choice of each axis is made INSIDE this build from a probe of the
     // sweep's own input, so a fresh context (the reference's API is one-shot: collision_map.hpp:680-712 builds and returns)
     // never runs a sweep that is thrown away, and a handle's latency does not depend on what it built before.
@@ -806,7 +840,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // K12 (fused z+y) only as the guarded stand-by behind a dense build that is expected to be certified
     // again; everywhere else K1 + K2 (rows from the int16 z field) scan much faster than the fused kernel
     // recomputes, and only they can hand a far-field y sweep to the envelope kernel.
-    const bool fused = !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
+    const bool fused = !standby && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
     const bool select = dev_select && !fused;
     if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
@@ -895,14 +929,19 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     } else {
         HIP_TRY(h, mark(1));
     }
+    h->last_dense3 = cur_dense3;
+    h->last_staged = cur_staged;
     HIP_TRY(h, mark(2));
     h->last_fused = fused;
+    h->last_standby = standby;
     h->last_plane16 = p16;
     h->far_y = (envelope && !fused) ? h->d_small + 4 : nullptr;
     h->scan_y = h->scan_x = kScanExpectNear;
     if (!fused) {
-        if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
-                                    (int16_t*)h->zfield.ptr, s)) return rc;
+        h->standby_launch = standby;
+        const int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz, (int16_t*)h->zfield.ptr, s);
+        h->standby_launch = false;
+        if (rc) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(3));
@@ -923,6 +962,20 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // (the radius-8 y window exists for 4-voxel lanes only; a forced window leaves nothing to choose)
     const bool window_choice = select && (nz % 4) == 0 && h->march_h != 8 && h->mid_den_y > 0;
     auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff, window_choice); };   // probe counters -> guard words
+    DcExtra sb2{}, sb3{};                                       // stand-by pair: int32 hand-off unconditionally, LOOP form, self-reporting
+    sb2.out_i32 = (int32_t*)h->yzfield.ptr; sb2.loop = true; sb2.ran_flag = h->d_small + 4;
+    sb3.in_i32 = (const int32_t*)h->yzfield.ptr; sb3.loop = true; sb3.ran_flag = h->d_small + 5;
+    if (standby) {
+        HIP_TRY(h, mark(4));                                    // (stage slot 3, the marching y sweep: nothing launched)
+        if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nx, ny, nz, resolution, vb,
+                                     h->d_small, general_guard, s, 0, nullptr, &sb2)) return rc;
+        launched_since_mark = true;
+        HIP_TRY(h, mark(5));
+        HIP_TRY(h, mark(6));                                    // (stage slot 5, the marching x sweep: nothing launched)
+        if (int rc = launch_envelope(h, 3, nullptr, nullptr, d_out, nullptr, nx, ny, nz, resolution, vb, h->d_small,
+                                     general_guard, s, 0, nullptr, &sb3)) return rc;
+        launched_since_mark = true;
+    } else {
     if (select) {
         // probe + decision in one launch (the probe's last workgroup decides); a forced tier needs no probe
         DcDecide dy; dy.stage = 0; dy.dense_tried = dense; dy.handoff = handoff; dy.window_choice = window_choice;
@@ -988,6 +1041,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                                      nx, ny, nz, resolution, vb, h->d_small, h->d_small + 5, s, 0, nullptr, ex3)) return rc;
         launched_since_mark = true;
     }
+    }   // (!standby)
     // one kernel folds the maxima, publishes the status block (device copy for get_extrema, pinned host copy for the
     // next build's policy) and clears it for the next build
     // The report (status block -> pinned host memory + an event) is only taken when the previous report has been
@@ -1029,14 +1083,15 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
 // the faults and the runtime's pinning of the source pages fought over the address space, and the 128 MiB upload took
 // 29 ms instead of 2.5.)  Returns when the data is in dst.
 constexpr size_t kPinChunk = (size_t)32 << 20;
+constexpr size_t kPinMin = (size_t)4 << 20;      // below this a plain (runtime-staged) copy is as fast as the team
 
 int copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, hipStream_t st = nullptr) {
     if (bytes == 0) return SDFGPU_OK;
-    for (int i = 0; i < 2 && bytes >= kPinChunk; ++i) {
+    for (int i = 0; i < 2 && bytes >= kPinMin; ++i) {
         if (!h->pin[i] && hipHostMalloc(&h->pin[i], kPinChunk, hipHostMallocDefault) != hipSuccess) h->pin[i] = nullptr;
         if (h->pin[i] && !h->pin_ev[i] && hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) h->pin_ev[i] = nullptr;
     }
-    if (bytes < kPinChunk || !h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
+    if (bytes < kPinMin || !h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
         HIP_TRY(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(h, hipStreamSynchronize(st));
         return SDFGPU_OK;
@@ -1101,11 +1156,11 @@ int copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, hi
 // Enqueued on `st`; returns when the last chunk's DMA has completed.
 int copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, hipStream_t st = nullptr) {
     if (bytes == 0) return SDFGPU_OK;
-    for (int i = 0; i < 2 && bytes >= kPinChunk; ++i) {
+    for (int i = 0; i < 2 && bytes >= kPinMin; ++i) {
         if (!h->pin[i] && hipHostMalloc(&h->pin[i], kPinChunk, hipHostMallocDefault) != hipSuccess) h->pin[i] = nullptr;
         if (h->pin[i] && !h->pin_ev[i] && hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) h->pin_ev[i] = nullptr;
     }
-    if (bytes < kPinChunk || !h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
+    if (bytes < kPinMin || !h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
         HIP_TRY(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, st));
         HIP_TRY(h, hipStreamSynchronize(st));
         return SDFGPU_OK;
@@ -1156,18 +1211,20 @@ int copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, 
     return SDFGPU_OK;
 }
 
+// d_out_user != nullptr: the field stays on the device in the caller's buffer (no download; out_sdf is unused)
 int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t stride, size_t off,
                     int unknown, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb, float* out_sdf,
-                    double* out_max, double* out_min) {
+                    double* out_max, double* out_min, float* d_out_user = nullptr) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
-    if ((!filled && !cells) || !out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
+    if ((!filled && !cells) || (!out_sdf && !d_out_user)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
     if (int rc = check_dims(h, nx, ny, nz)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nx * ny * nz;
     const size_t in_bytes = cells ? (size_t)n * stride : (size_t)n;
     h->tag_cached_bytes = 0;                        // (stage_in is about to be overwritten)
     if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
-    if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
+    if (!d_out_user) if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
+    float* const d_out = d_out_user ? d_out_user : (float*)h->stage_out.ptr;
     const bool timing = getenv("SDFGPU_HOST_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t1 = now();
@@ -1176,10 +1233,10 @@ int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, s
     const double t2 = now();
     int rc = build_device_impl(h, cells ? nullptr : (const uint8_t*)h->stage_in.ptr,
                                cells ? h->stage_in.ptr : nullptr, stride, off, unknown, nx, ny, nz, resolution,
-                               vb, (float*)h->stage_out.ptr, nullptr);
+                               vb, d_out, nullptr);
     if (rc) return rc;
     const double t3 = now();
-    if (int rc2 = copy_to_host(h, out_sdf, h->stage_out.ptr, (size_t)n * 4)) return rc2;
+    if (!d_out_user) if (int rc2 = copy_to_host(h, out_sdf, h->stage_out.ptr, (size_t)n * 4)) return rc2;
     const double t5 = now();
     double mx, mn;
     rc = sdfgpu_get_extrema(h, &mx, &mn);
@@ -1244,7 +1301,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
     for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->unc, &h->tileflag, &h->fix_order, &h->tagmask, &h->tagids, &h->stage_in,
-                            &h->stage_out})
+                            &h->stage_out, &h->query_stage})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
     if (h->d_slots) (void)hipFree(h->d_slots);
@@ -1274,6 +1331,24 @@ int sdfgpu_build_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, s
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
     return build_host_impl(h, nullptr, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz,
                            resolution, add_virtual_border, out_sdf, out_max, out_min);
+}
+
+int sdfgpu_build_to_device(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                           int add_virtual_border, float* d_out_sdf, double* out_max, double* out_min) {
+    if (h && !d_out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_out_sdf is null");
+    return build_host_impl(h, filled, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, nullptr, out_max, out_min,
+                           d_out_sdf);
+}
+
+int sdfgpu_build_cells_to_device(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                                 int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                 int add_virtual_border, float* d_out_sdf, double* out_max, double* out_min) {
+    if (h && !cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cells is null");
+    if (h && !d_out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_out_sdf is null");
+    if (h && (cell_stride < 4 || (cell_stride % 4) || (occupancy_offset % 4) || occupancy_offset + 4 > cell_stride))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
+    return build_host_impl(h, nullptr, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz, resolution,
+                           add_virtual_border, nullptr, out_max, out_min, d_out_sdf);
 }
 
 int sdfgpu_build_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nx, int64_t ny, int64_t nz,
@@ -1713,6 +1788,51 @@ int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, 
     return SDFGPU_OK;
 }
 
+int sdfgpu_device_malloc(sdfgpu_handle h, size_t bytes, void** out_ptr) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!out_ptr) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "out_ptr is null");
+    *out_ptr = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMalloc(out_ptr, std::max<size_t>(bytes, 256)));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_device_free(sdfgpu_handle h, void* ptr) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!ptr) return SDFGPU_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipFree(ptr));
+    return SDFGPU_OK;
+}
+
+int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                        const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
+                        const double* points, int64_t n_points, int enable_edge_gradients, double* out_distance,
+                        double* out_gradient, uint8_t* out_flags) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_sdf || (n_points > 0 && !points)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
+    if (n_points < 0 || !(resolution > 0.0)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad point count or resolution");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    if (n_points == 0 || (!out_distance && !out_gradient && !out_flags)) return SDFGPU_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    // staging in the context (grown on demand, re-used by the next call): points | distance | gradient | flags
+    const size_t n = (size_t)n_points;
+    const size_t o_d = n * 24, o_g = o_d + n * 8, o_f = o_g + n * 24, total = o_f + ((n + 255) & ~(size_t)255);
+    if (int rc = ensure(h, h->query_stage, total)) return rc;
+    char* base = (char*)h->query_stage.ptr;
+    hipStream_t s = h->last_stream;                  // (ordered behind the build that produced the field, if it ran on this handle)
+    if (int rc = copy_from_host(h, base, points, n * 24, s)) return rc;
+    if (int rc = sdfgpu_query_points_device(h, d_sdf, nx, ny, nz, resolution, world_to_grid, grid_to_world_rotation, oob_value,
+                                            (const double*)base, n_points, enable_edge_gradients,
+                                            out_distance ? (double*)(base + o_d) : nullptr,
+                                            out_gradient ? (double*)(base + o_g) : nullptr,
+                                            out_flags ? (uint8_t*)(base + o_f) : nullptr, s)) return rc;
+    if (out_distance) if (int rc = copy_to_host(h, out_distance, base + o_d, n * 8, s)) return rc;
+    if (out_gradient) if (int rc = copy_to_host(h, out_gradient, base + o_g, n * 24, s)) return rc;
+    if (out_flags) if (int rc = copy_to_host(h, out_flags, base + o_f, n, s)) return rc;
+    return SDFGPU_OK;
+}
+
 int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {
     if (!h || !out_host) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!h->have_result || n > h->last_n) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no matching build");
@@ -1806,6 +1926,8 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "ball_variant") h->ball_variant = value;
 #endif
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
+    else if (n == "standby_far") h->standby_far = value != 0;
+    else if (n == "expect_dense") h->expect_dense = value != 0;      // tests: put the handle into the "dense tier trusted" state
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
@@ -1833,7 +1955,8 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
 
 int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy) {
     if (!h || !out_fused_zy) return SDFGPU_ERR_INVALID_ARGUMENT;
-    *out_fused_zy = (h->last_fused ? 1 : 0) | (h->last_plane16 ? 2 : 0) | (h->last_dense ? 4 : 0);
+    *out_fused_zy = (h->last_fused ? 1 : 0) | (h->last_plane16 ? 2 : 0) | (h->last_dense ? 4 : 0) | (h->last_standby ? 8 : 0) |
+                    (h->last_dense3 ? 16 : 0) | (h->last_staged ? 32 : 0);
     return SDFGPU_OK;
 }
 

@@ -378,7 +378,13 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
     }
     if ((t & 63) == 0) {
         const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
-        slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
+        // The early-out test at the top is per wave: if the flag rises between the loads of two waves of one workgroup, some
+        // waves leave and the others run on over a partly staged tile -- what they find is garbage.  The field is rewritten
+        // by the stage behind (the flag is up), but maxima are max-folded: they must not leave this wave.  A wave that can
+        // have been affected sees the flag set HERE (it only ever rises), and then the stage behind recomputes every
+        // maximum anyway.
+        const bool void_maxima = a.early_out && __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (!void_maxima) slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
         if (any_uncert) {
             if (a.unc) {
                 atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up
@@ -441,10 +447,6 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
     const uint32_t flags = a.tileflag[tile_id];               // wave-uniform
     if (flags == 0u) return;
-    if (__hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {   // the general sweeps will redo the grid anyway
-        if (threadIdx.x == 0) a.tileflag[tile_id] = 0u;       // (the flag words stay zero between builds)
-        return;
-    }
     const int t = threadIdx.x;
     const int nzw = a.nzw, lg = a.log2_nzw;
     const int rw = nzw + 2;                                   // one replicated edge word on each side
@@ -453,10 +455,18 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     uint32_t* list = order + kFixOrderPad;                    // [kFixCap] (tile row << 16) | z
     uint32_t* count = list + kFixCap;                         // [1] (+ pad to 4 words)
     uint32_t* tile = count + 4;                               // [hx][hy][rw]
-    if (t == 0) { *count = 0u; a.tileflag[tile_id] = 0u; }
+    // "the general sweeps will redo the grid anyway": ONE lane reads the flag for the whole workgroup (count[1]) -- read per
+    // wave, two waves could see it on either side of its rise, wave 0 would leave without clearing the list counter and the
+    // others would walk a garbage list.  (The flag words stay zero between builds: cleared either way.)
+    if (t == 0) {
+        *count = 0u;
+        count[1] = __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int i = t; i < kFixRows; i += BD) order[i] = a.order[i];
     const int x0 = a.out_lo + (int)blockIdx.y * a.tx, y0 = (int)blockIdx.x * a.ty;
     __syncthreads();
+    if (t == 0) a.tileflag[tile_id] = 0u;                     // (behind the barrier: every wave has read its copy of the word)
+    if (count[1] != 0u) return;                               // (block-uniform)
     // this lane's word (same mapping as KD) -> list of its undecided voxels
     {
         const int r = t >> lg, w = t & (nzw - 1);

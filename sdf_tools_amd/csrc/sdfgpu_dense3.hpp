@@ -302,7 +302,13 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
     }
     if ((t & 63) == 0) {
         const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
-        slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
+        // The early-out test at the top is per wave: if the flag rises between the loads of two waves of one workgroup, some
+        // waves leave and the others run on over a partly staged tile -- what they find is garbage.  The field is rewritten
+        // by the stage behind (the flag is up), but maxima are max-folded: they must not leave this wave.  A wave that can
+        // have been affected sees the flag set HERE (it only ever rises), and then the stage behind recomputes every
+        // maximum anyway.
+        const bool void_maxima = a.early_out && __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (!void_maxima) slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
         if (any_uncert) {
             if (a.unc) {
                 atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up

@@ -103,6 +103,8 @@ struct EnvDcArgs {
     int64_t group_lines;      // lines per outer unit (tiles that stick out replicate the last line)
     unsigned long long* clocks;   // SDFGPU_PHASE_CLOCKS builds only: per-phase shader-clock sums over waves ([stage - 2][8])
     int dbg;                  // SDFGPU_DEBUG_HOOKS builds only (wrong results): bit0 no search, bit1 no fp64 finish, bit2 no stores
+    int64_t ntiles;           // LOOP form: tiles of the whole launch (a workgroup takes tiles blockIdx.x, + gridDim.x, ...)
+    uint32_t* ran_flag;       // nullptr, or a status word that a launch which does work raises (the stand-by pair reports itself)
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -289,7 +291,12 @@ __global__ __launch_bounds__(256) void k_probe_window(const ProbeArgs a) {
 // NL lines per tile, NT lanes: S = NT / NL lanes ("slots") per line.  The kernel is sensitive to how many WORKGROUPS a CU
 // holds (their phases interleave; 2 instead of 4 per CU is 1.55x slower), and that number is set by the LDS footprint:
 // 16 lines x 512 positions x 4 B of keys = 39 KB -> 4 per CU; 8 lines -> 20 KB -> 7 - 8 per CU.
-template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines>
+//
+// LOOP (round 4): the stand-by form behind a trusted dense tier.  Such a launch nearly always exits on its guard, and what a
+// guarded exit costs grows with the grid (1.7 us up to 2048 workgroups, 2.9 us at 8192, tools/probe/launch_probe.hip): the
+// LOOP form is launched with at most 2048 workgroups that take tiles blockIdx.x, + gridDim.x, ... -- static assignment,
+// a few % slower than one tile per workgroup when it does run (the build in which a scene leaves the dense tier).
+template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines, bool LOOP = false>
 __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envelope_dc(const EnvDcArgs a) {
     constexpr int S = NT / NL;              // lanes per line
     constexpr int LPR = NL / 4;             // staging: lanes per row (4 lines each)
@@ -320,16 +327,21 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
 #ifdef SDFGPU_PHASE_CLOCKS
     unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #endif
+    if (a.ran_flag && blockIdx.x == 0 && t == 0) *a.ran_flag = 1u;
+    int mxF = 0, mxQ = 0;
+    const uint32_t nblk = LOOP ? (uint32_t)a.ntiles : gridDim.x;          // "virtual" workgroups = tiles
+    uint32_t vblk = blockIdx.x;
+    do {
 
     // tile of this workgroup.  Four consecutive tiles share cache lines (16 lines x 2 B = 32 B of a 128-B line), so an XCD
     // (workgroups are dealt to the 8 XCDs round-robin, each with its own L2) gets runs of 4 consecutive tiles; the runs
     // themselves are dealt round-robin, so that every XCD sees every part of the grid (work is not uniform in space)
-    int64_t tile = blockIdx.x;
-    const bool probe = a.probe_stride > 0;
+    int64_t tile = vblk;
+    const bool probe = !LOOP && a.probe_stride > 0;
     if (probe) {
         tile = (int64_t)blockIdx.x * a.probe_stride + (blockIdx.x * 7u) % (uint32_t)a.probe_stride;
-    } else if ((gridDim.x & 31u) == 0u) {
-        const uint32_t xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+    } else if ((nblk & 31u) == 0u) {
+        const uint32_t xcd = vblk & 7u, seq = vblk >> 3;
         tile = ((int64_t)(seq >> 2) * 8 + xcd) * 4 + (seq & 3u);
     }
     const int64_t o = tile / a.tiles_per_outer;
@@ -342,7 +354,6 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
     const int32_t* const in32 = (STAGE == 3 && a.in_i32 && i32) ? a.in_i32 + base : nullptr;
     const bool out32 = STAGE == 2 && a.out_i32 && i32;
 
-    int mxF = 0, mxQ = 0;
     auto byz_of = [&](int line) -> int {        // virtual-border distance of a line to the padded layer over y and z
         int64_t b = kInf32;
         if constexpr (STAGE == 3) {
@@ -791,7 +802,9 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
     // The second pass (distance to free, for filled voxels) runs only when pass 0 asked for it: a filled voxel whose in-row
     // squared distance S is small is finished by pass 0 itself with a local search (candidates at offset d can only matter
     // while d^2 < S), which covers the thin surfaces of sensed scenes; pass 0 raises misc[25] for the rest.
-    if (!probe && misc[25] != 0u) run_pass(std::integral_constant<int, 1>{});      // (block-uniform)
+    const bool second = !probe && misc[25] != 0u;                                  // (block-uniform)
+    if constexpr (LOOP) __syncthreads();            // (the next tile's first pass clears misc: everybody has read it)
+    if (second) run_pass(std::integral_constant<int, 1>{});
 
 #ifdef SDFGPU_PHASE_CLOCKS
     if (a.clocks && (t & 63) == 0 && !probe && (blockIdx.x & 31u) == 5u) {     // a sample: same-address atomics serialise
@@ -817,6 +830,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
         probe_done(a);
         return;
     }
+    } while (LOOP && (vblk += gridDim.x) < nblk);
     if constexpr (STAGE == 3) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {

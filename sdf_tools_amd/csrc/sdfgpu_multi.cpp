@@ -58,6 +58,16 @@ struct sdfgpu_multi_context {
     int halo = 3;
     bool dense_on = true;
     int last_path = 0;
+    // General path without a host decision in the middle (round 4).  Which x sweep a general build runs -- halo planes +
+    // slab-local sweep, or the re-partition to complete lines -- used to be decided by reading every rank's far hint back
+    // after the z / y sweeps (one host round trip with all GPUs idle), and a second read found out whether the halo had
+    // been enough.  RCCL sends cannot be guarded by a device word, so the choice is now PREDICTED from the previous
+    // general build and validated by the ONE read at the end that the synchronous API needs anyway (maxima, completion):
+    // a wrong "near" costs the re-partition on top (exact either way), a wrong "far" costs nothing but the next prediction.
+    bool predict_far = false;
+    int whole_hold = 0;             // builds left that keep the whole-line sweep after a halo sweep came back unresolved
+    int host_reads = 0;             // read_small round trips of the last build
+    int mispredictions = 0;         // general builds (since creation) whose predicted x sweep had to be redone
 };
 
 namespace {
@@ -175,6 +185,7 @@ int exchange_msgs(sdfgpu_multi_handle h, const std::vector<Msg>& msgs) {
 }
 
 int read_small(sdfgpu_multi_handle h) {         // status blocks of all ranks -> pinned host memory, then wait
+    ++h->host_reads;
     for (Rank& k : h->r) {
         M_HIP(h, hipSetDevice(k.dev));
         M_HIP(h, hipMemcpyAsync(k.h_small, k.d_small, 32, hipMemcpyDeviceToHost, k.s));
@@ -215,6 +226,7 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
         if (!d_mask[q] || !d_out[q]) return mfail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null slab pointer for rank %d", q);
     }
     h->last_path = h->use_rccl ? 4 : 0;
+    h->host_reads = 0;
     uint32_t max_f = 0, max_q = 0;
 
     // ---- dense tier: pack -> 2 bit-planes per neighbour -> ball kernel -----------------------------------------------
@@ -277,9 +289,9 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
             M_SDF(h, q, sdfgpu_sweep_zy_tiered_device(k.ctx, d_mask[q], nxs, ny, nz, (int32_t*)k.ext.p + hl * plane,
                                                       k.d_small + 4, k.s));
         }
-        if (int rc = read_small(h)) return rc;
-        bool far = false;
-        for (Rank& k : h->r) far |= k.h_small[4] != 0;
+        // (no host read here: the far hints stay in d_small[4] and come back with the final status block)
+        bool far = h->predict_far || h->whole_hold > 0;
+        bool hinted = false;
         if (!far) {
             // ---- near-field: `halo` int32 planes per neighbour, x sweep that reports voxels needing more ----------------
             if (int rc = comm_after_compute(h)) return rc;
@@ -301,14 +313,22 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
                 M_SDF(h, q, sdfgpu_sweep_x_device(k.ctx, (const int32_t*)k.ext.p, hl, nxs, hh, ny, nz, k.x0 - hl > 0,
                                                   k.x1 + hh < nx, k.x0, nx, res, vb, d_out[q], k.d_small, k.d_small + 2, k.s));
             }
-            if (int rc = read_small(h)) return rc;
+            if (int rc = read_small(h)) return rc;             // the build's one host round trip when the prediction holds
             max_f = max_q = 0;
+            bool unresolved = false;
             for (Rank& k : h->r) {
-                far |= k.h_small[2] != 0;
+                unresolved |= k.h_small[2] != 0;
+                hinted |= k.h_small[4] != 0;
                 max_f = std::max(max_f, k.h_small[0]);
                 max_q = std::max(max_q, k.h_small[1]);
             }
-        }
+            far = unresolved || hinted;
+            if (far) {
+                ++h->mispredictions;
+                h->predict_far = hinted;
+                if (unresolved && !hinted) h->whole_hold = 8;   // near-field clutter with a cavity deeper than the halo:
+            }                                                   // stay on complete lines for a while instead of flapping
+        } else if (h->whole_hold > 0) --h->whole_hold;
         if (far) {
             // ---- far-field: x slabs -> y slabs, exact x sweep on complete lines, back to x slabs ------------------------
             h->last_path |= 2;
@@ -350,7 +370,7 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
                 Rank& k = h->r[q];
                 const int64_t nys = k.y1 - k.y0;
                 M_HIP(h, hipSetDevice(k.dev));
-                M_HIP(h, hipMemsetAsync(k.d_small, 0, 32, k.s));
+                M_HIP(h, hipMemsetAsync(k.d_small, 0, 16, k.s));      // (maxima, status; word 4 keeps the far hint)
                 if (nys > 0)
                     M_SDF(h, q, sdfgpu_sweep_x_lines_device(k.ctx, (const int32_t*)k.lines.p, nx, nys, nz, k.y0, ny, res, vb,
                                                             (float*)k.out_y.p, k.d_small, k.s));
@@ -390,7 +410,10 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
             for (Rank& k : h->r) {
                 max_f = std::max(max_f, k.h_small[0]);
                 max_q = std::max(max_q, k.h_small[1]);
+                hinted |= k.h_small[4] != 0;
             }
+            // (the whole-line sweep is exact on any scene: a stale "far" costs nothing but this update)
+            h->predict_far = hinted;
         }
     }
     for (Rank& k : h->r) {                      // everything enqueued has finished (read_small synchronised the compute
@@ -588,9 +611,17 @@ int sdfgpu_multi_last_path(sdfgpu_multi_handle h, int* out_bits) {
     return SDFGPU_OK;
 }
 
+int sdfgpu_multi_last_stats(sdfgpu_multi_handle h, int* out_host_reads, int* out_mispredictions) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (out_host_reads) *out_host_reads = h->host_reads;
+    if (out_mispredictions) *out_mispredictions = h->mispredictions;
+    return SDFGPU_OK;
+}
+
 int sdfgpu_multi_set_option(sdfgpu_multi_handle h, const char* name, int value) {
     if (!h || !name) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!strcmp(name, "halo")) { h->halo = std::max(0, value); return SDFGPU_OK; }
+    if (!strcmp(name, "predict_far")) { h->predict_far = value != 0; h->whole_hold = 0; return SDFGPU_OK; }
     if (!strcmp(name, "dense")) h->dense_on = value != 0;     // (also forwarded: the ranks' own dense tier is not used here)
     for (size_t q = 0; q < h->r.size(); ++q) M_SDF(h, q, sdfgpu_set_option(h->r[q].ctx, name, value));
     return SDFGPU_OK;

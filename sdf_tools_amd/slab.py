@@ -16,16 +16,19 @@ Dense path (scenes whose every voxel has an opposite-class voxel within squared 
 
 General path (only if some rank raised the flag; exact for any input)
   1. ``sweep_zy``    mask slab -> signed in-plane d^2 (int32); the y sweep's tier (marching / envelope kernel) is
-                     chosen on the device, and a "far" hint comes back with it
-  near-field scenes (hint clear on every rank):
+                     chosen on the device, and a "far" hint is left in the status block
+  Which x sweep follows is PREDICTED from the previous general build (no host read in the middle of a build):
+  predicted near-field:
   2. halo exchange   `halo` int32 planes per neighbour
-  3. ``sweep_x``     x sweep + signed merge; raises a status bit if a voxel needed planes beyond the halo
-  far-field scenes (hint set somewhere, or the status bit of step 3):
+  3. ``sweep_x``     x sweep + signed merge; raises a status bit if a voxel needed planes beyond the halo;
+                     all-reduce(MAX) of {max d^2 free, max d^2 filled, status, far hint} -- the build's ONE host read;
+                     status or hint set: steps 4-6 on top (a misprediction: the scene turned far-field)
+  predicted far-field (or redoing a mispredicted build):
   4. re-partition    x slabs -> y slabs: every rank sends the rows of every other rank's y slab, ONE message per peer
                      and direction (grouped isend/irecv = one message per direct xGMI link; 64 MiB per peer at
                      1024^3 on 8 GPUs), and receives complete x lines of its own y slab: [nx, ny/G, nz]
   5. ``sweep_x_lines``  exact x sweep on complete lines (marching or envelope kernel, chosen on the device)
-  6. re-partition back to x slabs (fp32), all-reduce(MAX) of the integer extrema
+  6. re-partition back to x slabs (fp32), all-reduce(MAX) of the integer extrema and the hint (-> next prediction)
   No rank ever holds more than 1/G of any field.
 
 A build is validated one step late (:meth:`SlabSdfBuilder.build_async` / :meth:`finish`): the
@@ -161,7 +164,10 @@ class SlabSdfBuilder:
         self.y0, self.y1 = slab_range(self.ny, self.rank, self.world)      # this rank's y slab (whole-line x sweep)
         self.lines = None               # [nx, nys, nz] int32: complete x lines of the y slab, allocated on first use
         self.out_y = None               # [nx, nys, nz] fp32
-        self.hint = None                # int32[1]: "far-field" hint of the y sweep
+        self.predict_far = False        # general path: the x sweep predicted for the next build (complete lines / halo)
+        self.whole_hold = 0             # builds left on complete lines after a halo sweep came back unresolved
+        self.host_reads = 0             # host round trips of the general path (one per build when the prediction holds)
+        self.mispredictions = 0         # general builds whose predicted x sweep had to be redone
         self.general_exchange = "halo (near-field) / all-to-all re-partition to y slabs (far-field)"
         self.fallbacks = 0              # whole-line (re-partitioned) x sweeps of the general path
         self.general_builds = 0         # builds the dense path could not certify
@@ -330,7 +336,8 @@ class SlabSdfBuilder:
             w.wait()
 
     def _whole_lines(self, own, slot):
-        """Steps 4-6: x slabs -> y slabs, exact x sweep on complete lines, back to x slabs.  Returns the maxima."""
+        """Steps 4-6: x slabs -> y slabs, exact x sweep on complete lines, back to x slabs.  Returns the maxima and the
+        all-reduced far hint of the y sweeps (status word 3)."""
         nys = self.y1 - self.y0
         if self.lines is None:
             self.lines = torch.empty((self.nx, max(nys, 1), self.nz), dtype=torch.int32, device=self.device)
@@ -352,7 +359,7 @@ class SlabSdfBuilder:
                 if nys > 0:
                     recvs.append((self.lines[xa:xb], r))
         self._p2p(sends, recvs)
-        small.zero_()
+        small[:3].zero_()                   # (word 3 keeps the far hint of the y sweep)
         if nys > 0:
             self.stages.sweep_x_lines(self.lines, self.y0, self.ny, self.resolution, self.vb, self.out_y, small)
             if hasattr(self.stages, "fold"):
@@ -376,36 +383,48 @@ class SlabSdfBuilder:
             ya, yb = ranges_y[r]
             slot.out[:, ya:yb].copy_(t)
         self._allreduce_small(small)
-        max_f, max_q, _, _ = (int(v) for v in small.tolist())
-        return max_f, max_q
+        max_f, max_q, _, hinted = (int(v) for v in small.tolist())
+        self.host_reads += 1
+        return max_f, max_q, hinted
 
     def _build_general(self, mask_slab, slot):
+        """General path with ONE host read per build in the steady state (round 4).  Which x sweep runs -- halo planes +
+        slab-local sweep, or the re-partition to complete lines -- is PREDICTED from the previous general build instead of
+        read back from the GPUs in the middle of the build (a collective plus a host synchronisation with every GPU idle);
+        the far hint rides in word 3 of the status block (unused on this path) and comes back, all-reduced, with the
+        maxima at the end.  A wrong "near" costs the re-partition on top, a wrong "far" costs nothing: the whole-line
+        sweep is exact on any scene.  Every rank sees the same all-reduced block, so every rank predicts alike."""
         if self.ext is None:
             self.ext = torch.empty((self.ext_rows, self.ny, self.nz), dtype=torch.int32, device=self.device)
-            self.hint = torch.zeros(1, dtype=torch.int32, device=self.device)
         lo, n, hi, h = self.halo_lo, self.nxs, self.halo_hi, self.halo
         own = self.ext[lo:lo + n]
-        self.hint.zero_()
-        self.stages.sweep_zy(mask_slab, own, self.hint)
-        if self.world > 1:
-            dist.all_reduce(self.hint, op=dist.ReduceOp.MAX, group=self.group)
-        far = int(self.hint.item()) != 0
         small = slot.small
+        small.zero_()
+        self.stages.sweep_zy(mask_slab, own, small[3:4])
+        far = self.predict_far or self.whole_hold > 0
         if not far:
             for w in self._exchange(self.ext, lo, n, h):
                 w.wait()
-            small.zero_()
             self.stages.sweep_x(self.ext, lo, n, hi, self.x0 - lo > 0, self.x1 + hi < self.nx, self.x0, self.nx,
                                 self.resolution, self.vb, slot.out, small)
             if hasattr(self.stages, "fold"):
                 self.stages.fold(small)
             self._allreduce_small(small)
-            max_f, max_q, status, _ = (int(v) for v in small.tolist())
-            if not status:
+            max_f, max_q, status, hinted = (int(v) for v in small.tolist())
+            self.host_reads += 1
+            if not status and not hinted:
                 return max_f, max_q
-        # far-field scene, or some voxel needed a plane beyond its halo: sweep complete lines
+            # far-field scene, or some voxel needed a plane beyond its halo: sweep complete lines after all
+            self.mispredictions += 1
+            self.predict_far = bool(hinted)
+            if status and not hinted:
+                self.whole_hold = 8             # near-field clutter with a cavity deeper than the halo: do not flap
+        elif self.whole_hold > 0:
+            self.whole_hold -= 1
         self.fallbacks += 1
-        return self._whole_lines(own, slot)
+        max_f, max_q, hinted = self._whole_lines(own, slot)
+        self.predict_far = bool(hinted)
+        return max_f, max_q
 
     # -- public API --------------------------------------------------------------------------------
     def build_async(self, mask_slab):

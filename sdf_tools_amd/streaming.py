@@ -1,11 +1,17 @@
-"""Streaming point cloud -> occupancy -> SDF (+ gradient) on one GPU (BASELINE.json configs[4]).
+"""Streaming point cloud -> occupancy -> SDF -> distance / gradient queries on one GPU (BASELINE.json configs[4]:
+"fused gradient (EstimateDistance/gradient query) kernel").
 
 Everything stays in HBM: the point cloud is voxelised on the device
 (``sdfgpu_voxelize_points_device``, the convention of the reference's scripts/3d_sdf_demo_rviz.py:22-29),
 the SDF is built by the same C-ABI entry point as everywhere else (dense kernel first, general sweeps
-behind it -- point clouds are sparse scenes, so the general path usually does the work) and the
-grid-aligned gradient (sdf.hpp:432-526) is computed for every voxel by one more kernel.  The context's
-scratch buffers are allocated once and re-used by every frame.
+behind it -- point clouds are sparse scenes, so the general path usually does the work), and what the
+consumer of a frame needs from the field -- ``EstimateDistance`` + ``GetGradient`` at ITS points
+(sdf.hpp:922-961, :383-430; a planner's few thousand to a million query points, not 134 M voxels) --
+is answered by one gather kernel (``sdfgpu_query_points_device``: trilinear estimate and gradient fused,
+one lane per point).  That is the default (``gradient="query"``, round 4): a frame no longer writes
+1.6 GB of full-grid gradient that nobody reads back (0.48 of 1.46 ms at 512^3).  The full-grid gradient
+of ``GetFullGradient`` callers (sdf.hpp:341-358, utils_3d.py:77-80) is still there as ``gradient="full"``.
+The context's scratch buffers are allocated once and re-used by every frame.
 """
 import torch
 
@@ -13,7 +19,16 @@ from . import capi
 
 
 class StreamingSdf:
-    def __init__(self, shape, resolution, origin=(0.0, 0.0, 0.0), device_index=0, gradient=True, grad_f64=False):
+    def __init__(self, shape, resolution, origin=(0.0, 0.0, 0.0), device_index=0, gradient="query", grad_f64=False):
+        """gradient: "query" (default) -- frame(points, query_points) answers batched distance + gradient queries on
+        the fresh field; "full" / True -- frame() also writes the grid-aligned gradient of every voxel; None / False --
+        the field only."""
+        if gradient is True:
+            gradient = "full"
+        if gradient not in ("query", "full", None, False):
+            raise ValueError("gradient must be 'query', 'full' or None")
+        self.mode = gradient or None
+        gradient = self.mode == "full"
         self.shape = tuple(int(s) for s in shape)
         self.resolution = float(resolution)
         self.origin = tuple(float(v) for v in origin)
@@ -27,9 +42,13 @@ class StreamingSdf:
             self.gradient = torch.empty(self.shape + (3,), dtype=torch.float64 if grad_f64 else torch.float32,
                                         device=self.device)
 
-    def frame(self, points):
-        """points: [n, 3] float32 device tensor (x, y, z).  Returns (sdf, gradient or None); asynchronous on
-        the current stream."""
+        self._q = None                                  # (distance, gradient, flags) buffers of query-mode frames
+
+    def frame(self, points, query_points=None, enable_edge_gradients=True):
+        """points: [n, 3] float32 device tensor (x, y, z).  Asynchronous on the current stream.
+        Returns (sdf, gradient) in "full" mode (gradient None without it); in "query" mode (sdf, q) with
+        q = (distance [m] f64, gradient [m, 3] f64, flags [m] u8) for query_points [m, 3] float64 (world frame), or
+        None when no query points were given.  The query buffers are re-used by the next frame."""
         assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous() and points.shape[-1] == 3
         s = torch.cuda.current_stream(self.device).cuda_stream
         self.ctx.voxelize_points_device(points.data_ptr(), points.shape[0], self.origin, self.resolution, self.shape,
@@ -38,17 +57,30 @@ class StreamingSdf:
         if self.gradient is not None:
             self.ctx.gradient_device(self.sdf.data_ptr(), self.shape, self.gradient.data_ptr(), self.resolution, True,
                                      self.grad_f64, s)
+        if self.mode == "query":
+            if query_points is None:
+                return self.sdf, None
+            m = query_points.shape[0]
+            if self._q is None or self._q[0].shape[0] < m:
+                self._q = (torch.empty(m, dtype=torch.float64, device=self.device),
+                           torch.empty((m, 3), dtype=torch.float64, device=self.device),
+                           torch.empty(m, dtype=torch.uint8, device=self.device))
+            out = tuple(t[:m] for t in self._q)
+            return self.sdf, self.query(query_points, enable_edge_gradients, out)
         return self.sdf, self.gradient
 
-    def query(self, points, enable_edge_gradients=True):
+    def query(self, points, enable_edge_gradients=True, out=None):
         """Batched EstimateDistance + GetGradient (sdf.hpp:947-961, :383-430) on the current field.
         points: [n, 3] float64 device tensor in the world frame (grid origin = self.origin, axis-aligned).
         Returns (distance [n] f64, gradient [n, 3] f64, flags [n] u8: bit0 inside, bit1 gradient available)."""
         assert points.is_cuda and points.dtype == torch.float64 and points.is_contiguous() and points.shape[-1] == 3
         n = points.shape[0]
-        dist = torch.empty(n, dtype=torch.float64, device=self.device)
-        grad = torch.empty((n, 3), dtype=torch.float64, device=self.device)
-        flags = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if out is not None:
+            dist, grad, flags = out
+        else:
+            dist = torch.empty(n, dtype=torch.float64, device=self.device)
+            grad = torch.empty((n, 3), dtype=torch.float64, device=self.device)
+            flags = torch.empty(n, dtype=torch.uint8, device=self.device)
         ox, oy, oz = self.origin
         w2g = (1, 0, 0, -ox, 0, 1, 0, -oy, 0, 0, 1, -oz)
         self.ctx.query_points_device(self.sdf.data_ptr(), self.shape, self.resolution, points.data_ptr(), n,

@@ -157,3 +157,88 @@ def test_collision_map_wire_format_is_pinned_and_round_trips(tmp_path):
     plain.serialized_map = list(blob)
     plain.is_compressed = False
     assert _cells(m.CollisionMapGrid.LoadFromMessageRepresentation(plain)) == want
+
+
+def test_tagged_map_wire_format_is_pinned_and_round_trips(tmp_path):
+    """N3 / N4 symmetry (VERDICT r3 "next round" 8; reference src/sdf_tools/tagged_object_collision_map.cpp:23-75, :242-339,
+    msg/TaggedObjectCollisionMap.msg): the serialised bytes of a fixed tagged map equal the committed self-golden (field
+    order: the VoxelGrid block with 16-byte cells, then number of components, number of convex segments, frame,
+    components_valid, convex_segments_valid), and raw bytes, TCMR / TCMZ files and the compressed message restore the same
+    map.  Interoperability with files written by the reference itself is unverified (arc_utilities is not vendored)."""
+    import importlib.util
+    import os
+    import struct
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_tagged_map_golden", os.path.join(here, "golden", "make_tagged_map_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = mod.make_grid(m)
+    blob = bytes(g.SerializeSelf())
+    golden = bytes.fromhex(open(os.path.join(here, "golden", "tagged_map_serialized.hex")).read().strip())
+    assert blob == golden
+
+    def cells(t):
+        out = []
+        for x in range(t.GetNumXCells()):
+            for y in range(t.GetNumYCells()):
+                for z in range(t.GetNumZCells()):
+                    c = t.GetValueByIndex(x, y, z)[0]
+                    out.append((c.occupancy, c.component, c.object_id, c.convex_segment))
+        return out
+
+    # layout: 1 byte initialized, 2 x 16 doubles of transforms, u64 cell count, 16-byte cells {occupancy, component, object, segment}
+    assert blob[0] == 1 and struct.unpack_from("<Q", blob, 1 + 256)[0] == 12
+    assert struct.unpack_from("<fIII", blob, 1 + 256 + 8 + 16 * 5) == (0.25 * 5, 105, 1, 35)
+    assert blob.endswith(struct.pack("<II", 0, 0) + struct.pack("<Q", 13) + b"tagged_golden" + b"\x00\x00")
+    want = cells(g)
+    back = m.TaggedObjectCollisionMapGrid.Deserialize(blob)
+    assert cells(back) == want and back.GetFrame() == "tagged_golden" and back.GetResolution() == 0.25
+    oob, ok = back.GetValueByIndex(0, 3, 0)
+    assert not ok and (oob.occupancy, oob.object_id, oob.component, oob.convex_segment) == (-3.5, 11, 5, 2)
+    for compress, magic in ((False, b"TCMR"), (True, b"TCMZ")):
+        path = str(tmp_path / ("map_%d.tcm" % compress))
+        g.SaveToFile(path, compress)
+        raw = open(path, "rb").read()
+        assert raw[:4] == magic and (compress or raw[4:] == blob)
+        assert cells(m.TaggedObjectCollisionMapGrid.LoadFromFile(path)) == want
+    bad = str(tmp_path / "bad.tcm")
+    open(bad, "wb").write(b"CMGR" + blob)                 # the plain map's magic is not this map's
+    with pytest.raises(Exception):
+        m.TaggedObjectCollisionMapGrid.LoadFromFile(bad)
+    msg = g.GetMessageRepresentation()
+    assert msg.is_compressed and msg.frame_id == "tagged_golden"
+    assert cells(m.TaggedObjectCollisionMapGrid.LoadFromMessageRepresentation(msg)) == want
+    msg2 = m.TaggedObjectCollisionMap()
+    msg2.serialized_map, msg2.is_compressed = list(blob), False
+    assert cells(m.TaggedObjectCollisionMapGrid.LoadFromMessageRepresentation(msg2)) == want
+
+
+def test_deserialisers_refuse_hostile_headers():
+    """Deserialize / LoadFromFile / LoadFromMessageRepresentation take untrusted bytes.  An element count beyond
+    the buffer must be refused before memory is reserved for it; negative or overflowing dimensions must not pass the
+    consistency check; truncated buffers raise instead of reading past the end."""
+    import struct
+    g = _golden_grid()
+    blob = bytearray(bytes(g.SerializeSelf()))
+    count_at = 1 + 256
+    huge = bytearray(blob)
+    struct.pack_into("<Q", huge, count_at, 1 << 60)       # "2^60 cells follow"
+    with pytest.raises(Exception):
+        m.CollisionMapGrid.Deserialize(bytes(huge))
+    # dims block: 9 doubles then stride1, stride2, nx, ny, nz (int64) behind the 12 cells
+    dims_at = count_at + 8 + 12 * 8 + 9 * 8 + 2 * 8
+    assert struct.unpack_from("<qqq", blob, dims_at) == (3, 2, 2)
+    for bad_dims in ((-3, -2, 2), (3, 2, -2), (1 << 62, 1 << 62, 48), (0, 0, 0), (12, 1, 1)):
+        b = bytearray(blob)
+        struct.pack_into("<qqq", b, dims_at, *bad_dims)
+        with pytest.raises(Exception):
+            m.CollisionMapGrid.Deserialize(bytes(b))
+    for cut in (0, 1, 100, count_at + 4, len(blob) - 1):
+        with pytest.raises(Exception):
+            m.CollisionMapGrid.Deserialize(bytes(blob[:cut]))
+    frame_len_at = len(blob) - 1 - 12 - 8
+    assert struct.unpack_from("<Q", blob, frame_len_at)[0] == 12
+    b = bytearray(blob)
+    struct.pack_into("<Q", b, frame_len_at, (1 << 64) - 4)    # string length that wraps the bounds arithmetic
+    with pytest.raises(Exception):
+        m.CollisionMapGrid.Deserialize(bytes(b))

@@ -71,3 +71,42 @@ def test_c_client_single_and_multi_rank_fields_are_identical():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fields identical" in r.stdout
+
+
+DQ_EXE = os.path.join(ROOT, "examples", "device_queries_example")
+
+
+def _build_dq():
+    """examples/device_queries.cpp: the device-resident seam (CollisionMapGrid::ExtractSignedDistanceFieldDevice,
+    DeviceSignedDistanceField::QueryBatch / EstimateDistanceBatch / GetGradientBatch / Host)."""
+    from sdf_tools_amd import build as b
+    b.build_libsdfgpu()
+    src = os.path.join(ROOT, "examples", "device_queries.cpp")
+    hdr = os.path.join(ROOT, "include", "sdf_tools", "device_sdf.hpp")
+    if not os.path.exists(DQ_EXE) or os.path.getmtime(DQ_EXE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), src,
+                               "-o", DQ_EXE, "-L", os.path.join(ROOT, "sdf_tools_amd"), "-lsdfgpu",
+                               "-Wl,-rpath," + os.path.join(ROOT, "sdf_tools_amd"), "-lz"])
+    return DQ_EXE
+
+
+def test_cpp_device_queries_compile_and_refuse_without_gpu():
+    from sdf_tools_amd import capi
+    exe = _build_dq()
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,points", [(96, 200000), (512, 1 << 20)])
+def test_cpp_device_queries_without_downloading_the_field(n, points):
+    """VERDICT r3 "next round" 7: a C++ caller builds n^3, answers its queries from HBM (no n^3 x 4-byte download),
+    and the answers equal the reference-shaped host calls on the lazily downloaded field (<= 1e-9)."""
+    exe = _build_dq()
+    r = subprocess.run([exe, str(n), str(points)], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "device queries OK" in r.stdout and "no field download" in r.stdout

@@ -74,6 +74,69 @@ def test_collision_map_extract_both_seams_and_extrema():
     assert ok and est == pytest.approx(float(want[30, 10, 10]) - 0.125, abs=1e-6)
 
 
+@pytest.mark.parametrize("unknown_is_filled", [False, True])
+def test_config1_64cube_random_occupancy_through_the_class(unknown_is_filled):
+    """BASELINE.json configs[0] end to end: a 64^3 CollisionMapGrid with random occupancy ->
+    CollisionMapGrid.ExtractSignedDistanceField (collision_map.hpp:680-712) -> bit-identical to the reference algorithm
+    (oracle) on the same grid, extrema included; cells are set one by one through the reference-shaped SetValue and in
+    bulk through the numpy fast path."""
+    n, res = 64, 0.02
+    rng = np.random.default_rng(64)
+    occ = rng.choice(np.array([0.0, 0.5, 1.0], np.float32), size=(n, n, n), p=[0.45, 0.1, 0.45])
+    origin = m.Isometry3d([[1, 0, 0, -0.64], [0, 1, 0, -0.64], [0, 0, 1, -0.64], [0, 0, 0, 1]])
+    g = m.CollisionMapGrid(origin, "world", res, n, n, n, m.COLLISION_CELL(0.0))
+    g.SetOccupancyFromNumpy(occ)
+    for (x, y, z) in ((0, 0, 0), (63, 63, 63), (17, 5, 40)):              # reference-shaped writes land in the same cells
+        assert g.SetValue(x, y, z, m.COLLISION_CELL(1.0))
+        occ[x, y, z] = 1.0
+    assert g.GetNumXCells() == n and g.GetNumYCells() == n and g.GetNumZCells() == n
+    mask = ((occ > 0.5) | (unknown_is_filled & (occ == 0.5))).astype(np.uint8)
+    for vb in (False, True):
+        sdf, ext = g.ExtractSignedDistanceField(float("inf"), unknown_is_filled, vb)
+        want, want_ext = O.reference_sdf(mask, res, vb)
+        assert np.array_equal(sdf.GetRawDataNumpy().view(np.uint32), want.view(np.uint32)), (unknown_is_filled, vb)
+        assert tuple(ext) == want_ext
+        assert np.array_equal(np.signbit(sdf.GetRawDataNumpy()), mask != 0)      # occupancy / sign bit-exact
+    v, ok = sdf.GetValueByIndex(17, 5, 40)
+    assert ok and v < 0.0
+
+
+def test_device_resident_field_answers_batched_queries():
+    """Round 4, N1 for callers of the class API: CollisionMapGrid.ExtractSignedDistanceFieldDevice leaves the field in HBM;
+    QueryBatch = n x (EstimateDistance3d, GetGradient3d) (sdf.hpp:947-953, :395-403) from one kernel, no download; Host()
+    then yields the same container ExtractSignedDistanceField returns."""
+    n, res = 40, 0.05
+    mask = synth.bernoulli_mask((n, n, n), 0.08, 9)
+    origin = m.Isometry3d([[0, -1, 0, 0.3], [1, 0, 0, -0.2], [0, 0, 1, 0.1], [0, 0, 0, 1]])       # rotated + shifted frame
+    g = m.CollisionMapGrid(origin, "world", res, n, n, n, m.COLLISION_CELL(0.0))
+    g.SetOccupancyFromNumpy(mask.astype(np.float32))
+    dsdf, ext = g.ExtractSignedDistanceFieldDevice(float("inf"), False, False)
+    host, host_ext = g.ExtractSignedDistanceField(float("inf"), False, False)
+    assert tuple(ext) == tuple(host_ext) == tuple(dsdf.GetExtrema())
+    assert (dsdf.GetNumXCells(), dsdf.GetResolution(), dsdf.GetFrame()) == (n, res, "world")
+    rng = np.random.default_rng(3)
+    grid_pts = rng.uniform(-0.1, n * res + 0.1, size=(4000, 3))
+    R, t = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]]), np.array([0.3, -0.2, 0.1])
+    pts = grid_pts @ R.T + t                                          # world-frame points
+    dist, grad, flags = dsdf.QueryBatch(pts, True)
+    assert not dsdf.HostCopyExists()                                  # nobody asked for the field yet
+    inside = 0
+    for i in range(0, len(pts), 7):
+        e, ok = host.EstimateDistance(*pts[i])
+        assert ok == bool(flags[i] & 1)
+        if ok:
+            inside += 1
+            assert dist[i] == pytest.approx(e, abs=1e-9)
+        else:
+            assert np.isinf(dist[i])
+    assert inside > 300
+    back = dsdf.Host()
+    assert dsdf.HostCopyExists() and np.array_equal(back.GetRawDataNumpy(), host.GetRawDataNumpy())
+    assert back.GetFrame() == "world"
+    with pytest.raises(ValueError):
+        dsdf.QueryBatch(np.zeros((4, 2)), False)
+
+
 def test_file_and_message_round_trip(tmp_path):
     mask = synth.bernoulli_mask((9, 8, 7), 0.5, 2)
     g = m.CollisionMapGrid(m.Isometry3d(IDENT), "world", 0.5, 9, 8, 7, m.COLLISION_CELL(0.0))

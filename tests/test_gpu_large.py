@@ -63,6 +63,61 @@ def test_512_cube_matches_exact_everywhere(gpu):
     assert ext == ex_ext
 
 
+def test_dense_to_far_field_transition_build_is_bounded():
+    """VERDICT r3 "next round" 1: config 5 is a STREAM -- scenes change under a handle.  One handle at 512^3: Bernoulli(0.5)
+    until the dense tier is trusted (the guarded stand-by behind it is then the far-field pair, three small-grid launches),
+    then the two-box cloud.  The transition build -- dense kernels wasted, stand-by does the work -- must be exact and take
+    at most 3x the steady-state far-field build (round 3: the stand-by was fused K12 + K3/16 with unbounded scans, tens of
+    ms on this scene), and the handle must come back to the dense scene exactly."""
+    import torch
+    from sdf_tools_amd import capi
+    n, res = 512, 0.01
+    dev = torch.device("cuda", 0)
+    ctx = capi.SdfGpu(0)                                         # own handle, default policy
+    try:
+        dense = synth.bernoulli_mask_torch((n, n, n), 0.5, 1, device=dev)
+        pts = torch.from_numpy(synth.two_box_points(200000, seed=0, scale=n * res)).to(dev)
+        far = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        ctx.voxelize_points_device(pts.data_ptr(), pts.shape[0], (0.0, 0.0, 0.0), res, (n, n, n), far.data_ptr(), True, s)
+        out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
+
+        def timed(mask):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ctx.build_device(mask.data_ptr(), (n, n, n), out.data_ptr(), res, False, s)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+
+        for _ in range(6):                                       # synchronised: the policy sees every report
+            timed(dense)
+        assert ctx.last_path()["dense_certified"]
+        info = ctx.last_build_info()
+        assert info["standby_far"] and not info["fused_zy"], info
+        t_dense = min(timed(dense) for _ in range(5))
+        want_dense = out.clone()
+        ext_dense = ctx.get_extrema()
+        t_trans = timed(far)                                     # the transition build
+        path = ctx.last_path()
+        assert path["far_y"] and path["far_x"] and not path["dense_certified"], path
+        assert ctx.last_build_info()["standby_far"]
+        got_trans, ext_trans = out.clone(), ctx.get_extrema()
+        for _ in range(4):
+            timed(far)
+        assert not ctx.last_build_info()["standby_far"]
+        t_far = min(timed(far) for _ in range(5))
+        assert bool(torch.equal(out, got_trans)) and ctx.get_extrema() == ext_trans
+        ex, ex_ext, _ = O.exact_sdf(far.cpu().numpy(), res)
+        assert np.array_equal(got_trans.cpu().numpy().view(np.uint32), ex.view(np.uint32)) and ext_trans == ex_ext
+        print("dense %.3f ms, transition %.3f ms, far-field steady state %.3f ms" % (t_dense, t_trans, t_far))
+        assert t_trans <= 3.0 * t_far, (t_trans, t_far)
+        timed(dense)                                             # and back: exact whatever the handle has learned
+        assert bool(torch.equal(out, want_dense)) and ctx.get_extrema() == ext_dense
+    finally:
+        ctx.close()
+
+
 def test_sparse_256_far_scans(gpu):
     """Sparse 256^3 (p = 1e-4): distances of tens of voxels, the outward-scan path dominates."""
     m = synth.bernoulli_mask((256, 256, 256), 1e-4, 3)

@@ -91,3 +91,36 @@ def test_multi_512_far_field_matches_single_gpu(gpu):
         mg.close()
     want, want_ext = gpu.build(m, 0.01)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and ext == want_ext
+
+
+def cavity_scene(n=256, cav=88, p=0.3, seed=5):
+    """Near-field clutter (Bernoulli p) around ONE free cavity of cav^3 voxels: the tier probes see a near-field scene
+    (the cavity is < 1/24 of the voxels), the marching x sweep meets voxels that are still undecided after its
+    40-row scan bound (cav / 2 > 41), raises the far flag and leaves them to the far-field kernel -- whose values,
+    not the marching sweep's upper bounds, must reach the extrema (sdfgpu_kernels.hpp `inexact`)."""
+    m = synth.bernoulli_mask((n, n, n), p, seed)
+    a = (n - cav) // 2
+    m[a:a + cav, a:a + cav, a:a + cav] = 0
+    return m
+
+
+def test_cavity_in_clutter_extrema_on_the_whole_line_path(gpu):
+    """The advisor's regression (VERDICT r3 missing #6) through sdfgpu_multi_build: 2 logical ranks, the halo path
+    raises 'unresolved' inside the cavity, the re-partitioned complete-lines x sweep runs near-field + scan bound +
+    far-field kernel; field and extrema bit-identical to the exact oracle and to the single-GPU ABI."""
+    m = cavity_scene()
+    want, want_ext, dsq = O.exact_sdf(m, 0.01)
+    assert np.abs(dsq).max() > 41 * 41                               # the cavity is deeper than the scan bound
+    mg = capi.MultiSdfGpu(2, [0, 0])
+    try:
+        got, ext = mg.build(m, 0.01)
+        path = mg.last_path()
+        assert path["whole_lines"] and not path["dense_certified"], path
+    finally:
+        mg.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert ext == want_ext, (ext, want_ext)
+    one, one_ext = gpu.build(m, 0.01)
+    assert np.array_equal(one.view(np.uint32), want.view(np.uint32)) and one_ext == want_ext
+    lp = gpu.last_path()
+    assert lp["far_x"] and not lp["far_y"], lp                       # ... there: marching y sweep; the far-field kernel redid the x sweep

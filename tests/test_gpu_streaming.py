@@ -199,3 +199,28 @@ def test_streaming_query_after_frame(gpu):
     assert bool((f.cpu().numpy() == 3).all())
     want = _numpy_estimate_distance(sdf.cpu().numpy(), res, q.cpu().numpy())
     assert np.allclose(d.cpu().numpy(), want, rtol=0, atol=1e-9)
+
+
+def test_streaming_query_mode_fuses_the_consumers_queries_into_the_frame(gpu):
+    """BASELINE configs[4], "fused gradient (EstimateDistance/gradient query) kernel": the default StreamingSdf answers the
+    caller's distance + gradient queries on the fresh field (no full-grid gradient is written); same answers as the
+    stand-alone query on the full-gradient variant's field, which is the same field."""
+    import torch
+    n, res = 64, 0.02
+    stq = StreamingSdf((n, n, n), res, (0.0, 0.0, 0.0), 0)                       # default: gradient="query"
+    stf = StreamingSdf((n, n, n), res, (0.0, 0.0, 0.0), 0, gradient="full")
+    assert stq.mode == "query" and stq.gradient is None and stf.gradient is not None
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.rand((5000, 3), dtype=torch.float64, device="cuda", generator=gen) * (n * res * 1.1) - 0.05
+    for seed in (0, 1):
+        pc = torch.from_numpy(synth.two_box_points(3000, seed=seed, scale=n * res)).cuda()
+        sdf_q, ans = stq.frame(pc, q)
+        sdf_f, grad = stf.frame(pc)
+        torch.cuda.synchronize()
+        assert bool(torch.equal(sdf_q, sdf_f)) and stq.extrema() == stf.extrema()
+        d2, g2, f2 = stf.query(q)
+        assert bool(torch.equal(ans[2], f2))
+        assert np.array_equal(ans[0].cpu().numpy(), d2.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(ans[1].cpu().numpy(), g2.cpu().numpy(), equal_nan=True)
+        assert 0 < int((f2 & 1).sum()) < q.shape[0]                              # some points inside, some outside
+    assert stq.frame(pc)[1] is None                                              # no query points: the field only

@@ -1,7 +1,11 @@
-"""CPU: pins the oracle (oracle/sdf_oracle.c) to the reference's known answers.
+"""Pins the oracle (oracle/sdf_oracle.c) to the reference's known answers.
 
 The expected values are the assertions of the reference's own test
-(test/test_bindings.py:24-33) and the known-answer table of SURVEY.md section 4."""
+(test/test_bindings.py:24-33) and the known-answer table of SURVEY.md section 4.
+
+The reference-pinning tests run in BOTH tiers ("next round" 3a): once under -m "not gpu" and once under
+-m gpu, where the oracle is the library rebuilt / loaded on the GPU box -- the checker every parity test of that run
+leans on is pinned in the same run.  (No GPU is touched by them: the `tier` parameter only carries the marker.)"""
 import json
 import math
 import os
@@ -12,6 +16,8 @@ import pytest
 import scenes
 from oracle import oracle as O
 from sdf_tools_amd import synth
+
+both_tiers = pytest.mark.parametrize("tier", ["cpu", pytest.param("gpu_box", marks=pytest.mark.gpu)])
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KA = json.load(open(os.path.join(HERE, "golden", "known_answers.json")))
@@ -28,7 +34,8 @@ def _check_values(sdf, spec):
 
 
 @pytest.mark.parametrize("impl", ["reference", "exact"])
-def test_test_bindings_scene(impl):
+@both_tiers
+def test_test_bindings_scene(impl, tier):
     m, res = scenes.test_bindings_scene()
     sdf, ext = O.reference_sdf(m, res) if impl == "reference" else O.exact_sdf(m, res)[:2]
     ka = KA["test_bindings"]
@@ -41,7 +48,8 @@ def test_test_bindings_scene(impl):
 
 
 @pytest.mark.parametrize("impl", ["reference", "exact"])
-def test_tutorial_scene(impl):
+@both_tiers
+def test_tutorial_scene(impl, tier):
     m, res = scenes.tutorial_scene()
     sdf, ext = O.reference_sdf(m, res) if impl == "reference" else O.exact_sdf(m, res)[:2]
     _check_values(sdf, KA["tutorial"]["sdf"])
@@ -49,7 +57,8 @@ def test_tutorial_scene(impl):
     assert ext[1] == pytest.approx(KA["tutorial"]["extrema"][1], abs=1e-12)
 
 
-def test_convex_segments_scene():
+@both_tiers
+def test_convex_segments_scene(tier):
     m, res = scenes.convex_segments_scene()
     sdf, ext = O.reference_sdf(m, res)
     assert ext[0] == pytest.approx(18.0, abs=1e-12)
@@ -59,7 +68,8 @@ def test_convex_segments_scene():
     assert eext == ext
 
 
-def test_all_free_all_filled():
+@both_tiers
+def test_all_free_all_filled(tier):
     s, ext = O.reference_sdf(np.zeros((8, 8, 8), np.uint8), 1.0)
     assert np.all(np.isposinf(s)) and ext == (math.inf, math.inf)
     s, ext = O.reference_sdf(np.ones((8, 8, 8), np.uint8), 1.0)
@@ -69,7 +79,8 @@ def test_all_free_all_filled():
         assert ext == want
 
 
-def test_virtual_border_uniform_grids():
+@both_tiers
+def test_virtual_border_uniform_grids(tier):
     s, ext = O.reference_sdf(np.zeros((16, 16, 16), np.uint8), 1.0, True)
     assert s.min() == 1.0 and s.max() == 8.0 and ext == (8.0, math.inf)
     s, ext = O.reference_sdf(np.ones((16, 16, 16), np.uint8), 1.0, True)
@@ -90,7 +101,8 @@ def test_exact_edt_against_brute_force():
                 assert np.array_equal(O.brute_edt(m, sv), O.exact_edt(m, sv))
 
 
-def test_reference_is_exact_on_dense_random_occupancy():
+@both_tiers
+def test_reference_is_exact_on_dense_random_occupancy(tier):
     # at p = 0.5 the propagation never errs (true d^2 < 8)
     for n, seed in ((32, 1), (48, 2)):
         m = synth.bernoulli_mask((n, n, n), 0.5, seed)
@@ -120,7 +132,8 @@ def test_virtual_border_matches_clamped_exact_on_dense_grid():
     assert np.array_equal(a, b) and ea == eb
 
 
-def test_oracle_vectors_are_stable():
+@both_tiers
+def test_oracle_vectors_are_stable(tier):
     z = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))
     names = sorted({k.split("/")[0] for k in z.files})
     assert len(names) == 5
@@ -133,7 +146,8 @@ def test_oracle_vectors_are_stable():
         assert np.array_equal(np.array(ext), z[name + "/extrema"]), name
 
 
-def test_classify_cells_predicate():
+@both_tiers
+def test_classify_cells_predicate(tier):
     # collision_map.hpp:680-712
     occ = np.array([0.0, 0.4999, 0.5, 0.5001, 1.0, -10000.0, np.nan], np.float32)
     cells = np.zeros((occ.size, 2), np.float32)

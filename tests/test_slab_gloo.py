@@ -322,3 +322,56 @@ def test_dense_path_through_the_native_phase_schedule():
     want, want_ext, _ = O.exact_sdf(synth.bernoulli_mask(shape, 0.004, 5), 1.0)
     assert dense and general == 2
     assert np.array_equal(got, want) and ext == want_ext
+
+
+def _predict_worker(rank, world, port, shape, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x0, x1 = slab.slab_range(shape[0], rank, world)
+        far_mask = torch.from_numpy(synth.bernoulli_mask(shape, 0.01, 7, x_range=(x0, x1)))
+        near_mask = torch.from_numpy(synth.bernoulli_mask(shape, 0.5, 3, x_range=(x0, x1)))
+        stages = OracleStages()
+        b = slab.SlabSdfBuilder(stages, shape, 0.5, False, halo=2, rank=rank, world=world, dense=False)
+        log = []
+        for name, mask, hint in (("far", far_mask, 1), ("far", far_mask, 1), ("far", far_mask, 1), ("near", near_mask, 0),
+                                 ("near", near_mask, 0), ("far", far_mask, 1)):
+            stages.far_hint = hint               # what the HIP y sweep's probe would report for this scene
+            r0, f0, m0 = b.host_reads, b.fallbacks, b.mispredictions
+            sdf, ext = b.build(mask)
+            log.append((name, b.host_reads - r0, b.fallbacks - f0, b.mispredictions - m0, sdf.numpy().copy(), ext))
+        q.put((rank, x0, x1, log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_general_path_predicts_its_x_sweep_one_host_read_per_build():
+    """VERDICT r3 "next round" 5: no host decision in the middle of a general build.  far, far, far, near, near, far on
+    one builder: the first far-field build mispredicts (halo sweep, then complete lines: 2 host reads), the next two go
+    straight to the re-partition (1 read each); the first near-field build still sweeps complete lines (exact, 1 read)
+    and resets the prediction; the second takes the halo path (1 read); the scene turning far-field again costs one
+    misprediction.  Results exact every time, counters identical on every rank."""
+    world, shape = 2, (18, 10, 8)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = sorted((q.get(timeout=240) for _ in range(world)), key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    want = {"far": O.exact_sdf(synth.bernoulli_mask(shape, 0.01, 7), 0.5), "near": O.exact_sdf(synth.bernoulli_mask(shape, 0.5, 3), 0.5)}
+    counters = [[(n, r, f, m) for (n, r, f, m, _, _) in res[3]] for res in results]
+    assert counters[0] == counters[1]
+    assert counters[0] == [("far", 2, 1, 1), ("far", 1, 1, 0), ("far", 1, 1, 0), ("near", 1, 1, 0), ("near", 1, 0, 0),
+                           ("far", 2, 1, 1)], counters[0]
+    for step in range(6):
+        name = results[0][3][step][0]
+        full = np.empty(shape, np.float32)
+        for rank, x0, x1, log in results:
+            full[x0:x1] = log[step][4]
+            assert log[step][5] == want[name][1]
+        assert np.array_equal(full, want[name][0]), (step, name)

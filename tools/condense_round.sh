@@ -19,16 +19,8 @@ python tools/rocprof_summary.py pmc $G/pmc_general_FETCH_SIZE $G/pmc_general_WRI
 python tools/rocprof_summary.py pmc $G/pmc_env_FETCH_SIZE $G/pmc_env_WRITE_SIZE $P/${name}_pmc_traffic_envelope.json
 python tools/pmc_summary.py $G/pmc_env_SQ $G/pmc_env_SQ2 k_envelope k_sweep_z > $P/${name}_sq_counters_envelope.txt
 [ -d $G/pmc_general_SQ ] && python tools/pmc_summary.py $G/pmc_general_SQ $G/pmc_general_SQ k_sweep_x16 k_sweep_y16 k_sweep_z > $P/${name}_sq_counters_general.txt
-# average kernel times of the bench command (rocprofv3 --kernel-trace --stats), read by bench.py next to its HIP-event times
-python - "$P/${name}_dense_kernel_stats.csv" "$P/kernel_times.json" <<'PY'
-import csv, json, sys
-out = {}
-for r in csv.DictReader(open(sys.argv[1])):
-    name = r.get("Name") or r.get("KernelName") or ""
-    avg = float(r.get("AverageNs") or r.get("Average") or 0.0)
-    for key in ("k_ball_dense", "k_pack_bits_mask", "k_envelope_dc", "k_sweep_x16", "k_sweep_march", "k_sweep_y16", "k_sweep_z_wave16", "k_sweep_z_vec16"):
-        if key in name and key not in out:
-            out[key] = round(avg / 1e6, 5)
-json.dump(out, open(sys.argv[2], "w"), indent=1)
-print(out)
-PY
+python tools/rocprof_summary.py pmc $G/pmc_mid_FETCH_SIZE $G/pmc_mid_WRITE_SIZE $P/${name}_pmc_traffic_mid.json
+# average kernel times of the bench command (rocprofv3 --kernel-trace --stats; exact kernel names, guard exits left out), read by
+# bench.py next to its HIP-event times; and the HBM bytes per launch of every kernel from THIS round's PMC files only
+python tools/rocprof_summary.py times $G/stats_dense $P/kernel_times.json
+python tools/make_traffic.py $name

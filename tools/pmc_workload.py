@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Workload for the rocprofv3 --pmc passes: a few 512^3 SDF builds plus a torch copy of known size
-(512 MiB read + 512 MiB written) that calibrates FETCH_SIZE / WRITE_SIZE in the same pass."""
+(512 MiB read + 512 MiB written) that calibrates FETCH_SIZE / WRITE_SIZE in the same pass.
+usage: pmc_workload.py [n] [p=<Bernoulli density>] [builds=<count>] [name=value library options ...]
+Every build is synchronised so that the handle's policy has seen it before the next one (p = 0.03: the steady state is
+KD3 + the fix-up kernel from the second build on)."""
 import os
 import sys
 
@@ -11,14 +14,21 @@ from sdf_tools_amd import capi, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ctx = capi.SdfGpu(0)
+p, builds = 0.5, 4
 for kv in sys.argv[2:]:
-    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-mask = synth.bernoulli_mask_torch((n, n, n), 0.5, 1, device="cuda")
+    k, v = kv.split("=")
+    if k == "p":
+        p = float(v)
+    elif k == "builds":
+        builds = int(v)
+    else:
+        ctx.set_option(k, int(v))
+mask = synth.bernoulli_mask_torch((n, n, n), p, 1, device="cuda")
 out = torch.empty((n, n, n), dtype=torch.float32, device="cuda")
 src = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
 dst = torch.empty_like(src)
-for _ in range(4):
+for _ in range(builds):
     ctx.build_device(mask.data_ptr(), (n, n, n), out.data_ptr(), 0.01, False, torch.cuda.current_stream().cuda_stream)
     dst.copy_(src)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
 print("extrema", ctx.get_extrema())

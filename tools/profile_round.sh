@@ -3,7 +3,7 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
 # bench line, kernel-trace stats of the bench and of the streaming / far-field workloads, PMC passes (HBM traffic and SQ
 # counters; counters are collected in their own runs, with --kernel-trace only).
-tag=${1:-r03}
+tag=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -19,6 +19,7 @@ rocprofv3 --kernel-trace --stats -d $O/stats_general -o s --output-format csv --
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $O/pmc_dense_$c -o p --output-format csv -- python $R/tools/pmc_workload.py 512 > $O/pmc_dense_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c -d $O/pmc_general_$c -o p --output-format csv -- python $R/tools/pmc_workload.py 512 dense=0 > $O/pmc_general_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_mid_$c -o p --output-format csv -- python $R/tools/pmc_workload.py 512 p=0.03 builds=8 > $O/pmc_mid_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c -d $O/pmc_env_$c -o p --output-format csv -- python $R/tools/env_bench.py 512 4 > $O/pmc_env_$c.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_env_SQ -o p --output-format csv -- python $R/tools/env_bench.py 512 4 > $O/pmc_env_SQ.log 2>&1
