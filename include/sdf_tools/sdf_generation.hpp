@@ -46,13 +46,13 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
         ThrowOnMultiStatus(mh, sdfgpu_multi_build(mh, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells,
                                                   grid_resolution, add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(),
                                                   &max_distance, &min_distance));
-        return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+        return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
     }
 #endif
     sdfgpu_handle h = GpuContext::Get();
     ThrowOnStatus(h, sdfgpu_build(h, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells, grid_resolution,
                                   add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(), &max_distance, &min_distance));
-    return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+    return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
 }
 
 // Grid overload with the virtual-border switch (reference :273-420).
@@ -94,14 +94,14 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
         ThrowOnMultiStatus(mh, sdfgpu_multi_build_cells(mh, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny,
                                                         nz, cell_sizes.x(), add_virtual_border ? 1 : 0,
                                                         new_sdf.MutableDataForBuild(), &max_distance, &min_distance));
-        return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+        return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
     }
 #endif
     sdfgpu_handle h = GpuContext::Get();
     ThrowOnStatus(h, sdfgpu_build_cells(h, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny, nz,
                                         cell_sizes.x(), add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(),
                                         &max_distance, &min_distance));
-    return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+    return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
 }
 
 // ---- device-resident results (round 4; no counterpart in the reference: its result is always a host container) -----------

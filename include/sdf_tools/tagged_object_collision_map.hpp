@@ -76,7 +76,7 @@ protected:
                                          GetNumXCells(), GetNumYCells(), GetNumZCells(), cell_sizes.x(),
                                          add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(), &max_distance,
                                          &min_distance));
-        return std::make_pair(new_sdf, std::make_pair(max_distance, min_distance));
+        return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
     }
 
 public:

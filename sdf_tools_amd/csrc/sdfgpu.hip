@@ -110,7 +110,7 @@ struct sdfgpu_context {
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     bool standby_far = true;         // stand-by pipeline behind a trusted dense tier = the far-field pair (bounded whatever the scene
                                      // turns into), not fused K12 + K3/16 with unbounded scans (option "standby_far")
-    bool standby_launch = false;     // set while a build enqueues that stand-by: small grids (what a guarded exit costs grows with the grid)
+    int standby_grid = 1024;         // workgroups of the stand-by launches (LOOP form; option "standby_grid"): 4 per CU = all resident at once
     bool dc_attr_set[8] = {false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
@@ -234,7 +234,7 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
         // at 512^3: 8 per CU 0.099 ms, 16 0.093, 32 0.088, one step per wave 0.100)
         const int rw = 1024 / (int)nz;                                  // rows per wave step
         const int64_t ngroups = (nrows + rw - 1) / rw;
-        dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), h->standby_launch ? 2048 : 8192));
+        dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), 8192));
         switch ((int)nz) {
             case 64: hipLaunchKernelGGL(k_sweep_z_wave16<4>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
             case 128: hipLaunchKernelGGL(k_sweep_z_wave16<8>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
@@ -432,6 +432,8 @@ struct DcExtra {                 // int32 plane fields instead of p16 + side tab
     int64_t y_off = 0, ny_glob = -1;
     const uint32_t* i32_flag = nullptr;     // device word: use the int32 fields only when it is non-zero (nullptr: always)
     bool loop = false;                      // LOOP form of the kernel: a small grid whose workgroups walk the tiles (stand-by launches)
+    const uint32_t* bits = nullptr;         // stage 2: z distances from the dense tier's bit field instead of the z field (forces the scalar form)
+    int nzw = 0;
     uint32_t* ran_flag = nullptr;           // status word raised by a launch that does work
 };
 struct DcDecide {                // a probe launch turns its counters into the tier decision itself (last workgroup)
@@ -484,6 +486,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
             a.ran_flag = ex->ran_flag;
+            if (stage == 2) { a.bits = ex->bits; a.nzw = ex->nzw; }
         }
         const bool loop = ex && ex->loop && !probe_out;
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
@@ -544,7 +547,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         }
         // vector loads: 4 consecutive lines per load, whole tiles, aligned rows
         auto al = [](const void* p, uintptr_t n) { return (reinterpret_cast<uintptr_t>(p) % n) == 0; };
-        const bool vec = (nz % 4) == 0 && (a.group_lines % NL) == 0 && al(d_in16, 8) && al(d_side_in, 16) && al(a.in_i32, 16);
+        const bool vec = !a.bits && (nz % 4) == 0 && (a.group_lines % NL) == 0 && al(d_in16, 8) && al(d_side_in, 16) && al(a.in_i32, 16);
 #ifdef SDFGPU_DEBUG_HOOKS
         const size_t lds = envelope_dc_lds_bytes(a.L, NL) + (size_t)(h->dc_debug >> 8) * 1024;  // profiling builds: LDS padding = lower occupancy
 #else
@@ -557,7 +560,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         a.ntiles = ntiles;
         // LOOP form: at most 2048 workgroups (a guarded exit costs 1.7 us up to there and grows with the grid), a multiple of 8
         // so that a workgroup's tiles stay on its XCD
-        const int64_t nwg = loop ? std::min<int64_t>(ntiles, 2048) : ntiles;
+        const int64_t nwg = loop ? std::min<int64_t>(ntiles, h->standby_grid) : ntiles;
         const int which = (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0);
         auto launch = [&](auto kern) -> int {
             // (the attribute is per kernel: raised once per instantiation, not on every launch -- ADVICE r3)
@@ -723,7 +726,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
         f.nzw = a.nzw; f.log2_nzw = a.log2_nzw; f.ny = a.ny; f.rows_x = a.rows_x; f.out_lo = a.out_lo; f.out_hi = a.out_hi;
         f.tx = a.tx; f.ty = a.ty; f.log2_ty = a.log2_ty; f.resolution = resolution;
         f.slots = h->d_slots; f.uncertified = d_uncert;
-        const size_t flds = (size_t)(kFixOrderPad + kFixCap + 4) * 4 +
+        const size_t flds = (size_t)(2 * kFixOrderPad + kFixCap + 4) * 4 +
                             (size_t)(a.tx + 2 * kFixTileR) * (a.ty + 2 * kFixTileR) * (a.nzw + 2) * 4;
         if (bd == 1024) hipLaunchKernelGGL(k_ball_fixup<1024>, grid, dim3(1024), flds, s, f);
         else if (bd == 512) hipLaunchKernelGGL(k_ball_fixup<512>, grid, dim3(512), flds, s, f);
@@ -829,9 +832,11 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // Stand-by behind a TRUSTED dense tier (round 4).  It nearly always exits on its guard, so it must be
     // few launches with small grids -- and since the scene of a stream can change under the handle (dense -> far-field), it
     // must be BOUNDED whatever the scene turns into.  That is the far-field pair with no probes and no marching sweeps:
-    // K1 [guard] -> KE2 [guard] -> KE3 [guard], int32 hand-off, LOOP form (<= 2048 workgroups each): three guarded launches
-    // like the K12 + K3/16 pair it replaces, O(L log L) per line on any input (the old pair ran unbounded outward scans:
-    // tens of ms on the build in which a dense scene turned into the two-box cloud).
+    // KE2 [guard] -> KE3 [guard], int32 hand-off, LOOP form (1024 workgroups each); KE2 takes its z distances straight from
+    // the dense tier's bit field (zdist_from_bits), so no z sweep is launched in front: TWO guarded launches like the
+    // K12 + K3/16 pair it replaces (a third one, a guarded K1, cost the dense-certified step 2.6 us: 0.1405 -> 0.1431 ms),
+    // O(L log L) per line on any input (the old pair ran unbounded outward scans: tens of ms on the build in which a
+    // dense scene turned into the two-box cloud).
     const bool standby = far_ok && h->standby_far && h->expect_dense && dense && !h->fused_always;
     // Device-side tier selection: the marching-vs-far-field choice of each axis is made INSIDE this build from a probe of the
     // sweep's own input, so a fresh context (the reference's API is one-shot: collision_map.hpp:680-712 builds and returns)
@@ -843,7 +848,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     const bool fused = !standby && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
                        (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
     const bool select = dev_select && !fused;
-    if (!fused) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
+    if (!fused && !standby) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
     // Builds on one handle share its status block, extrema slots and scratch fields.  On the same stream they are
@@ -937,11 +942,9 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     h->last_plane16 = p16;
     h->far_y = (envelope && !fused) ? h->d_small + 4 : nullptr;
     h->scan_y = h->scan_x = kScanExpectNear;
-    if (!fused) {
-        h->standby_launch = standby;
-        const int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz, (int16_t*)h->zfield.ptr, s);
-        h->standby_launch = false;
-        if (rc) return rc;
+    if (!fused && !standby) {                                   // (the stand-by pair takes its z distances from the bit field)
+        if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
+                                    (int16_t*)h->zfield.ptr, s)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(3));
@@ -964,10 +967,11 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff, window_choice); };   // probe counters -> guard words
     DcExtra sb2{}, sb3{};                                       // stand-by pair: int32 hand-off unconditionally, LOOP form, self-reporting
     sb2.out_i32 = (int32_t*)h->yzfield.ptr; sb2.loop = true; sb2.ran_flag = h->d_small + 4;
+    sb2.bits = (const uint32_t*)h->bits.ptr; sb2.nzw = (int)((nz + 31) / 32);
     sb3.in_i32 = (const int32_t*)h->yzfield.ptr; sb3.loop = true; sb3.ran_flag = h->d_small + 5;
     if (standby) {
         HIP_TRY(h, mark(4));                                    // (stage slot 3, the marching y sweep: nothing launched)
-        if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nx, ny, nz, resolution, vb,
+        if (int rc = launch_envelope(h, 2, nullptr, nullptr, nullptr, nullptr, nx, ny, nz, resolution, vb,
                                      h->d_small, general_guard, s, 0, nullptr, &sb2)) return rc;
         launched_since_mark = true;
         HIP_TRY(h, mark(5));
@@ -1837,6 +1841,7 @@ int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {
     if (!h || !out_host) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!h->have_result || n > h->last_n) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no matching build");
     if (h->last_fused) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "the last build fused the z sweep into the y sweep: no z field exists");
+    if (h->last_standby) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "the last build's stand-by pair takes its z distances from the bit field: no z field exists");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     HIP_TRY(h, hipMemcpy(out_host, h->zfield.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
@@ -1927,6 +1932,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
 #endif
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "standby_far") h->standby_far = value != 0;
+    else if (n == "standby_grid") h->standby_grid = value >= 32 ? value : 1024;
     else if (n == "expect_dense") h->expect_dense = value != 0;      // tests: put the handle into the "dense tier trusted" state
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;

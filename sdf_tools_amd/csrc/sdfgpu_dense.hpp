@@ -426,6 +426,7 @@ constexpr int kFixTileR = 6;                                  // halo of the sta
                                                               // 0.46 -> 0.58 ms per build)
 constexpr int kFixRows = (2 * kFixR + 1) * (2 * kFixR + 1);   // 289 (dx, dy) rows
 constexpr int kFixOrderPad = (kFixRows + 7) & ~7;             // LDS words reserved for the row table
+constexpr int kFixOutside = 0x40000000;                       // rowofs[] marker: the row lies beyond the staged halo
 
 struct FixArgs {
     const uint32_t* bits;   // [rows_x][ny][nzw]
@@ -452,7 +453,10 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     const int rw = nzw + 2;                                   // one replicated edge word on each side
     const int hx = a.tx + 2 * kFixTileR, hy = a.ty + 2 * kFixTileR;
     uint32_t* order = reinterpret_cast<uint32_t*>(fix_smem);  // [kFixRows] (+ pad)
-    uint32_t* list = order + kFixOrderPad;                    // [kFixCap] (tile row << 16) | z
+    int* rowofs = reinterpret_cast<int*>(order + kFixOrderPad);   // [kFixRows] (+ pad): LDS word offset of row (dx, dy) from the voxel's own
+                                                              // row, or kFixOutside for rows beyond the staged halo (round 4: the scan loop
+                                                              // decoded dx, dy and multiplied them out for every row of every voxel)
+    uint32_t* list = reinterpret_cast<uint32_t*>(rowofs + kFixOrderPad);   // [kFixCap] (tile row << 16) | z
     uint32_t* count = list + kFixCap;                         // [1] (+ pad to 4 words)
     uint32_t* tile = count + 4;                               // [hx][hy][rw]
     // "the general sweeps will redo the grid anyway": ONE lane reads the flag for the whole workgroup (count[1]) -- read per
@@ -462,7 +466,12 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         *count = 0u;
         count[1] = __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (int i = t; i < kFixRows; i += BD) order[i] = a.order[i];
+    for (int i = t; i < kFixRows; i += BD) {
+        const uint32_t o = a.order[i];
+        order[i] = o;
+        const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
+        rowofs[i] = (dx >= -kFixTileR && dx <= kFixTileR && dy >= -kFixTileR && dy <= kFixTileR) ? (dx * hy + dy) * rw : kFixOutside;
+    }
     const int x0 = a.out_lo + (int)blockIdx.y * a.tx, y0 = (int)blockIdx.x * a.ty;
     __syncthreads();
     if (t == 0) a.tileflag[tile_id] = 0u;                     // (behind the barrier: every wave has read its copy of the word)
@@ -493,37 +502,35 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     // halo tile in LDS ((tx + 12) x (ty + 12) rows for two voxels was most of this kernel's time there).
     const bool direct = n <= (uint32_t)kFixDirect;            // (block-uniform)
     if (!direct) {
-    {
-            // rows / edge words replicate the nearest in-grid voxel.  Lanes = (row in pass, word slot): 2^lgp >= rw slots
-            const int lgp = lg + 1 > 2 ? lg + 1 : 2;
-            const int ws = t & ((1 << lgp) - 1), r0 = t >> lgp, rpp = BD >> lgp;
-            if (ws < rw) {
-                const int nrows = hx * hy;
-                for (int row0 = r0; row0 < nrows; row0 += 4 * rpp) {          // 4 independent loads in flight per lane
-                    uint32_t v[4];
+        // rows / edge words replicate the nearest in-grid voxel.  Round 4: a lane per WORD of the bit row (nzw lanes per row,
+        // BD / nzw rows per pass, every lane busy; the two replicated edge words are derived by the lanes that hold the row's
+        // first / last word) and the row -> (jx, jy) split by a multiply-shift -- the first form spent 14 of every 32 lanes on
+        // nothing and two integer divisions per element: 40 % of this kernel's instructions at Bernoulli p = 0.02.
+        const int j = t & (nzw - 1), rp = t >> lg, rpp = BD >> lg;
+        const uint32_t inv_hy = ((1u << 20) + (uint32_t)hy - 1u) / (uint32_t)hy;      // (exact for rows < 2^20 / hy)
+        const int nrows = hx * hy;
+        for (int row0 = rp; row0 < nrows; row0 += 4 * rpp) {                          // 4 independent loads in flight per lane
+            uint32_t v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = min(row0 + k * rpp, nrows - 1);
-                        const int jx = row / hy, jy = row - jx * hy;
-                        const int gx = min(max(x0 + jx - kFixTileR, 0), a.rows_x - 1);
-                        const int gy = min(max(y0 + jy - kFixTileR, 0), a.ny - 1);
-                        const uint32_t* src = a.bits + ((int64_t)gx * a.ny + gy) * nzw;
-                        v[k] = src[min(max(ws - 1, 0), nzw - 1)];
-                    }
+            for (int k = 0; k < 4; ++k) {
+                const int row = min(row0 + k * rpp, nrows - 1);
+                const int jx = (int)(((uint32_t)row * inv_hy) >> 20), jy = row - jx * hy;
+                const int gx = min(max(x0 + jx - kFixTileR, 0), a.rows_x - 1);
+                const int gy = min(max(y0 + jy - kFixTileR, 0), a.ny - 1);
+                v[k] = a.bits[((int64_t)gx * a.ny + gy) * nzw + j];
+            }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int row = row0 + k * rpp;
-                        if (row < nrows) {
-                            uint32_t x = v[k];
-                            if (ws == 0) x = (x & 1u) ? ~0u : 0u;
-                            else if (ws == rw - 1) x = (x >> 31) ? ~0u : 0u;
-                            tile[row * rw + ws] = x;
-                        }
-                    }
+            for (int k = 0; k < 4; ++k) {
+                const int row = row0 + k * rpp;
+                if (row < nrows) {
+                    uint32_t* dst = tile + row * rw;
+                    dst[j + 1] = v[k];
+                    if (j == 0) dst[0] = (v[k] & 1u) ? ~0u : 0u;
+                    if (j == nzw - 1) dst[rw - 1] = (v[k] >> 31) ? ~0u : 0u;
                 }
             }
         }
-    __syncthreads();
+        __syncthreads();
     }
     int mxF = 0, mxQ = 0;
     bool failed = false;
@@ -567,6 +574,11 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         words(0, 0, cw0, cw1, cw2);
         const uint32_t cls = (cw1 >> b) & 1u;
         const uint32_t flip = cls ? ~0u : 0u;                 // after the XOR a set bit = voxel of the OTHER class
+        // the bits around z of a row as two funnel shifts (v_alignbit_b32) whose shift counts depend on the voxel only:
+        //   up: bit dz of (next : cur) >> b              = voxel z + dz,          dz = 0 .. kFixR
+        //   dn: bit i  of (cur : prev) >> (32 + b - kFixR) = voxel z - kFixR + i,   i = 0 .. kFixR - 1
+        const bool dn_in_cur = b >= kFixR;                    // ... all inside `cur`: (0 : cur) >> (b - kFixR)
+        const uint32_t dn_sh = (uint32_t)(b - kFixR) & 31u;
         int best = 1 << 20;
         bool done = !live;
 #pragma unroll 1
@@ -581,17 +593,23 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
                     const int k = k0 + gl + 16 * m;
                     if (k < kFixRows) {
                         const uint32_t o = order[k];
-                        const int d2 = (int)(o >> 16);
-                        const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
+                        const int d2 = (int)(o >> 16), ofs = rowofs[k];
                         uint32_t prev, cur, next;
-                        words(dx, dy, prev, cur, next);
+                        if (!direct && ofs != kFixOutside) {
+                            const uint32_t* p = c0 + ofs;
+                            prev = p[-1]; cur = p[0]; next = p[1];
+                        } else {
+                            words((int)(o & 0xffu) - kFixR, (int)((o >> 8) & 0xffu) - kFixR, prev, cur, next);
+                        }
                         prev ^= flip; cur ^= flip; next ^= flip;
-                        // dz >= 0: bit dz of `up` = voxel z + dz
-                        const uint32_t up = (uint32_t)((((uint64_t)next << 32) | cur) >> b) & ((2u << kFixR) - 1u);
-                        if (up) { const int dz = __builtin_ctz(up); best = min(best, d2 + dz * dz); }
-                        // dz < 0: bit i of `dn` = voxel z - kFixR + i
-                        const uint32_t dn = (uint32_t)((((uint64_t)cur << 32) | prev) >> (32 + b - kFixR)) & ((1u << kFixR) - 1u);
-                        if (dn) { const int dz = kFixR - (31 - __builtin_clz(dn)); best = min(best, d2 + dz * dz); }
+                        // (no hit: the forced top bit / clz(0) = 32 give dz = 31 / kFixR + 1, i.e. a candidate above kFixR^2 that the
+                        //  final test rejects; it cannot end the scan early before every row that could hold a real hit has gone past)
+                        const uint32_t up = (__builtin_amdgcn_alignbit(next, cur, (uint32_t)b) & ((2u << kFixR) - 1u)) | 0x80000000u;
+                        const int dzu = __builtin_ctz(up);
+                        best = min(best, d2 + dzu * dzu);
+                        const uint32_t dn = __builtin_amdgcn_alignbit(dn_in_cur ? 0u : cur, dn_in_cur ? cur : prev, dn_sh) & ((1u << kFixR) - 1u);
+                        const int dzd = kFixR - 31 + __clz((int)dn);
+                        best = min(best, d2 + dzd * dzd);
                     }
                 }
             }

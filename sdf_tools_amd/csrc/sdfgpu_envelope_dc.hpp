@@ -104,6 +104,9 @@ struct EnvDcArgs {
     unsigned long long* clocks;   // SDFGPU_PHASE_CLOCKS builds only: per-phase shader-clock sums over waves ([stage - 2][8])
     int dbg;                  // SDFGPU_DEBUG_HOOKS builds only (wrong results): bit0 no search, bit1 no fp64 finish, bit2 no stores
     int64_t ntiles;           // LOOP form: tiles of the whole launch (a workgroup takes tiles blockIdx.x, + gridDim.x, ...)
+    const uint32_t* bits;     // STAGE 2, scalar (VEC = false) form only: the dense tier's bit field ([x][y][nzw] words, bit i of word w =
+    int nzw;                  // voxel z = 32 w + i is filled) INSTEAD of the z field: the stand-by behind a trusted dense tier computes
+                              // the z distances itself, so that it needs no z sweep launched in front of it (see zdist_from_bits)
     uint32_t* ran_flag;       // nullptr, or a status word that a launch which does work raises (the stand-by pair reports itself)
 };
 
@@ -124,6 +127,85 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
     return __builtin_fma(d1, h1, s2);
 }
 
+
+// Signed z distance of voxel z of one bit row, as the z sweep (K1) defines it: + distance to the nearest FILLED voxel of the row
+// for a free voxel, - distance to the nearest FREE one for a filled voxel, +-kInf16 when the row holds no voxel of the other
+// class.  Word-at-a-time scans in both directions: slow next to K1 (up to 2 nzw loads per voxel on an empty row), which is fine
+// where it is used -- the stand-by pair behind a trusted dense tier runs once, in the build in which the scene left that tier;
+// what matters there is that the stand-by is ONE launch shorter (every launch costs the dense-certified steady state ~2.6 us:
+// 0.1405 -> 0.1431 ms per 512^3 step measured with a separate guarded K1 in front).  Pad bits of a ragged last word replicate
+// the row's last voxel (k_pack_bits_rows): a hit there is never nearer than that voxel itself, and is dropped.
+__device__ __forceinline__ int zdist_from_bits(const uint32_t* __restrict__ row, int nzw, int nz, int z) {
+    const int w0 = z >> 5, b = z & 31;
+    const uint32_t cw = row[w0];
+    const bool own = (cw >> b) & 1u;
+    const uint32_t flip = own ? 0xFFFFFFFFu : 0u;              // word ^ flip: set bits = voxels of the other class
+    int best = kInf16;
+    {
+        uint32_t x = (cw ^ flip) & (0xFFFFFFFEu << b);          // above z (b = 31: nothing left in this word)
+        int w = w0;
+        while (x == 0u && ++w < nzw) x = row[w] ^ flip;
+        if (x != 0u) { const int zz = w * 32 + (__ffs((int)x) - 1); if (zz < nz) best = zz - z; }
+    }
+    {
+        uint32_t x = (cw ^ flip) & ((1u << b) - 1u);            // below z
+        int w = w0;
+        while (x == 0u && --w >= 0) x = row[w] ^ flip;
+        if (x != 0u) { const int zz = w * 32 + (31 - __clz((int)x)); best = best < z - zz ? best : z - zz; }
+    }
+    return own ? -best : best;
+}
+
+// The same distances for the staging loop of the stand-by y sweep, where the 4 lanes of a DPP quad hold the 4 x 4 voxels of one
+// tile row (16 consecutive z = half a word of the bit row): the quad reads the row's words ONCE, interleaved (lane j takes
+// words 4 i + j: independent loads, 16 bytes per quad and step), every lane reduces its words to four positions -- first set /
+// first clear bit in the words above the tile's word w0, last set / last clear bit in the words below it -- the quad combines
+// them with two quad-permute steps, and each lane finishes its 4 voxels from w0's word and those four positions.  (One
+// zdist_from_bits call per voxel walked up to 2 nzw dependent loads on an empty row: the transition build of the two-box scene
+// took 2.6 ms, 2.9x the steady-state far-field build; this form: see DESIGN.)  All lanes of the wave must be active.
+struct ZRowBits { uint32_t W; int fa1, fa0, lb1, lb0; };
+__device__ __forceinline__ ZRowBits zrow_scan_quad(const uint32_t* __restrict__ row, int nzw, int w0, int j) {
+    int a1 = 1 << 20, a0 = 1 << 20, b1 = -(1 << 20), b0 = -(1 << 20);
+    uint32_t W = 0u;
+    for (int i = 0; 4 * i < nzw; ++i) {
+        const int w = 4 * i + j;
+        if (w < nzw) {
+            const uint32_t x = row[w], nx = ~x;
+            if (w == w0) W = x;
+            if (w > w0) {
+                if (x) a1 = min(a1, 32 * w + __ffs((int)x) - 1);
+                if (nx) a0 = min(a0, 32 * w + __ffs((int)nx) - 1);
+            }
+            if (w < w0) {
+                if (x) b1 = max(b1, 32 * w + 31 - __clz((int)x));
+                if (nx) b0 = max(b0, 32 * w + 31 - __clz((int)nx));
+            }
+        }
+    }
+    auto quad = [](int v, auto op) {
+        v = op(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));       // quad_perm [1,0,3,2]
+        return op(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    };
+    ZRowBits r;
+    r.W = (uint32_t)quad((int)W, [](int x, int y) { return x | y; });
+    r.fa1 = quad(a1, [](int x, int y) { return x < y ? x : y; });
+    r.fa0 = quad(a0, [](int x, int y) { return x < y ? x : y; });
+    r.lb1 = quad(b1, [](int x, int y) { return x > y ? x : y; });
+    r.lb0 = quad(b0, [](int x, int y) { return x > y ? x : y; });
+    return r;
+}
+__device__ __forceinline__ int zdist_from_row(const ZRowBits& r, int w0, int nz, int z) {
+    const int b = z & 31;
+    const bool own = (r.W >> b) & 1u;
+    const uint32_t X = own ? ~r.W : r.W;                        // set bits = voxels of the other class
+    const uint32_t up = X & (0xFFFFFFFEu << b), dn = X & ((1u << b) - 1u);
+    const int zu = up ? 32 * w0 + __ffs((int)up) - 1 : (own ? r.fa0 : r.fa1);
+    const int zd = dn ? 32 * w0 + 31 - __clz((int)dn) : (own ? r.lb0 : r.lb1);
+    int best = kInf16;
+    if (zu < nz) best = zu - z;
+    if (zd >= 0 && z - zd < best) best = z - zd;
+    return own ? -best : best;
+}
 
 constexpr int kDcLines = 16;          // lines per tile (the kernel is a template over 8 / 16 lines and 128 / 256 / 512 lanes: 16 x 256 is the measured optimum)
 constexpr int NB = 8;          // staging: row loads in flight per lane (a 512-line is staged from ONE round of loads)
@@ -375,7 +457,9 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
     auto raw_signed = [&](int line, int q) -> int {
         const uint32_t idx = (uint32_t)line + (uint32_t)q * ls;
         if (STAGE == 3 && in32) return in32[idx];
-        int v = in16[idx];
+        int v;
+        if (STAGE == 2 && !VEC && a.bits) v = zdist_from_bits(a.bits + (o * a.ny + q) * a.nzw, a.nzw, (int)a.nz, (int)c0 + line);
+        else v = in16[idx];
         if constexpr (STAGE == 2) {
             const int g = abs(v);
             const int sq = g >= kInf16 ? kInf32 : g * g;
@@ -452,6 +536,15 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                         const uint2 raw = *reinterpret_cast<const uint2*>(in16 + off);
                         sv[it][0] = (int)raw.x; sv[it][1] = (int)raw.y;         // (unpacked below, once every row is requested)
                     }
+                } else if (STAGE == 2 && a.bits) {
+                    // stand-by: z distances straight from the dense tier's bit field.  The LPR = 4 lanes of a tile row are one
+                    // DPP quad (sub = t & 3) and the tile's 16 lines lie in ONE word of the bit row (c0 is a multiple of 16)
+                    static_assert(LPR == 4, "the lanes of a tile row must be one DPP quad");
+                    const int prow = (pb + PP * it + r < L) ? pb + PP * it + r : L - 1;
+                    const int w0 = (int)(c0 >> 5);
+                    const ZRowBits zr = zrow_scan_quad(a.bits + (o * a.ny + prow) * a.nzw, a.nzw, w0, sub);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sv[it][k] = zdist_from_row(zr, w0, (int)a.nz, (int)c0 + lsel[k]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {

@@ -93,14 +93,17 @@ def test_multi_512_far_field_matches_single_gpu(gpu):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and ext == want_ext
 
 
-def cavity_scene(n=256, cav=88, p=0.3, seed=5):
-    """Near-field clutter (Bernoulli p) around ONE free cavity of cav^3 voxels: the tier probes see a near-field scene
-    (the cavity is < 1/24 of the voxels), the marching x sweep meets voxels that are still undecided after its
-    40-row scan bound (cav / 2 > 41), raises the far flag and leaves them to the far-field kernel -- whose values,
-    not the marching sweep's upper bounds, must reach the extrema (sdfgpu_kernels.hpp `inexact`)."""
-    m = synth.bernoulli_mask((n, n, n), p, seed)
-    a = (n - cav) // 2
-    m[a:a + cav, a:a + cav, a:a + cav] = 0
+def cavity_scene(shape=(512, 32, 512), cav=84, p=0.3, seed=5):
+    """Near-field clutter (Bernoulli p) around ONE free cavity, cav voxels long in x and z and spanning the whole (short) y
+    extent: the y sweep's outward scans end at the grid faces, so the y axis stays near-field, the x probe sees a
+    near-field scene (the cavity is 3 % of the voxels, < 1/24), and the marching x sweep meets voxels that are still
+    undecided after its 40-row scan bound (in-plane distance up to cav / 2 = 42), raises the far flag and leaves them to
+    the far-field kernel -- whose values, not the marching sweep's upper bounds, must reach the extrema (ADVICE r2
+    medium; sdfgpu_kernels.hpp `inexact`)."""
+    nx, ny, nz = shape
+    m = synth.bernoulli_mask(shape, p, seed)
+    ax, az = (nx - cav) // 2, (nz - cav) // 2
+    m[ax:ax + cav, :, az:az + cav] = 0
     return m
 
 

@@ -114,10 +114,15 @@ def test_cavity_in_clutter_extrema_through_whole_lines(gpu):
     assert not any(hints)                                        # the y probes saw a near-field scene
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert ext == want_ext, (ext, want_ext)
-    b = slab.SlabSdfBuilder(slab.HipStages(0), shape, 0.01, False, rank=0, world=1)
-    o, bext = b.build(torch.from_numpy(m).cuda())
-    assert np.array_equal(o.cpu().numpy().view(np.uint32), want.view(np.uint32)) and bext == want_ext
-    assert b.general_builds == 1 and b.fallbacks == 1
+    # the builder at world = 1: the halo sweep sees the whole grid (nothing truncated, exact by itself); with the x sweep
+    # predicted "complete lines" the same build goes through _whole_lines -- both exact, extrema included
+    for predict_far, fallbacks in ((False, 0), (True, 1)):
+        b = slab.SlabSdfBuilder(slab.HipStages(0), shape, 0.01, False, rank=0, world=1)
+        b.predict_far = predict_far
+        o, bext = b.build(torch.from_numpy(m).cuda())
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), want.view(np.uint32)) and bext == want_ext, predict_far
+        assert b.general_builds == 1 and b.fallbacks == fallbacks and b.host_reads == 1
+        assert not b.predict_far                                 # no far hint came back: the next build tries the halo path
 
 
 def test_slab_builder_far_field_world1(gpu):

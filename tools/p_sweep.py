@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 out = torch.empty(shape, dtype=torch.float32, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 rows = []
-for p in [0.5, 0.2, 0.1, 0.05, 0.03, 0.02, 0.01, 0.003, 0.001, 0.0001]:
+for p in ([float(a) for a in sys.argv[1:]] or [0.5, 0.2, 0.1, 0.05, 0.03, 0.02, 0.015, 0.01, 0.003, 0.001, 0.0001]):
     masks = [synth.bernoulli_mask_torch(shape, p, 1 + k, device=dev) for k in range(2)]
     ctx = capi.SdfGpu(0)
     torch.cuda.synchronize()                      # (the mask generators above are asynchronous)
