@@ -547,6 +547,56 @@ def main():
         result["config"]["whole_line_fallbacks"] = builder.fallbacks
         result["config"]["general_exchange"] = getattr(builder, "general_exchange", None)
 
+    if args.force_slab and world == 1:
+        # VERDICT r3 "next round" 5: what the HOST costs a multi-rank build.  libsdfgpu_multi with 1 / 2 / 8 logical ranks on
+        # this one GPU (the messages travel as device-to-device copies) against the single-GPU ABI on the same scenes:
+        # wall time per synchronous build, its host round trips, and the difference to the single-GPU build = host calls +
+        # exchange + (for 2 and 8 ranks) the lost overlap of slabs that share one GPU.
+        try:
+            import numpy as np
+            one = capi.SdfGpu(local_rank)
+            dense_m = synth.bernoulli_mask_torch(shape, 0.5, 1, device=dev)
+            pts = torch.from_numpy(synth.two_box_points(200000, seed=0, scale=nx * res)).to(dev)
+            far_m = torch.zeros(shape, dtype=torch.uint8, device=dev)
+            one.voxelize_points_device(pts.data_ptr(), pts.shape[0], (0.0, 0.0, 0.0), res, shape, far_m.data_ptr(), True, stream.cuda_stream)
+            o1 = torch.empty(shape, dtype=torch.float32, device=dev)
+
+            def wall(fn, reps=10):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) / reps * 1e3
+
+            def single(mk):
+                one.build_device(mk.data_ptr(), shape, o1.data_ptr(), res, False, stream.cuda_stream)
+                one.get_extrema()                                       # (synchronous like the multi-rank call)
+
+            ref = {"dense": wall(lambda: single(dense_m)), "far": wall(lambda: single(far_m))}
+            block = {"single_gpu_abi_ms": {k: round(v, 4) for k, v in ref.items()}, "logical_ranks": {}}
+            for ranks in (1, 2, 8):
+                mg = capi.MultiSdfGpu(ranks, [local_rank] * ranks)
+                outs = []
+                row = {}
+                for name, mk in (("dense", dense_m), ("far", far_m)):
+                    slabs = [mk[a:b] for a, b in (mg.slab_range(nx, r) for r in range(ranks))]
+                    outs = [torch.empty(tuple(t.shape), dtype=torch.float32, device=dev) for t in slabs]
+                    ms = wall(lambda: mg.build_device([t.data_ptr() for t in slabs], shape, [t.data_ptr() for t in outs], res, False))
+                    st = mg.last_stats()
+                    row[name] = {"ms_per_build": round(ms, 4), "host_reads": st["host_reads"],
+                                 "over_single_gpu_us": round((ms - ref[name]) * 1e3, 1), "path": mg.last_path()}
+                row["mispredictions"] = mg.last_stats()["mispredictions"]
+                block["logical_ranks"][str(ranks)] = row
+                mg.close()
+                del outs
+            one.close()
+            result["multi_native_on_one_gpu"] = block
+        except Exception as e:
+            result["multi_native_on_one_gpu"] = {"error": repr(e)}
+
     single = rank == 0 and world == 1 and not args.force_slab
     if single and not args.no_legs:
         legs = {}

@@ -386,7 +386,10 @@ int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy);
 
 /* Which path did the work of the last build (synchronises): bit 0 = the dense kernel decided every voxel
  * (the general pipeline behind it exited immediately); bit 1 / bit 2 = the y / x sweep was done by the far-field
- * kernel (chosen by the probe, after a marching sweep hit its scan bound, or as the stand-by pair). */
+ * kernel (chosen by the probe, after a marching sweep hit its scan bound, or as the stand-by pair); bits 8..13 = why the
+ * dense tier handed the scene on (diagnostics): 8 a staged tile held one class only, 9 a wave without a single decided
+ * voxel, 10 a wave with more undecided voxels than the fix-up kernel takes, 11 a tile over the fix-up kernel's cap,
+ * 12 a voxel beyond the fix-up kernel's reach (d^2 > 64), 13 a voxel beyond the ball with no fix-up stage behind. */
 int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified);
 
 /* Tuning hook (benchmarks): rows marched per thread in the y / x sweeps

@@ -349,7 +349,12 @@ class SdfGpu:
         """{'dense_certified', 'far_y', 'far_x'} of the last build (synchronises)."""
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_last_dense_certified(self._h, ctypes.byref(v)))
-        return {"dense_certified": bool(v.value & 1), "far_y": bool(v.value & 2), "far_x": bool(v.value & 4)}
+        why = (v.value >> 8) & 0xff
+        names = ("one_class_tile", "wave_all_undecided", "wave_too_many_undecided", "tile_over_fixup_cap", "beyond_fixup_reach", "beyond_ball")
+        out = {"dense_certified": bool(v.value & 1), "far_y": bool(v.value & 2), "far_x": bool(v.value & 4)}
+        if why:
+            out["dense_gave_up"] = [n for k, n in enumerate(names) if why & (1 << k)]
+        return out
 
     def last_dense_certified(self):
         return self.last_path()["dense_certified"]

@@ -670,6 +670,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     static const int level3_d2[13] = {1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14};
     for (int l = 0; l < 16; ++l) a.mag3[l] = l < 13 ? (float)(std::sqrt((double)level3_d2[l]) * resolution) : 0.0f;
     a.slots = h->d_slots; a.uncertified = d_uncert;
+    a.reason = early_out ? h->d_small + 21 : nullptr;                // (whole builds: the context's status block; stage calls have none)
     a.nt_store = h->nt_store;
     a.guard = d_guard;
     const int64_t gx = (ny + a.ty - 1) / a.ty, gy = (out_hi - out_lo + a.tx - 1) / a.tx;
@@ -725,7 +726,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
         f.order = (const uint32_t*)h->fix_order.ptr;
         f.nzw = a.nzw; f.log2_nzw = a.log2_nzw; f.ny = a.ny; f.rows_x = a.rows_x; f.out_lo = a.out_lo; f.out_hi = a.out_hi;
         f.tx = a.tx; f.ty = a.ty; f.log2_ty = a.log2_ty; f.resolution = resolution;
-        f.slots = h->d_slots; f.uncertified = d_uncert;
+        f.slots = h->d_slots; f.uncertified = d_uncert; f.reason = a.reason;
         const size_t flds = (size_t)(2 * kFixOrderPad + kFixCap + 4) * 4 +
                             (size_t)(a.tx + 2 * kFixTileR) * (a.ty + 2 * kFixTileR) * (a.nzw + 2) * 4;
         if (bd == 1024) hipLaunchKernelGGL(k_ball_fixup<1024>, grid, dim3(1024), flds, s, f);
@@ -1974,7 +1975,9 @@ int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified) {
     HIP_TRY(h, hipMemcpyAsync(v, h->d_result, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
     HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     // bit 0: dense kernel decided everything; bit 1 / 2: the y / x sweep was redone by the envelope kernel
-    *out_certified = ((h->last_dense && v[3] == 0) ? 1 : 0) | (v[4] ? 2 : 0) | (v[5] ? 4 : 0);
+    uint32_t why = 0;
+    HIP_TRY(h, hipMemcpy(&why, h->d_result + 21, sizeof why, hipMemcpyDeviceToHost));
+    *out_certified = ((h->last_dense && v[3] == 0) ? 1 : 0) | (v[4] ? 2 : 0) | (v[5] ? 4 : 0) | (int)((why & 0xffu) << 8);
     return SDFGPU_OK;
 }
 

@@ -100,6 +100,7 @@ struct DenseArgs {
     float mag3[16];         // ... of the 13 levels of KD3 (sdfgpu_dense3.hpp); [13..15] = 0
     uint32_t* slots;        // [kSlots][kSlotWords]: per-slot {max d^2 free, max d^2 filled}, see slot_max2 / k_fold_slots
     uint32_t* uncertified;  // set to 1 if some voxel has no opposite-class voxel within d^2 <= 8
+    uint32_t* reason;       // nullptr, or a word that collects WHY the tier gave up (kGiveUp* bits; diagnostics, whole builds only)
     // fix-up mode (k_ball_fixup runs behind this launch): instead of raising `uncertified`, a wave that holds
     // undecided voxels writes its 64 "undecided" words, sets its bit in the tile's flag word and raises fix_needed
     uint32_t* unc;          // [out rows][ny][nzw] undecided bits (only written by waves that have some)
@@ -116,6 +117,14 @@ struct DenseArgs {
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
     const uint32_t* guard;  // KD3 only: non-null = run iff *guard != 0 (the staged fix-up stage behind KD in the same build)
 };
+
+// why the dense tier handed a scene on (status word 21 of whole builds; sdfgpu_last_dense_certified reports them from bit 8 up)
+constexpr uint32_t kGiveUpOneClassTile = 1u, kGiveUpWaveAllUndecided = 2u, kGiveUpWaveTooMany = 4u, kGiveUpTileOverCap = 8u,
+                   kGiveUpBeyondReach = 16u, kGiveUpBeyondBall = 32u;
+__device__ __forceinline__ void note_reason(uint32_t* reason, uint32_t bit) {
+    if (reason && !(__hip_atomic_load(reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(reason, bit);
+}
+
 
 constexpr int kBallR = 2;                                    // |dx|,|dy|,|dz| <= 2
 __host__ __device__ constexpr int ball_level(int d2) {       // d^2 -> level index, -1 = not in the ball
@@ -390,9 +399,10 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
                 atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up
                 raise_flag(a.fix_needed);
                 // a wave without a single decided voxel sits in empty (or solid) space: nothing for the fix-up kernel
-                if (a.early_out && all_undecided) raise_flag(a.uncertified);
+                if (a.early_out && all_undecided) { raise_flag(a.uncertified); note_reason(a.reason, kGiveUpWaveAllUndecided); }
             } else {
                 raise_flag(a.uncertified);
+                note_reason(a.reason, kGiveUpBeyondBall);
             }
         }
     }
@@ -439,6 +449,7 @@ struct FixArgs {
     double resolution;
     uint32_t* slots;
     uint32_t* uncertified;
+    uint32_t* reason;       // see DenseArgs
 };
 
 template <int BD>
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     __syncthreads();
     const uint32_t n = *count;
     if (n > (uint32_t)kFixCap) {                              // too many: let the general sweeps do the whole grid
-        if (t == 0) raise_flag(a.uncertified);
+        if (t == 0) { raise_flag(a.uncertified); note_reason(a.reason, kGiveUpTileOverCap); }
         return;
     }
     // A tile with a handful of undecided voxels (Bernoulli p = 0.1: two per tile, in nearly every tile) reads the rows it
@@ -578,6 +589,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         //   up: bit dz of (next : cur) >> b              = voxel z + dz,          dz = 0 .. kFixR
         //   dn: bit i  of (cur : prev) >> (32 + b - kFixR) = voxel z - kFixR + i,   i = 0 .. kFixR - 1
         const bool dn_in_cur = b >= kFixR;                    // ... all inside `cur`: (0 : cur) >> (b - kFixR)
+        const bool up_past_cur = b + kFixR > 31;              // the upward window reaches into `next`
         const uint32_t dn_sh = (uint32_t)(b - kFixR) & 31u;
         int best = 1 << 20;
         bool done = !live;
@@ -594,10 +606,14 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
                     if (k < kFixRows) {
                         const uint32_t o = order[k];
                         const int d2 = (int)(o >> 16), ofs = rowofs[k];
-                        uint32_t prev, cur, next;
+                        uint32_t prev = 0u, cur, next = 0u;
                         if (!direct && ofs != kFixOutside) {
+                            // (the neighbour words only where this voxel's bit window leaves `cur`: half of the voxels need neither,
+                            //  and every LDS access spared is a bank conflict spared -- the rows of a group's 16 lanes are scattered)
                             const uint32_t* p = c0 + ofs;
-                            prev = p[-1]; cur = p[0]; next = p[1];
+                            cur = p[0];
+                            if (!dn_in_cur) prev = p[-1];
+                            if (up_past_cur) next = p[1];
                         } else {
                             words((int)(o & 0xffu) - kFixR, (int)((o >> 8) & 0xffu) - kFixR, prev, cur, next);
                         }
@@ -636,7 +652,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     const bool any_failed = __any(failed);
     if ((t & 63) == 0) {
         slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
-        if (any_failed) raise_flag(a.uncertified);
+        if (any_failed) { raise_flag(a.uncertified); note_reason(a.reason, kGiveUpBeyondReach); }
     }
 }
 

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
 #pragma unroll
         for (int k = 0; k < BD / 64; ++k) { z = z && uni[2 * k] != 0u; o = o && uni[2 * k + 1] != 0u; }
         if (z || o) {
-            if (t == 0) raise_flag(a.uncertified);
+            if (t == 0) { raise_flag(a.uncertified); note_reason(a.reason, kGiveUpOneClassTile); }
             return;
         }
     }
@@ -314,9 +314,13 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
                 atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up
                 raise_flag(a.fix_needed);
                 // a wave without a single decided voxel sits in empty (or solid) space: nothing for the fix-up kernel
-                if ((a.early_out && all_undecided) || hopeless) raise_flag(a.uncertified);
+                if ((a.early_out && all_undecided) || hopeless) {
+                    raise_flag(a.uncertified);
+                    note_reason(a.reason, hopeless ? kGiveUpWaveTooMany : kGiveUpWaveAllUndecided);
+                }
             } else {
                 raise_flag(a.uncertified);
+                note_reason(a.reason, kGiveUpBeyondBall);
             }
         }
     }

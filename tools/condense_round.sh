@@ -6,7 +6,7 @@ tag=$1; name=$2
 G=gpurun_out/$tag; P=profiles
 cp $G/bench.json $P/${name}_bench.json
 cp $G/stream_bench.json $P/${name}_stream_bench.json
-cp $G/bench_slab_world1.json $P/${name}_bench_slab_world1.json
+head -1 $G/bench_slab_world1.json > $P/${name}_bench_slab_world1.json      # (RCCL prints its banner on stdout behind the line)
 [ -f $G/psweep.jsonl ] && cp $G/psweep.jsonl $P/${name}_p_sweep.jsonl
 python tools/rocprof_summary.py stats $G/stats_dense $P/${name}_dense_kernel_stats.md
 python tools/rocprof_summary.py stats $G/stats_stream $P/${name}_stream_kernel_stats.md
