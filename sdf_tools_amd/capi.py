@@ -43,7 +43,7 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("SDFGPU_LIB") or _build.LIB        # (SDFGPU_LIB: a profiling build of the same library, tools/ only)
     if not os.path.exists(path):
         raise ImportError("libsdfgpu.so is not built (run `python -m sdf_tools_amd.build`); "
                           "there is no CPU fallback for the SDF build path")

@@ -245,6 +245,68 @@ def test_error_codes(gpu):
     assert np.all(np.isposinf(s))
 
 
+def test_device_resident_entry_points_through_the_abi(gpu):
+    """Round 4: sdfgpu_device_malloc / sdfgpu_build_to_device / sdfgpu_build_cells_to_device (host input, field left in HBM) and
+    sdfgpu_query_points (host points -> host answers against that field): same field and extrema as sdfgpu_build, same
+    answers as the device-pointer query on it; error codes for null / bad arguments."""
+    import ctypes
+    import torch
+    from sdf_tools_amd.capi import SdfGpuError
+    shape, res = (40, 33, 48), 0.05
+    m = synth.bernoulli_mask(shape, 0.1, 11)
+    want, want_ext = gpu.build(m, res, True)
+    n = int(np.prod(shape))
+    d_field = gpu.device_malloc(n * 4)
+    try:
+        ext = gpu.build_to_device(m, d_field, res, True)
+        assert ext == want_ext
+        back = np.empty(shape, np.float32)
+        gpu._check(gpu._lib.sdfgpu_copy_to_host(gpu._h, back.ctypes.data, ctypes.c_void_p(d_field), n * 4, None))
+        assert np.array_equal(back.view(np.uint32), want.view(np.uint32))
+        # cells form: 8-byte COLLISION_CELL records, unknown (0.5) filled on request
+        cells = np.zeros(shape + (2,), np.float32)
+        cells[..., 0] = np.where(m != 0, 1.0, 0.0)
+        cells[3, 4, 5, 0] = 0.5
+        ext_c = (ctypes.c_double * 2)()
+        c = np.ascontiguousarray(cells)
+        gpu._check(gpu._lib.sdfgpu_build_cells_to_device(gpu._h, c.ctypes.data, 8, 0, 1, *shape, res, 0, ctypes.c_void_p(d_field),
+                                                         ctypes.byref(ext_c, 0), ctypes.byref(ext_c, 8)))
+        want_c, want_c_ext = gpu.build_cells(cells, shape, 8, 0, True, res, False)
+        gpu._check(gpu._lib.sdfgpu_copy_to_host(gpu._h, back.ctypes.data, ctypes.c_void_p(d_field), n * 4, None))
+        assert np.array_equal(back.view(np.uint32), want_c.view(np.uint32)) and (ext_c[0], ext_c[1]) == want_c_ext
+        # host-point queries == device-pointer queries on the same field (a rotated, shifted frame)
+        rng = np.random.default_rng(1)
+        pts = rng.uniform(-0.2, 2.6, size=(3000, 3))
+        w2g = [0, 1, 0, 0.1, -1, 0, 0, 2.0, 0, 0, 1, -0.05]
+        rot = [0, -1, 0, 1, 0, 0, 0, 0, 1]
+        dist, grad, flags = gpu.query_points(d_field, shape, res, pts, world_to_grid=w2g, rotation=rot, oob_value=7.5,
+                                             enable_edge_gradients=True)
+        tp = torch.from_numpy(pts).cuda()
+        td, tg, tf = (torch.empty(3000, dtype=torch.float64, device="cuda"), torch.empty((3000, 3), dtype=torch.float64, device="cuda"),
+                      torch.empty(3000, dtype=torch.uint8, device="cuda"))
+        gpu.query_points_device(d_field, shape, res, tp.data_ptr(), 3000, td.data_ptr(), tg.data_ptr(), tf.data_ptr(),
+                                world_to_grid=w2g, rotation=rot, oob_value=7.5, enable_edge_gradients=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(flags, tf.cpu().numpy()) and 0 < int((flags & 1).sum()) < 3000
+        assert np.array_equal(dist, td.cpu().numpy()) and np.array_equal(grad, tg.cpu().numpy(), equal_nan=True)
+        assert np.all(dist[(flags & 1) == 0] == 7.5)
+        # zero points / no outputs are no-ops; bad arguments are INVALID_ARGUMENT
+        d0, g0, f0 = gpu.query_points(d_field, shape, res, np.zeros((0, 3)))
+        assert d0.shape == (0,)
+        with pytest.raises(SdfGpuError) as ei:
+            gpu.query_points(0, shape, res, pts)
+        assert ei.value.code == -1
+        with pytest.raises(SdfGpuError) as ei:
+            gpu.build_to_device(m, 0, res)
+        assert ei.value.code == -1
+        with pytest.raises(SdfGpuError) as ei:
+            gpu.query_points(d_field, shape, -1.0, pts)
+        assert ei.value.code == -1
+    finally:
+        gpu.device_free(d_field)
+    gpu.device_free(0)                                          # freeing NULL is fine
+
+
 def test_tuning_does_not_change_results(gpu):
     m = synth.bernoulli_mask((50, 45, 64), 0.2, 5)
     base, ext = gpu.build(m, 1.0)
