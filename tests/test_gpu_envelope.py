@@ -117,6 +117,44 @@ def test_policy_transitions_stay_exact(gpu, shape):
         assert ext == want[name][1], name
 
 
+@pytest.mark.parametrize("shape", [(40, 33, 50), (25, 20, 15), (17, 64, 96), (9, 7, 130), (64, 64, 64), (5, 300, 33)])
+def test_standby_pair_takes_over_exactly_on_every_shape(gpu, shape):
+    """Round 4: behind a TRUSTED dense tier the general pipeline is the stand-by pair -- the far-field y sweep staged from the
+    dense tier's BIT FIELD (ragged last word, rows padded to whole words on the generic dense shapes, partial 16-line tiles,
+    quad-cooperative row scan) and the far-field x sweep, both in the LOOP form.  Put the handle into that state (option
+    `expect_dense`), then build scenes the dense tier cannot certify -- boxes, a sparse cloud, a single voxel, an empty grid,
+    an almost-full grid -- with and without the virtual border and through the COLLISION_CELL input: exact, extrema included,
+    and the status says the far-field kernels did it."""
+    rng = np.random.default_rng(7)
+    nx, ny, nz = shape
+    scenes_ = {"boxes": _two_boxes(shape), "sparse": synth.bernoulli_mask(shape, 0.004, 3), "empty": np.zeros(shape, np.uint8),
+               "single": np.zeros(shape, np.uint8), "almost full": (1 - synth.bernoulli_mask(shape, 0.003, 5)).astype(np.uint8)}
+    scenes_["single"][nx // 2, ny - 1, nz - 1] = 1
+    dense = synth.bernoulli_mask(shape, 0.5, 1)
+    want_dense = O.exact_sdf(dense, 0.05)
+    for name, m in scenes_.items():
+        for vb in (False, True):
+            gpu.set_option("policy_reset", 1)
+            sdf, ext = gpu.build(dense, 0.05)                        # a certified dense build ...
+            assert gpu.last_path()["dense_certified"], (name, shape)
+            assert np.array_equal(sdf.view(np.uint32), want_dense[0].view(np.uint32))
+            gpu.set_option("expect_dense", 1)                        # ... after which the handle trusts its dense tier
+            want, want_ext, _ = O.exact_sdf(m, 0.05, vb)
+            if name == "sparse" and not vb:
+                cells = np.zeros(shape + (2,), np.float32)
+                cells[..., 0] = m
+                sdf, ext = gpu.build_cells(cells, shape, 8, 0, False, 0.05, vb)
+            else:
+                sdf, ext = gpu.build(m, 0.05, vb)
+            info, path = gpu.last_build_info(), gpu.last_path()
+            assert info["standby_far"] and not info["fused_zy"], (name, shape, vb, info)
+            bad = np.argwhere(sdf.view(np.uint32) != want.view(np.uint32))
+            assert len(bad) == 0, (name, shape, vb, len(bad), bad[:3].tolist())
+            assert ext == want_ext, (name, shape, vb, ext, want_ext)
+            assert not path["dense_certified"] and path["far_y"] and path["far_x"], (name, shape, vb, path)
+    gpu.set_option("policy_reset", 1)
+
+
 def test_envelope_rare_paths_deep_pops_and_dense_advances(gpu):
     """The hot loops of the envelope kernels read only LDS / registers; these scenes force their out-of-line paths:
     a site that pops far more stack entries than the 16-entry LDS ring holds, and runs of positions that each
