@@ -117,7 +117,8 @@ def test_policy_transitions_stay_exact(gpu, shape):
         assert ext == want[name][1], name
 
 
-@pytest.mark.parametrize("shape", [(40, 33, 50), (25, 20, 15), (17, 64, 96), (9, 7, 130), (64, 64, 64), (5, 300, 33)])
+@pytest.mark.parametrize("shape", [(40, 33, 50), (25, 20, 15), (17, 64, 96), (9, 7, 130), (64, 64, 64), (5, 300, 33), (20, 40, 1),
+                                   (1, 1, 100), (3, 1, 257)])
 def test_standby_pair_takes_over_exactly_on_every_shape(gpu, shape):
     """Round 4: behind a TRUSTED dense tier the general pipeline is the stand-by pair -- the far-field y sweep staged from the
     dense tier's BIT FIELD (ragged last word, rows padded to whole words on the generic dense shapes, partial 16-line tiles,
@@ -130,7 +131,7 @@ def test_standby_pair_takes_over_exactly_on_every_shape(gpu, shape):
     scenes_ = {"boxes": _two_boxes(shape), "sparse": synth.bernoulli_mask(shape, 0.004, 3), "empty": np.zeros(shape, np.uint8),
                "single": np.zeros(shape, np.uint8), "almost full": (1 - synth.bernoulli_mask(shape, 0.003, 5)).astype(np.uint8)}
     scenes_["single"][nx // 2, ny - 1, nz - 1] = 1
-    dense = synth.bernoulli_mask(shape, 0.5, 1)
+    dense = (np.indices(shape).sum(axis=0) & 1).astype(np.uint8)      # a checkerboard: certified on any shape, 1-D lines included
     want_dense = O.exact_sdf(dense, 0.05)
     for name, m in scenes_.items():
         for vb in (False, True):
