@@ -63,6 +63,12 @@ while time.time() - t0 < budget:
     ctx.set_option("far_threshold_x", int(rng.choice([1, 9, 25])))
     ctx.set_option("probe_window", int(rng.random() < 0.7))      # window statistic / level A on sampled tiles
     ctx.set_option("z_wave", int(rng.random() < 0.8))
+    # round 4: the handle "trusts its dense tier" (the general pipeline behind it is then the stand-by pair: far-field y sweep
+    # staged from the bit field + far-field x sweep, LOOP form) with small and large stand-by grids, or the old stand-by
+    ctx.set_option("standby_far", int(rng.random() < 0.85))
+    ctx.set_option("standby_grid", int(rng.choice([32, 64, 1024])))
+    if rng.random() < 0.4:
+        ctx.set_option("expect_dense", 1)
     got, ext = ctx.build(m, res, vb)
     want, want_ext, _ = O.exact_sdf(m, res, vb)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
