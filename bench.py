@@ -624,6 +624,20 @@ def main():
             legs["config_256_cube"] = run_leg(torch, capi, dev, s256, res, m256, {}, max(leg_steps, 50), 10,
                                               "256x256x256 Bernoulli(p=0.5), 3 grids in rotation, default policy (BASELINE configs[1])")
             del m256
+            # BASELINE configs[3]'s WORKLOAD (1024^3) on this one GPU -- the N = 1 point of that grid's scaling table (the
+            # 8-GPU x-slab run of it is `bench.py --gpus 8`); 1 GiB of mask in, 4 GiB of fp32 out, everything resident
+            try:
+                free_b, _ = torch.cuda.mem_get_info(dev)
+                if free_b > 24 * (1 << 30):
+                    s1k = (1024, 1024, 1024)
+                    m1k = [synth.bernoulli_mask_torch(s1k, 0.5, 41, device=dev)]
+                    legs["config_1024_cube_single_gpu"] = run_leg(torch, capi, dev, s1k, res, m1k, {}, 10, 3,
+                                                                  "1024x1024x1024 Bernoulli(p=0.5), one grid, default policy, ONE GPU "
+                                                                  "(BASELINE configs[3]'s workload; its 8-GPU partition is --gpus 8)")
+                    del m1k
+                    torch.cuda.empty_cache()
+            except Exception as e:
+                legs["config_1024_cube_single_gpu"] = {"error": repr(e)}
         except Exception as e:                     # a leg must never take the contract line down with it
             legs["error"] = repr(e)
         result["legs"] = legs
