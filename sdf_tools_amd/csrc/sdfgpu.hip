@@ -8,6 +8,7 @@
 #include "sdfgpu_fused_zy.hpp"
 #include "sdfgpu_dense.hpp"
 #include "sdfgpu_envelope_dc.hpp"
+#include "sdfgpu_policy.hpp"
 
 #include <sys/mman.h>
 
@@ -73,22 +74,9 @@ struct sdfgpu_context {
     bool dense_on = true;            // try the bit-parallel dense kernel first when the shape allows
     int pack_variant = 0;
     int ball_block = 0;
-    int fixup_on = 1;             // fix-up kernel behind the dense ball kernel (almost-dense scenes)
-    bool fix_mode = false;        // policy: launch the fix-up kernel with the next dense build
-    bool prev_fix_mode = false;
-    int fix_clean = 0;            // consecutive fix-mode builds that needed no fix (the mode is left after 8)
-    int dense3_on = 1;            // KD3 (ball kernel with |offset| <= 3) in KD's place whenever the fix-up kernel runs (option "dense3")
-    bool dense3_mode = false;     // option "dense3_mode": KD3 + KF with every dense build (tests)
-    int dense3_staged = 1;        // a build that does not expect KD to decide the scene enqueues KD3 + KF behind KD, guarded on KD's verdict (option "dense3_staged")
-    bool prev_staged = false;
-    int fix_trust = 0;            // certified fix-up-mode reports in a row (the cheap stand-by pipeline needs 4)
+    DensePolicy pol;              // what the handle has learned about its scenes' dense tier (sdfgpu_policy.hpp)
     uint32_t* unc_override = nullptr;   // set around the staged KD3 launch: undecided bits in the z field's storage
     size_t unc_override_bytes = 0;
-    int dense_retry = 16;         // after an uncertified dense attempt, try the dense kernels again every N-th build (0 = always)
-    int dense_skip = 0;           // builds left that skip the dense kernels
-    int dense_backoff = 0;        // current length of that pause: doubles while the attempts keep failing (a caller that
-                                  // enqueues builds without synchronising feeds the policy ~30 builds late, so a fixed
-                                  // pause of dense_retry builds would leave the dense kernels in most of its builds)
     int defer_fold = 0;           // stage entry points leave their maxima in the slot array until sdfgpu_fold_extrema_device
     int ball_variant = 0;         // debugging: bit0 = bounds-checked expansion, bit1 = generic (non-ZINV) expansion
     int nt_store = 0;               // measured: non-temporal output stores slow the next build's pack (0.03 -> 0.08 ms)
@@ -129,9 +117,6 @@ struct sdfgpu_context {
                                           // work on another stream waits for it first
     bool order_valid = false;             // build_done_ev has been recorded on order_stream
     hipStream_t order_stream = nullptr;
-    bool prev_dense = false;
-    bool prev_generic = false;       // ... and it was the generic form (no fix-up kernel behind it)
-    bool expect_dense = false;
     bool last_dense = false;
     const uint32_t* guard = nullptr; // set while a build enqueues the flag-guarded general pipeline
     bool plane16_on = true;          // use the int16 plane field + side table when the shape allows
@@ -785,57 +770,22 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // shapes / modes the tuned dense kernels do not take go through their generic forms (any nz, virtual border)
     const bool dense_generic = !dense && h->dense_on && h->dense_generic_on && nx <= 0x7fffffff && ny <= 0x7fffffff;
     dense = dense || dense_generic;
-    // Learn from the previous build on this handle, if its flags have arrived (never a wait).  Every setting below is exact;
-    // the policy only decides whether the DENSE tier is worth trying (which tier does a sweep is decided on the device inside
-    // the build -- round 3 removed the host-learned "envelope mode" and window widths):
-    //   dense-certified  -> the general kernels will exit on their guard: enqueue the cheapest form of them
-    //                       (fused K12 + K3, unbounded scans, no far-field kernels)
+    // Learn from an earlier build on this handle, if its status block has arrived (never a wait), and plan the dense tier of
+    // this one: sdfgpu_policy.hpp.  Every outcome is exact; the policy only decides whether and in which form the DENSE tier is
+    // enqueued and whether the pipeline behind it may be the two-launch stand-by (which tier does a sweep is decided on the
+    // device inside the build).
     if (h->flags_pending && hipEventQuery(h->flags_ev) == hipSuccess) {
         h->flags_pending = false;
-        const bool general_ran = !h->prev_dense || h->h_flags[3] != 0;
-        // The cheap stand-by (fused K12 + K3/16 with UNBOUNDED scans, no probes) is only safe behind a dense tier that is
-        // trusted to certify the scene: on a noise-like scene at the edge of the fix-up stage's reach (Bernoulli p = 0.02: two
-        // seeds of three certify) every failed build ran those scans over a sparse grid -- 4.6 ms, 1.94 ms per build over
-        // the rotation.  A handle in fix-up mode earns the cheap stand-by with 4 certified reports in a row and loses it
-        // with the first failure; until then the stand-by is the full pipeline (bounded scans, probes, far-field kernels).
-        // (a STAGED build that KD failed and the fix-up stage certified -- status word 8 = KD's own verdict -- is a fix-up-mode
-        //  report like any other: it counts toward the trust and is held to it)
-        const bool via_fix = h->prev_fix_mode || (h->prev_staged && h->h_flags[8] != 0);
-        if (h->prev_dense && via_fix) h->fix_trust = general_ran ? 0 : std::min(255, h->fix_trust + 1);
-        h->expect_dense = !general_ran && (!via_fix || h->fix_trust >= 4);
-        //   dense attempted but not certified -> pack + ball were wasted (0.13 ms at 512^3): leave them out of the
-        //                       next dense_retry - 1 builds, then try once more
-        //   almost dense (the ball kernel left voxels undecided): first try the fix-up kernel behind it; only if that
-        //   cannot certify the scene either are the dense kernels left out of the next builds
-        //   (the fix-up stage = KD3 + KF where the shape allows it -- the ball kernel with |offset| <= 3 costs what KD costs
-        //   on the scenes KD decides and leaves KF 1/50 of the voxels: 0.20 instead of 0.47 ms at p = 0.05 -- else KD + KF)
-        if (h->prev_dense && h->fixup_on && !h->prev_generic) {
-            //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict, status word 20, as word 8)
-            if (!h->prev_fix_mode) { h->fix_mode = h->h_flags[h->prev_staged ? 8 : 3] != 0; h->fix_clean = 0; }   // KD alone could not: the fix-up stage next
-            else if (h->h_flags[3] != 0) h->fix_mode = false;                      // KF could not certify it either
-            else {                                                                 // keep KF while it is needed (left after
-                h->fix_clean = h->h_flags[6] != 0 ? 0 : h->fix_clean + 1;          // 8 clean builds in a row: a scene at the
-                if (h->fix_clean >= 8) { h->fix_mode = false; h->fix_clean = 0; }  // edge of the ball must not flap)
-            }
-        }
-        if (h->prev_dense && h->h_flags[3] != 0 && h->dense_retry > 0 && (h->prev_fix_mode || h->prev_staged || !h->fixup_on || h->prev_generic)) {
-            h->dense_backoff = h->dense_backoff ? std::min(255, 2 * h->dense_backoff + 1) : h->dense_retry - 1;
-            h->dense_skip = h->dense_backoff;
-        }
-        if (h->prev_dense && h->h_flags[3] == 0) { h->dense_backoff = 0; h->dense_skip = 0; }   // certified again: start over
+        //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict, status word 20, as word 8)
+        h->pol.consume_report(h->h_flags[3] != 0, h->h_flags[6] != 0, h->h_flags[8] != 0);
     }
-    if (dense && h->dense_skip > 0) { --h->dense_skip; dense = false; }
-    // A retry after a pause is a PROBE: pause again at once, on the assumption that it fails like the attempts before it, and let
-    // its report lift the pause if it did not.  (Round 4: with the pause re-armed only when the failure report arrived, a caller
-    // that enqueues builds without synchronising -- the report is then ~30 builds late -- attempted the dense tier in EVERY build
-    // between the end of a pause and that report: Bernoulli p = 0.015 at 512^3 took 1.16 ms per build where p = 0.01 takes 1.00,
-    // 0.2 ms of it dense attempts that could not succeed.)
-    else if (dense && h->dense_backoff > 0 && h->dense_retry > 0) h->dense_skip = h->dense_backoff;
+    const DensePlan plan = h->pol.plan(dense, dense_generic, nz / 32 <= 256 && h->ball_block <= 256, vb != 0);
+    dense = plan.dense;
     // bounded marching scans + the far-field kernel behind them, on every shape that kernel takes; other shapes (lines beyond
     // 2048, keys beyond 32 bits) keep unbounded marching scans.  Shapes without the 16-bit plane field (nz % 4 != 0) hand
     // exact int32 plane values from the y to the x sweep.
     const bool far_ok = h->envelope_on && far_geometry_ok(h, 2, nx, ny, nz) && far_geometry_ok(h, 3, nx, ny, nz);
-    const bool envelope = far_ok && !(h->expect_dense && dense);
+    const bool envelope = far_ok && !(h->pol.expect_dense && dense);
     // Stand-by behind a TRUSTED dense tier (round 4).  It nearly always exits on its guard, so it must be
     // few launches with small grids -- and since the scene of a stream can change under the handle (dense -> far-field), it
     // must be BOUNDED whatever the scene turns into.  That is the far-field pair with no probes and no marching sweeps:
@@ -844,7 +794,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // K12 + K3/16 pair it replaces (a third one, a guarded K1, cost the dense-certified step 2.6 us: 0.1405 -> 0.1431 ms),
     // O(L log L) per line on any input (the old pair ran unbounded outward scans: tens of ms on the build in which a
     // dense scene turned into the two-box cloud).
-    const bool standby = far_ok && h->standby_far && h->expect_dense && dense && !h->fused_always;
+    const bool standby = far_ok && h->standby_far && h->pol.expect_dense && dense && !h->fused_always;
     // Device-side tier selection: the marching-vs-far-field choice of each axis is made INSIDE this build from a probe of the
     // sweep's own input, so a fresh context (the reference's API is one-shot: collision_map.hpp:680-712 builds and returns)
     // never runs a sweep that is thrown away, and a handle's latency does not depend on what it built before.
@@ -853,7 +803,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // again; everywhere else K1 + K2 (rows from the int16 z field) scan much faster than the fused kernel
     // recomputes, and only they can hand a far-field y sweep to the envelope kernel.
     const bool fused = !standby && !d_cells && fused_zy_eligible(h, d_filled, zy_out, nz) &&
-                       (h->fused_always || (dense && h->expect_dense) || (!envelope && !dense));
+                       (h->fused_always || (dense && h->pol.expect_dense) || (!envelope && !dense));
     const bool select = dev_select && !fused;
     if (!fused && !standby) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
@@ -915,15 +865,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         // fix-up mode (policy): undecided voxels go to the fix-up kernel, which raises `uncertified` only for what it
         // cannot decide either; otherwise the ball kernel raises it directly and nothing extra is launched
         // (with a virtual border the fix-up kernel stays out: a voxel it would finish may still be bound by b >= 3)
-        const bool fix = h->fixup_on && h->fix_mode && !vb;
-        // ... with KD3 (the wider ball, sdfgpu_dense3.hpp) in KD's place where the shape allows it
-        const bool d3_ok = h->dense3_on && h->fixup_on && !vb && nz / 32 <= 256 && h->ball_block <= 256;
-        cur_dense3 = d3_ok && (fix || h->dense3_mode);
-        // A build that has no reason to expect that KD decides the scene (a fresh context: the reference API is one-shot;
-        // or the build after a failure) enqueues the fix-up stage behind KD in the SAME build, guarded on KD's verdict
-        // (status word 20), so that an almost-dense or noise-like scene does not pay for the sweeps once before the
-        // handle has learned: first build at p = 0.05 0.85 -> 0.35 ms.  Two guarded launches; not in the steady dense state.
-        cur_staged = d3_ok && !cur_dense3 && !h->expect_dense && h->dense3_staged;
+        // (fix-up mode, KD3 in KD's place, the fix-up stage staged behind KD: DensePolicy::plan)
+        const bool fix = plan.fix;
+        cur_dense3 = plan.dense3;
+        cur_staged = plan.staged;
         if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
                                        cur_staged ? h->d_small + 20 : h->d_small + 3, s,
                                        (fix || cur_dense3) ? h->d_small + 6 : nullptr, true, vb, nx, cur_dense3 ? 3 : 2)) return rc;
@@ -1060,7 +1005,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // enqueues builds back to back without ever synchronising keeps feeding the policy (a few builds late), and the
     // builds in between skip the host write.  What the reported build was (dense? fix-up? envelope mode?) is
     // remembered with the report -- not with whatever build happens to be the latest when it is read.
-    const bool report = h->envelope_on && h->h_flags_dev && !h->flags_pending;
+    // (only a build that carried the dense tier has anything to teach the policy: the builds of a pause leave the report slot
+    //  free, so that the PROBE at its end is the build whose verdict comes back -- with every build reporting, the slot was
+    //  usually taken by a paused build when the probe came, its failure went unseen and the pause never grew; tests/policy_harness)
+    const bool report = h->envelope_on && h->h_flags_dev && !h->flags_pending && dense;
     if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : nullptr)) return rc;
     h->small_clean = true;
     h->guard = nullptr;
@@ -1068,10 +1016,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (report) {
         HIP_TRY(h, hipEventRecord(h->flags_ev, s));
         h->flags_pending = true;
-        h->prev_dense = dense;
-        h->prev_generic = dense_generic;
-        h->prev_fix_mode = cur_fix_mode;
-        h->prev_staged = cur_staged;
+        h->pol.prev = ReportedBuild{dense, dense_generic, cur_fix_mode, cur_staged};
     }
     if (prof) {
         HIP_TRY(h, mark(7));
@@ -1940,18 +1885,18 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "standby_far") h->standby_far = value != 0;
     else if (n == "standby_grid") h->standby_grid = value >= 32 ? value : 1024;
-    else if (n == "expect_dense") h->expect_dense = value != 0;      // tests: put the handle into the "dense tier trusted" state
+    else if (n == "expect_dense") h->pol.expect_dense = value != 0;      // tests: put the handle into the "dense tier trusted" state
     else if (n == "pack_variant") h->pack_variant = value;
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
-    else if (n == "policy_reset") { h->flags_pending = false; h->expect_dense = false; h->dense_skip = 0; h->dense_backoff = 0; h->fix_mode = false; h->dense3_mode = false; h->fix_trust = 0; }
-    else if (n == "fixup") { h->fixup_on = value != 0; h->fix_mode = false; h->dense3_mode = false; }
-    else if (n == "dense3") { h->dense3_on = value != 0; h->dense3_mode = false; }
-    else if (n == "dense3_mode") h->dense3_mode = value != 0;
-    else if (n == "dense3_staged") h->dense3_staged = value != 0;
-    else if (n == "fixup_mode") h->fix_mode = value != 0;
-    else if (n == "dense_retry") { h->dense_retry = value; h->dense_skip = 0; h->dense_backoff = 0; }
+    else if (n == "policy_reset") { h->flags_pending = false; h->pol.reset(); }
+    else if (n == "fixup") { h->pol.fixup_on = value != 0; h->pol.fix_mode = false; h->pol.dense3_mode = false; }
+    else if (n == "dense3") { h->pol.dense3_on = value != 0; h->pol.dense3_mode = false; }
+    else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
+    else if (n == "dense3_staged") h->pol.dense3_staged = value != 0;
+    else if (n == "fixup_mode") h->pol.fix_mode = value != 0;
+    else if (n == "dense_retry") { h->pol.dense_retry = value; h->pol.dense_skip = 0; h->pol.dense_backoff = 0; }
     else if (n == "envelope_mode") { h->flags_pending = false; h->force_env = value != 0 ? 1 : -1; }
     else if (n == "far_threshold_y") h->far_thr[0] = value;
     else if (n == "far_threshold_x") h->far_thr[1] = value;

@@ -154,3 +154,96 @@ def test_wide_ball_level_tables_and_plane_encoding():
         planes[2] = sum(U[l] for l in (3, 7, 11)) & 1
         planes[3] = U[7]
         assert planes[0] | planes[1] << 1 | planes[2] << 2 | planes[3] << 3 == c
+
+
+def _policy_lib():
+    import ctypes
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "policy_harness.cpp")
+    hdr = os.path.join(ROOT, "sdf_tools_amd", "csrc", "sdfgpu_policy.hpp")
+    out = os.path.join(here, "policy_harness.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-fPIC", "-shared", src, "-o", out])
+    L = ctypes.CDLL(out)
+    L.pol_new.restype = ctypes.c_void_p
+    L.pol_new.argtypes = [ctypes.c_int]
+    L.pol_free.argtypes = [ctypes.c_void_p]
+    L.pol_build.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 5
+    L.pol_report.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
+    L.pol_state.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.pol_remember.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4
+    return L
+
+
+DENSE, FIX, KD3, STAGED, TRUSTED = 1, 2, 4, 8, 16
+
+
+def test_dense_tier_policy_sequences_on_the_cpu():
+    """sdf_tools_amd/csrc/sdfgpu_policy.hpp compiled host-only and driven through the sequences the GPU tests can only reach by
+    building scenes: (a) ADVICE r3 -- a STAGED build that KD failed and the fix-up stage certified is a fix-up-mode report: the
+    cheap stand-by is earned with 4 such reports in a row and lost with the first failing seed; (b) a certified plain-KD scene
+    is trusted at once; (c) synchronised retries: pause 3, 7, 15 builds; (d) a caller that never synchronises (reports ~30
+    builds late) probes the dense tier ONCE per pause, not in every build until the report arrives."""
+    L = _policy_lib()
+
+    def build(h, vb=0, take=1):
+        return L.pol_build(h, 1, 0, 1, vb, take)
+
+    # (a) staged -> fix-up mode -> failing seed
+    h = L.pol_new(16)
+    assert build(h) == DENSE | STAGED                              # fresh handle: KD, the fix-up stage staged behind it
+    L.pol_report(h, 0, 1, 1)                                       # KD failed (word 8), KD3 + KF certified (word 3 clear)
+    assert L.pol_state(h, 0) == 1 and L.pol_state(h, 1) == 1 and L.pol_state(h, 4) == 0     # fix-up mode, trust 1, NOT yet trusted
+    for trust in (2, 3):
+        assert build(h) == DENSE | FIX | KD3
+        L.pol_report(h, 0, 1, 0)
+        assert L.pol_state(h, 1) == trust and L.pol_state(h, 4) == 0
+    assert build(h) == DENSE | FIX | KD3
+    L.pol_report(h, 0, 1, 0)
+    assert L.pol_state(h, 1) == 4 and L.pol_state(h, 4) == 1      # four certified reports in a row: trusted
+    assert build(h) == DENSE | FIX | KD3 | TRUSTED
+    L.pol_report(h, 1, 1, 0)                                       # the failing seed: KF could not certify it
+    assert L.pol_state(h, 1) == 0 and L.pol_state(h, 4) == 0 and L.pol_state(h, 0) == 0 and L.pol_state(h, 2) == 15
+    assert [build(h) for _ in range(15)] == [0] * 15               # paused
+    assert build(h) == DENSE | STAGED                              # the probe (fix-up mode was left: staged again)
+    assert L.pol_state(h, 2) == 15                                 # ... re-arms the pause at once
+    L.pol_free(h)
+    # (b) plain KD certifies: trusted at once, no fix-up stage
+    h = L.pol_new(16)
+    assert build(h) == DENSE | STAGED
+    L.pol_report(h, 0, 0, 0)
+    assert L.pol_state(h, 4) == 1 and L.pol_state(h, 0) == 0
+    assert build(h) == DENSE | TRUSTED
+    assert build(h, vb=1) == DENSE | TRUSTED
+    L.pol_free(h)
+    # (c) synchronised caller on a scene the tier cannot take (dense_retry = 4): 1, 3 skipped, 1, 7 skipped, 1, 15 skipped, 1
+    h = L.pol_new(4)
+    seq = []
+    for _ in range(1 + 3 + 1 + 7 + 1 + 15 + 1):
+        b = build(h)
+        seq.append(b & DENSE)
+        if b & DENSE:
+            L.pol_report(h, 1, 1, 1)
+    assert seq == [1] + [0] * 3 + [1] + [0] * 7 + [1] + [0] * 15 + [1]
+    L.pol_free(h)
+    # (d) asynchronous caller: a report arrives 30 builds after its build, one report outstanding at a time, and only builds
+    #     that carried the dense tier take the report slot (build_device_impl)
+    h = L.pol_new(16)
+    outstanding, attempts = None, []
+    for k in range(400):
+        if outstanding is not None and k - outstanding >= 30:
+            L.pol_report(h, 1, 1, 1)                               # a scene the tier cannot take: every verdict is a failure
+            outstanding = None
+        b = L.pol_build(h, 1, 0, 1, 0, 0)
+        if (b & DENSE) and outstanding is None:
+            # remember this build: repeat the bookkeeping build_device_impl does when it takes the report slot
+            L.pol_remember(h, 1, 0, 1 if (b & (FIX | KD3)) else 0, 1 if (b & STAGED) else 0)
+            outstanding = k
+        attempts.append(b & DENSE)
+    # the first 30 builds cannot know better; after the first failure report: one or two probes per pause, and the pauses grow
+    assert sum(attempts[:30]) == 30
+    later = attempts[30:]
+    assert sum(later) <= 8, sum(later)                             # (before: a probe in EVERY build between a pause's end and the report)
+    assert L.pol_state(h, 3) >= 63                                 # the back-off doubled: 15 -> 31 -> 63 ...
+    L.pol_free(h)
