@@ -372,7 +372,11 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * table between them and a probe of its own for the x axis), "probe_window" (1 = the tier probes are window statistics
  * over ~32 k sampled voxels, default; 0 = level A of the far-field search on sampled tiles), "y16" (1 = the y sweep of
  * the 16-bit pipeline through the packed 16-bit kernel, default; 0 = the 32-bit marching kernel), "z_wave" (1 = z sweep
- * with whole rows per wave where nz is 64 ... 1024 and a power of two, default; 0 = the workgroup form).  Every option leaves the results exact: switches that
+ * with whole rows per wave where nz is 64 ... 1024 and a power of two, default; 0 = the workgroup form), "standby_far" (1 = behind a
+ * dense tier the handle trusts, the guarded general pipeline is the far-field kernel pair -- two launches, bounded on any scene --
+ * default; 0 = the fused z+y sweep + the marching x sweep with unbounded scans), "standby_grid" (workgroups of those stand-by
+ * launches, default 1024), "expect_dense" (tests: 1 = put the handle into the "dense tier trusted" state for the next build).
+ * Every option leaves the results exact: switches that
  * skip work for profiling ("dc_debug", "ball_variant") exist only in libraries built with -DSDFGPU_DEBUG_HOOKS and are
  * rejected with SDFGPU_ERR_INVALID_ARGUMENT by the shipped one. */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
