@@ -103,6 +103,7 @@ struct sdfgpu_context {
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
+    int dc_debug_stage = 0;          // ... of this stage only (2 / 3; 0 = both)
     uint32_t* far_y = nullptr;       // set while a build enqueues a bounded K2 / K3
     int scan_y = kScanExpectNear, scan_x = kScanExpectNear;   // outward-scan bounds of the marching kernels
     bool fused_always = false;
@@ -476,7 +477,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         const bool loop = ex && ex->loop && !probe_out;
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
 #ifdef SDFGPU_DEBUG_HOOKS
-        a.dbg = h->dc_debug;
+        a.dbg = (h->dc_debug_stage == 0 || h->dc_debug_stage == stage) ? h->dc_debug : 0;    // (an ablated y sweep hands garbage to the x sweep: ablate one stage at a time)
 #endif
 #ifdef SDFGPU_PHASE_CLOCKS
         if (!h->d_clocks) { HIP_TRY(h, hipMalloc((void**)&h->d_clocks, 16 * 8)); HIP_TRY(h, hipMemset(h->d_clocks, 0, 16 * 8)); }
@@ -1879,6 +1880,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "envelope") h->envelope_on = value != 0;
     else if (n == "envelope_dc") h->envelope_dc = value != 0;
 #ifdef SDFGPU_DEBUG_HOOKS
+    else if (n == "dc_debug_stage") h->dc_debug_stage = value;
     else if (n == "dc_debug") h->dc_debug = value;              // profiling builds only: these skip work, results are then wrong
     else if (n == "ball_variant") h->ball_variant = value;
 #endif

@@ -230,9 +230,19 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
 // Profiling builds (-DSDFGPU_PHASE_CLOCKS, never the shipped library): shader-clock time per phase, summed over waves.
-#ifdef SDFGPU_PHASE_CLOCKS
+// With -DSDFGPU_TRIP_COUNTS on top, the same eight slots count trips of the scan loops instead: [2 l] = trips issued by the
+// waves (the slowest lane's), [2 l + 1] = trips the lanes needed, summed, for level l = 0 (A), 1 (B), 2 (C).
+#if defined(SDFGPU_PHASE_CLOCKS) && defined(SDFGPU_TRIP_COUNTS)
+#define DC_TRIP ++dbgt
+#define DC_STAMP(k) do { int mx_ = dbgt, sm_ = dbgt; \
+        for (int off_ = 32; off_ >= 1; off_ >>= 1) { mx_ = max(mx_, __shfl_xor(mx_, off_)); sm_ += __shfl_xor(sm_, off_); } \
+        if ((k) >= 1 && (k) <= 3) { clk[2 * ((k) - 1)] += (unsigned long long)mx_; clk[2 * ((k) - 1) + 1] += (unsigned long long)sm_; } \
+        dbgt = 0; (void)tprev; } while (0)
+#elif defined(SDFGPU_PHASE_CLOCKS)
+#define DC_TRIP do {} while (0)
 #define DC_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); clk[k] += now_ - tprev; tprev = now_; } while (0)
 #else
+#define DC_TRIP do {} while (0)
 #define DC_STAMP(k) do {} while (0)
 #endif
 
@@ -376,8 +386,9 @@ __global__ __launch_bounds__(256) void k_probe_window(const ProbeArgs a) {
 //
 // LOOP (round 4): the stand-by form behind a trusted dense tier.  Such a launch nearly always exits on its guard, and what a
 // guarded exit costs grows with the grid (1.7 us up to 2048 workgroups, 2.9 us at 8192, tools/probe/launch_probe.hip): the
-// LOOP form is launched with at most 2048 workgroups that take tiles blockIdx.x, + gridDim.x, ... -- static assignment,
-// a few % slower than one tile per workgroup when it does run (the build in which a scene leaves the dense tier).
+// LOOP form is launched with a small grid (option "standby_grid", 1024 workgroups = 4 per CU) whose workgroups take tiles
+// blockIdx.x, + gridDim.x, ... -- static assignment, a few % slower than one tile per workgroup when it does run (the build in
+// which a scene leaves the dense tier).
 template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines, bool LOOP = false>
 __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envelope_dc(const EnvDcArgs a) {
     constexpr int S = NT / NL;              // lanes per line
@@ -408,6 +419,8 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
     const int t = threadIdx.x;
 #ifdef SDFGPU_PHASE_CLOCKS
     unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    int dbgt = 0;
+    (void)dbgt;
 #endif
     if (a.ran_flag && blockIdx.x == 0 && t == 0) *a.ran_flag = 1u;
     int mxF = 0, mxQ = 0;
@@ -501,6 +514,74 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
             for (int k = 0; k < 8; ++k) best[k] = umin(best[k], umin(mad_i24(qc, nc[k], kk.x), mad_i24(qc1, nc[k], kk.y)));
             kp += step;
             qc += step;
+            DC_TRIP;
+        }
+    };
+
+    // The same scan under WAVE-UNIFORM control (round 4).  A wave issues a trip of the loop for all 64 lanes while any lane
+    // has candidates left, so the few long ranges of a tile -- the intervals in which the argmin jumps from one object to
+    // another: 1.4 % of the two-box scene's chunks hold a third of the useful trips -- used to cost every lane of their wave
+    // their full length.  The lanes of a wave are 4 rows of 16 (the tile's lines x 4 slots), and its units of work are groups
+    // of `urows` rows (a chunk of level C = one row; an interval of level B = Hs rows).  scan8_calm runs trips in the lanes,
+    // in blocks of 4, 8, 16, ..., until after a block at most `kmax` units are still active and one of them has 6 trips
+    // or more to go, and
+    // coop8 spreads the rest of each such unit over all 4 rows (every row takes every 4th pair of the unit's line), reduces
+    // the partial minima across the rows (16 ds_bpermute) and hands them to the unit's first row.  Exact for the same reason
+    // as any other split of a scan: the candidate set of a unit is unchanged.  Both are only entered by a wave that holds a
+    // long range at all (one ballot; noise-like scenes, whose ranges are all alike, take the plain scan8).
+    auto scan8_calm = [&](const uint32_t* kl, int& q, int qe, int step, const int (&nc)[8], uint32_t (&best)[8], auto urows_tag, int kmax) {
+        constexpr int urows = decltype(urows_tag)::value;
+        int qc = q - h, blk = 4 * step;
+        const uint32_t* kp = kl + q;
+        for (;;) {
+            const int qcap = imin(qe, q + blk - step);          // a block of trips (4, 8, 16, ...) in the lanes: the plain loop
+            for (; q <= qcap; q += step) {
+                const uint2 kk = *reinterpret_cast<const uint2*>(kp);
+                const int qc1 = qc + 1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) best[k] = umin(best[k], umin(mad_i24(qc, nc[k], kk.x), mad_i24(qc1, nc[k], kk.y)));
+                kp += step;
+                qc += step;
+                DC_TRIP;
+            }
+            const uint64_t act = __ballot(q <= qe);             // (wave-uniform from here)
+            if (act == 0ull) return;
+            if (__ballot(q + 5 * step <= qe) != 0ull) {         // somebody has 6 trips or more to go
+                const uint32_t alo = (uint32_t)act, ahi = (uint32_t)(act >> 32);
+                int units;
+                if constexpr (urows == 1) units = ((alo & 0xFFFFu) != 0) + ((alo >> 16) != 0) + ((ahi & 0xFFFFu) != 0) + ((ahi >> 16) != 0);
+                else units = (alo != 0) + (ahi != 0);
+                if (units <= kmax) return;
+            }
+            blk *= 2;
+        }
+    };
+    // pos_step: positions between the first positions of consecutive units (their multipliers differ by pos_step << (B + 1))
+    auto coop8 = [&](const uint32_t* kl, int& q, int qe, const int (&nc)[8], uint32_t (&best)[8], auto urows_tag, int pos_step) {
+        constexpr int urows = decltype(urows_tag)::value;
+        const int lane = t & 63, row = lane >> 4;
+        uint64_t act = __ballot(q <= qe);
+        while (act != 0ull) {                                   // (wave-uniform)
+            const int r0 = ((__ffsll((unsigned long long)act) - 1) >> 4) & ~(urows - 1);     // first row of the first active unit
+            const int src = (lane & 15) + 16 * r0;              // its lane of my line: the share that is furthest behind
+            const int bq = __shfl(q, src), bqe = __shfl(qe, src);
+            const int d = ((r0 - (row & ~(urows - 1))) / urows) * pos_step * (1 << (B + 1));
+            int ncb[8];
+            uint32_t hb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ncb[k] = nc[k] - d; hb[k] = 0xFFFFFFFFu; }
+            scan8(kl, bq + 2 * row, bqe, 8, ncb, hb);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                hb[k] = umin(hb[k], (uint32_t)__shfl_xor((int)hb[k], 16));
+                hb[k] = umin(hb[k], (uint32_t)__shfl_xor((int)hb[k], 32));
+            }
+            if (row == r0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) best[k] = umin(best[k], hb[k]);
+            }
+            if ((row & ~(urows - 1)) == r0) q = qe + 2;         // (this unit is done)
+            act &= ~((urows == 1 ? 0xFFFFull : 0xFFFFFFFFull) << (16 * r0));
         }
     };
 
@@ -690,6 +771,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                             best = umin(best, umin(mad_i24(qc, nc1, kk.x), mad_i24(qc + 1, nc1, kk.y)));
                             kp += 2 * G;
                             qc += 2 * G;
+                            DC_TRIP;
                         }
                         atomicMin(&args[(8 * i1) * NL + lineA], best);
                     }
@@ -731,10 +813,14 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                 int Hs = 1;                                     // lanes per interval (S slots per line)
                 while (2 * Hs * MA <= S) Hs *= 2;
                 const uint32_t* kl = keys + lineT * pitch;
-                for (int i = slotT / Hs; i < MA; i += S / Hs) {
+                const bool coop = NL == 16 && Hs <= 2;          // (block-uniform: 2 or 4 intervals per wave)
+                for (int ib = 0; ib < MA; ib += S / Hs) {
+                    const int i = ib + slotT / Hs;
+                    if (!coop && i >= MA) continue;
+                    const int ic = imin(i, MA - 1);             // (coop: lanes past the last interval stay in the wave with an empty range)
                     const int u = slotT % Hs;
-                    const int lo = (int)(args[(8 * i) * NL + lineT] & mask);
-                    const int hi = (i + 1 < MA) ? (int)(args[(8 * (i + 1)) * NL + lineT] & mask) : hi_t;
+                    const int lo = (int)(args[(8 * ic) * NL + lineT] & mask);
+                    const int hi = i >= MA ? -1 : (i + 1 < MA) ? (int)(args[(8 * (i + 1)) * NL + lineT] & mask) : hi_t;
                     int nc[8];
                     uint32_t best[8];
 #pragma unroll
@@ -742,7 +828,22 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                         nc[k] = ncof(64 * i + 8 * k);
                         best[k] = 0xFFFFFFFFu;
                     }
-                    scan8(kl, (lo & ~1) + 2 * u, hi, 2 * Hs, nc, best);
+#ifdef SDFGPU_DEBUG_HOOKS
+                    if (a.dbg & 16) continue;
+#endif
+                    if (coop && __ballot(hi - lo >= 108) != 0ull) {             // (an interval's range without a jump: <= 64 + noise)
+                        int q = (lo & ~1) + 2 * u;
+                        if (Hs == 1) {                          // (block-uniform)
+                            scan8_calm(kl, q, hi, 2, nc, best, std::integral_constant<int, 1>{}, 2);
+                            coop8(kl, q, hi, nc, best, std::integral_constant<int, 1>{}, 64);
+                        } else {
+                            scan8_calm(kl, q, hi, 4, nc, best, std::integral_constant<int, 2>{}, 1);
+                            coop8(kl, q, hi, nc, best, std::integral_constant<int, 2>{}, 64);
+                        }
+                        if (i >= MA) continue;
+                    } else {
+                        scan8(kl, (lo & ~1) + 2 * u, hi, 2 * Hs, nc, best);
+                    }
 #pragma unroll
                     for (int k = 1; k < 8; ++k)
                         if (8 * i + k < M) atomicMin(&args[(8 * i + k) * NL + lineT], best[k]);
@@ -761,12 +862,14 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
             const uint32_t* kl = keys + lineT * pitch;
             for (int i0 = 0; i0 < M; i0 += S) {
                 const int i = i0 + slotT;
-                if (i >= M || !lineT_ok) continue;
+                const bool mine = i < M && lineT_ok;
+                if (NL != 16 && !mine) continue;                // (16-line tiles: the lane stays in its wave with an empty range)
                 const int p0 = 8 * i;
                 int D[8];
                 if (act) {
-                    const int a0 = (int)(args[i * NL + lineT] & mask);
-                    const int a8 = (i + 1 < M) ? (int)(args[(i + 1) * NL + lineT] & mask) : hi_t;
+                    const int ic = imin(i, M - 1);
+                    const int a0 = (int)(args[ic * NL + lineT] & mask);
+                    const int a8 = !mine ? -1 : (i + 1 < M) ? (int)(args[(i + 1) * NL + lineT] & mask) : hi_t;
                     int nc[8];
                     uint32_t best[8];
 #pragma unroll
@@ -775,7 +878,17 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                         best[k] = 0xFFFFFFFFu;
                     }
                     DC_STAMP(4);
-                    scan8(kl, a0 & ~1, a8, 2, nc, best);
+#ifdef SDFGPU_DEBUG_HOOKS
+                    if (a.dbg & 8) {}                           // profiling builds: bit 3 = no level-C scan, bit 4 = no level-B scan (use with bit 3)
+                    else
+#endif
+                    if (NL == 16 && __ballot(a8 - a0 >= 34) != 0ull) {          // (a chunk's range without a jump: <= 8 + noise)
+                        int q = a0 & ~1;
+                        scan8_calm(kl, q, a8, 2, nc, best, std::integral_constant<int, 1>{}, 2);
+                        coop8(kl, q, a8, nc, best, std::integral_constant<int, 1>{}, 8);
+                    } else {
+                        scan8(kl, a0 & ~1, a8, 2, nc, best);
+                    }
                     DC_STAMP(3);
                     // D = (best >> B) - (h^2 - p'^2), h^2 - p'^2 = p (2 h - p): a running value, + (2 h - 2 p - 1) per position
                     uint32_t hp = __umul24((uint32_t)p0, (uint32_t)(2 * h - p0));
@@ -790,6 +903,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
 #pragma unroll
                     for (int k = 0; k < 8; ++k) D[k] = kInf32;
                 }
+                if (!mine) continue;
                 // positions past the end of the line count as "not mine" (D = 0).  Pass 0: a voxel is filled iff its distance
                 // to the nearest filled voxel is 0; pass 1: free iff its distance to the nearest free voxel is 0 -- so in
                 // both passes the voxels this pass must write are exactly those with D != 0.
@@ -851,10 +965,11 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         mx = imax(mx, D[k]);
-                        float f = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);                 // (D = 0: not stored)
 #ifdef SDFGPU_DEBUG_HOOKS
-                        if (a.dbg & 2) f = (float)D[k];
+                        float f = (a.dbg & 2) ? (float)D[k] : (float)(sqrt_exact_pos((double)D[k]) * a.resolution);
                         if ((a.dbg & 4) && (k || slotT)) { bo += 4u * ls; continue; }
+#else
+                        float f = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);                 // (D = 0: not stored)
 #endif
                         f = D[k] >= kInf32 ? __builtin_inff() : f;
                         if (D[k] != 0) *reinterpret_cast<float*>(op + bo) = cls == 1 ? -f : f;
@@ -900,7 +1015,11 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
     if (second) run_pass(std::integral_constant<int, 1>{});
 
 #ifdef SDFGPU_PHASE_CLOCKS
-    if (a.clocks && (t & 63) == 0 && !probe && (blockIdx.x & 31u) == 5u) {     // a sample: same-address atomics serialise
+#ifdef SDFGPU_TRIP_COUNTS
+    if (a.clocks && (t & 63) == 0 && !probe) {
+#else
+    if (a.clocks && (t & 63) == 0 && !probe && ((blockIdx.x * 2654435761u) >> 27) == 5u) {     // a sample (hashed: consecutive workgroups are consecutive tiles of a row): same-address atomics serialise
+#endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(a.clocks + (STAGE - 2) * 8 + k, clk[k]);
     }

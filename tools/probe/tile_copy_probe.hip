@@ -10,7 +10,7 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s\n", hipGetErrorString(e), #x); exit(1); } } while (0)
 
-template <int NLN, int NT, int STORE>      // STORE 0: chunk mapping (lane = line, slot of 8 positions); 1: row mapping; 2: chunk mapping, input TILE-MAJOR (a tile's rows contiguous)
+template <int NLN, int NT, int STORE, int MODE = 0>      // MODE 0: load + store, 1: loads only (one value per lane stored at the end... of every 4096th workgroup), 2: stores only.  STORE 0: chunk mapping (lane = line, slot of 8 positions); 1: row mapping; 2: chunk mapping, input TILE-MAJOR (a tile's rows contiguous)
 __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* __restrict__ out, int L, uint32_t ls, int xcd_order, uint32_t pad_in = 0, uint32_t pad_out = 0) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int pitch = L + 2;
@@ -29,6 +29,8 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
     constexpr int PP = NT / LPR;            // rows per load round
     const int sub = t % LPR, r = t / LPR;
     constexpr int NB = 8;
+    int acc = 0;
+    if (MODE != 2)
     for (int pb = 0; pb < L; pb += PP * NB) {
         int4 v[NB];
 #pragma unroll
@@ -42,10 +44,12 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
             if (p < L) {
                 smem[(4 * sub + 0) * pitch + p] = v[it].x; smem[(4 * sub + 1) * pitch + p] = v[it].y;
                 smem[(4 * sub + 2) * pitch + p] = v[it].z; smem[(4 * sub + 3) * pitch + p] = v[it].w;
+                acc += v[it].x ^ v[it].y ^ v[it].z ^ v[it].w;
             }
         }
     }
     __syncthreads();
+    if (MODE == 1) { if (acc == 0x12345678) op[t] = 1.0f; return; }
     if (STORE == 0 || STORE == 2) {
         const int line = t % NLN, slot = t / NLN;
         constexpr int S = NT / NLN;
@@ -61,17 +65,17 @@ __global__ __launch_bounds__(NT) void k_tile(const int* __restrict__ in, float* 
     }
 }
 
-template <int NLN, int NT, int STORE>
+template <int NLN, int NT, int STORE, int MODE = 0>
 float run(const int* in, float* out, int n, int xcd, uint32_t pad_in = 0, uint32_t pad_out = 0) {
     const int L = n;
     const uint32_t ls = (uint32_t)n * n;
     const unsigned ntiles = (unsigned)((int64_t)n * n / NLN);
     const size_t lds = (size_t)NLN * (L + 2) * 4;
-    CK(hipFuncSetAttribute((const void*)k_tile<NLN, NT, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_tile<NLN, NT, STORE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd, pad_in, pad_out);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE, MODE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd, pad_in, pad_out);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd, pad_in, pad_out);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_tile<NLN, NT, STORE, MODE>), dim3(ntiles), dim3(NT), lds, 0, in, out, L, ls, xcd, pad_in, pad_out);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / 10;
@@ -99,6 +103,11 @@ int main() {
     for (uint32_t pad : {0u, 16u, 64u, 1024u, 4096u + 64u}) {
         printf("pad %u elements: in only %.4f ms, in + out %.4f ms (16 lines x 256 lanes, chunk stores)\n", pad, run<16, 256, 0>(in, out, n, 1, pad, 0), run<16, 256, 0>(in, out, n, 1, pad, pad));
     }
+    // round 4: the two sides on their own (the x sweep without its search takes 0.35 ms: 0.19 without its stores)
+    printf("loads only:  16 lines natural %.4f ms, plane stride + 4160 %.4f ms, tile-major %.4f ms; 32 lines %.4f ms; 64 lines %.4f ms\n",
+           run<16, 256, 0, 1>(in, out, n, 1), run<16, 256, 0, 1>(in, out, n, 1, 4160, 0), run<16, 256, 2, 1>(in, out, n, 1), run<32, 512, 0, 1>(in, out, n, 1), run<64, 1024, 0, 1>(in, out, n, 1));
+    printf("stores only: 16 lines chunk mapping %.4f ms, plane stride + 4160 %.4f ms, row mapping %.4f ms; 32 lines chunk %.4f ms, row %.4f ms; 64 lines chunk %.4f ms\n",
+           run<16, 256, 0, 2>(in, out, n, 1), run<16, 256, 0, 2>(in, out, n, 1, 0, 4160), run<16, 256, 1, 2>(in, out, n, 1), run<32, 512, 0, 2>(in, out, n, 1), run<32, 512, 1, 2>(in, out, n, 1), run<64, 1024, 0, 2>(in, out, n, 1));
     for (int xcd = 1; xcd >= 1; --xcd) {
         printf("xcd_order=%d\n", xcd);
         printf("  16 lines x 256 lanes, chunk stores: %.4f ms\n", run<16, 256, 0>(in, out, n, xcd));
