@@ -204,7 +204,7 @@ def test_envelope_rare_paths_deep_pops_and_dense_advances(gpu):
 
 
 DC_SHAPES = [(40, 100, 48), (1024, 4, 16), (7, 1024, 16), (512, 8, 32), (13, 9, 16), (2, 3, 16), (1, 1, 64), (24, 520, 32),
-             (65, 63, 80), (16, 16, 20)]
+             (65, 63, 80), (16, 16, 20), (520, 6, 16), (1000, 3, 32), (3, 700, 16)]
 
 
 @pytest.mark.parametrize("shape", DC_SHAPES, ids=["x".join(map(str, s)) for s in DC_SHAPES])
@@ -227,6 +227,19 @@ def test_divide_and_conquer_envelope_kernel_is_exact(gpu, shape):
         "all filled": np.ones(shape, np.uint8),
         "half dense": np.concatenate([synth.bernoulli_mask((nx, ny, nz - nz // 2), 0.4, 9), np.zeros((nx, ny, nz // 2), np.uint8)], axis=2),
     }
+    # noisy sheets near both ends of the x and the y lines, nothing in between: the argmin of every long line jumps from one
+    # sheet to the other -- the ranges that levels B and C spread over their wave (round 4: scan8_calm / coop8, with one
+    # interval per lane for lines above 512 and two lanes per interval below)
+    sheets = np.zeros(shape, np.uint8)
+    for ax, n_ax in ((0, nx), (1, ny)):
+        if n_ax < 64 and max(nx, ny) >= 64:                     # (sheets across the LONG lines only, or they fill each other's gaps)
+            continue
+        for pos in {min(5, n_ax - 1), max(n_ax - 6, 0), n_ax // 3}:
+            sl = [slice(None)] * 3
+            sl[ax] = pos
+            sheets[tuple(sl)] |= (rng.random(sheets[tuple(sl)].shape) < 0.08).astype(np.uint8)
+    scenes_["sheets"] = sheets
+    scenes_["inverse sheets"] = 1 - sheets
     hgt = (rng.random((nx, ny)) * nz * 0.8).astype(int)
     scenes_["height field"] = (np.arange(nz)[None, None, :] >= hgt[:, :, None]).astype(np.uint8)
     try:

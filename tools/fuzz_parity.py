@@ -27,6 +27,9 @@ while time.time() - t0 < budget:
         shape = shape[:2] + (int(rng.choice([32, 64, 128, 256])),)        # dense-path eligible z extents
     if rng.random() < 0.08:                                              # wide rows: other tile shapes / expansion paths
         shape = (int(rng.choice([1, 2, 5, 9, 17])), int(rng.choice([1, 3, 8, 20])), int(rng.choice([512, 1024, 2048])))
+    if rng.random() < 0.08:                                              # long x / y lines: the far-field kernel's levels with one interval
+        a, b = int(rng.choice([300, 512, 520, 777, 1024])), int(rng.choice([1, 2, 5, 9]))     # per lane (> 512) / two lanes per interval, wave-cooperative scans
+        shape = ((a, b) if rng.random() < 0.5 else (b, a)) + (int(rng.choice([16, 32, 64])),)
     if np.prod(shape) > 1 << 21:
         continue
     kind = rng.integers(0, 4)
