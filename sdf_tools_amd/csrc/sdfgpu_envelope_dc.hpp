@@ -58,7 +58,9 @@ namespace sdfgpu {
 // scenes (p = 0.01: distances up to ~30) never pay for a far-field pass they do not need.
 constexpr int kScanExpectNear = 40;
 
-constexpr int kDcLocalMax = 64;       // pass 0 finishes filled voxels whose in-row squared distance is at most this ...
+constexpr int kDcLocalSat = 255;      // pass 0 finishes a filled voxel itself when its result is below this: its own in-row squared distance or a free
+                                      // voxel within 15 positions along the line (round 4: the bound used to be on the in-row distance alone, 64 --
+                                      // a wall or a floor a few voxels thick, whose in-row distance is "none", sent every tile to the second pass) ...
 constexpr int kDcLocalFilled = 448;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second pass costs as much
                                       // as the first: a 3 %-occupied 512^3 scene has 245 per tile and must stay below)
 
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                             uint32_t S = (uint32_t)(-s1);       // squared distance to the nearest free voxel so far
                             if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
                             const uint32_t e = atomicAdd(&misc[24], 1u);
-                            if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | umin(S, 255u);
+                            if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | umin(S, (uint32_t)kDcLocalSat);
                         }
                     }
                 }
@@ -990,12 +992,21 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                     for (uint32_t e = (uint32_t)t; e < nf; e += (uint32_t)NT) {
                         const uint32_t ent = flist[e];
                         const int fl = (int)(ent >> 24), p = (int)((ent >> 8) & 0xffffu);
-                        int D1 = (int)(ent & 0xffu);
-                        if (D1 > kDcLocalMax) { misc[25] = 1u; continue; }
-                        for (int d = 1; (int)__umul24(d, d) < D1; ++d) {
-                            if (p - d >= 0) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p - d), 0));
-                            if (p + d < L) D1 = imin(D1, (int)__umul24(d, d) + imax(-raw_signed(fl, p + d), 0));
+                        int D1 = (int)(ent & 0xffu);            // (saturated at kDcLocalSat: then only a candidate found below can finish the voxel)
+                        // offsets in rounds of 4 (8 loads in flight; D1 <= 255: at most 4 rounds).  A candidate beyond the bound that
+                        // rides along in a round is still a candidate: harmless.
+                        for (int d0 = 1; (int)__umul24(d0, d0) < D1; d0 += 4) {
+                            int v[8];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int d = d0 + j;
+                                v[2 * j] = p - d >= 0 ? imax(-raw_signed(fl, p - d), 0) : (1 << 28);
+                                v[2 * j + 1] = p + d < L ? imax(-raw_signed(fl, p + d), 0) : (1 << 28);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) D1 = imin(D1, (int)__umul24(d0 + j, d0 + j) + imin(v[2 * j], v[2 * j + 1]));
                         }
+                        if (D1 >= kDcLocalSat) { misc[25] = 1u; continue; }      // deep inside a solid: the second pass
                         emit_filled((uint32_t)fl + (uint32_t)p * ls, p, D1, byz_of(fl));
                     }
                 }

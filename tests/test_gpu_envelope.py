@@ -238,6 +238,14 @@ def test_divide_and_conquer_envelope_kernel_is_exact(gpu, shape):
             sl = [slice(None)] * 3
             sl[ax] = pos
             sheets[tuple(sl)] |= (rng.random(sheets[tuple(sl)].shape) < 0.08).astype(np.uint8)
+    # walls and a floor a few voxels thick (their voxels have NO free voxel in their own row / plane: pass 0 of the kernel finishes them
+    # with its local search along the line -- up to 15 positions -- instead of sending the tile to the second pass), and a slab too thick for it
+    walls = np.zeros(shape, np.uint8)
+    walls[:min(10, max(nx // 3, 1))] = 1
+    walls[:, :min(7, max(ny // 3, 1))] = 1
+    walls[:, :, :3] = 1
+    walls[nx // 2:nx // 2 + 40, ny // 2:, nz // 2:] = 1
+    scenes_["walls"] = walls
     scenes_["sheets"] = sheets
     scenes_["inverse sheets"] = 1 - sheets
     hgt = (rng.random((nx, ny)) * nz * 0.8).astype(int)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Build times of a few structured 512^3 scenes (solid obstacles in free space -- what CollisionMapGrid callers hold --
+next to the synthetic ones of bench.py) with the library's own tier selection: ms per build after warm-up, the path the
+handle reports, per-stage HIP-event times.  usage: scene_bench.py [n = 512] [name=value ...]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from sdf_tools_amd import capi  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
+opts = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
+res = 0.01
+dev = torch.device("cuda", 0)
+ctx = capi.SdfGpu(0)
+s = torch.cuda.current_stream().cuda_stream
+
+
+def boxes(solid):
+    """The two boxes of the reference's tutorial / demo scripts scaled to the grid (src/sdf_tools_tutorial.cpp:23-59), solid or as shells."""
+    m = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
+    for (x0, x1, y0, y1, z0, z1) in ((0.5, 0.7, 0.5, 0.6, 0.0, 0.5), (0.5, 0.75, 0.2, 0.4, 0.25, 0.5)):
+        a = [int(v * n) for v in (x0, x1, y0, y1, z0, z1)]
+        m[a[0]:a[1], a[2]:a[3], a[4]:a[5]] = 1
+        if not solid:
+            m[a[0] + 1:a[1] - 1, a[2] + 1:a[3] - 1, a[4] + 1:a[5] - 1] = 0
+    return m
+
+
+def room(floor=True, xwall=True, ywall=True):
+    """A room: floor, two walls, a table top on four legs, a shelf -- thin and thick solids, most of the volume free."""
+    m = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
+    f = lambda v: int(v * n)
+    if floor:
+        m[:, :, :f(0.02)] = 1
+    if xwall:
+        m[:f(0.02), :, :] = 1
+    if ywall:
+        m[:, :f(0.02), :] = 1
+    m[f(0.3):f(0.7), f(0.3):f(0.6), f(0.35):f(0.38)] = 1
+    for (x, y) in ((0.31, 0.31), (0.68, 0.31), (0.31, 0.58), (0.68, 0.58)):
+        m[f(x):f(x) + f(0.02), f(y):f(y) + f(0.02), :f(0.35)] = 1
+    m[f(0.8):f(0.98), f(0.1):f(0.9), f(0.5):f(0.55)] = 1
+    return m
+
+
+def spheres():
+    g = torch.arange(n, device=dev, dtype=torch.float32)
+    X, Y, Z = torch.meshgrid(g, g, g, indexing="ij")
+    m = torch.zeros((n, n, n), dtype=torch.bool, device=dev)
+    for (cx, cy, cz, r) in ((0.3, 0.3, 0.3, 0.12), (0.7, 0.6, 0.4, 0.2), (0.5, 0.8, 0.8, 0.08)):
+        m |= (X - cx * n) ** 2 + (Y - cy * n) ** 2 + (Z - cz * n) ** 2 <= (r * n) ** 2
+    return m.to(torch.uint8)
+
+
+out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
+names = ["pack_bits", "dense_ball", "sweep_z", "sweep_y", "envelope_y", "sweep_x", "envelope_x"]
+result = {}
+SCENES = [("solid boxes", lambda: boxes(True)), ("box shells", lambda: boxes(False)), ("room", room), ("solid spheres", spheres)]
+if "--room-variants" in sys.argv:
+    SCENES = [("room", room), ("room, no x wall", lambda: room(xwall=False)), ("room, no y wall", lambda: room(ywall=False)),
+              ("room, no floor", lambda: room(floor=False)), ("furniture only", lambda: room(False, False, False))]
+for name, mk in SCENES:
+    mask = mk()
+    ctx.set_option("policy_reset", 1)
+    for kv in opts:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ctx.build_device(mask.data_ptr(), (n, n, n), out.data_ptr(), res, False, s)
+    e1.record()
+    torch.cuda.synchronize()
+    first = e0.elapsed_time(e1)
+    for _ in range(4):
+        ctx.build_device(mask.data_ptr(), (n, n, n), out.data_ptr(), res, False, s)
+        torch.cuda.synchronize()
+    ctx.get_stage_times()
+    B = 10
+    e0.record()
+    for _ in range(B):
+        ctx.build_device(mask.data_ptr(), (n, n, n), out.data_ptr(), res, False, s)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / B
+    ctx.set_profiling(1)
+    for _ in range(4):
+        ctx.build_device(mask.data_ptr(), (n, n, n), out.data_ptr(), res, False, s)
+    torch.cuda.synchronize()
+    st, b = ctx.get_stage_times()
+    ctx.set_profiling(0)
+    p = ctx.last_path()
+    result[name] = {"filled_fraction": round(float(mask.float().mean().item()), 4), "first_build_ms": round(first, 3), "ms_per_build": round(ms, 3),
+                    "path": {k: p[k] for k in ("dense_certified", "far_y", "far_x")},
+                    "stages_ms": {k: round(v / max(b, 1), 3) for k, v in zip(names, st) if v > 0}, "extrema": ctx.get_extrema()}
+    print(json.dumps({name: result[name]}), flush=True)

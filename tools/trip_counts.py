@@ -21,6 +21,13 @@ if kind == "stream":
     pts = torch.from_numpy(synth.two_box_points(200000, seed=0, scale=n * res)).to(dev)
     mask = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
     ctx.voxelize_points_device(pts.data_ptr(), pts.shape[0], (0.0, 0.0, 0.0), res, (n, n, n), mask.data_ptr(), True, s)
+elif kind == "furniture":                 # tools/scene_bench.py's table, legs and shelf without the room around them
+    mask = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
+    f = lambda v: int(v * n)
+    mask[f(0.3):f(0.7), f(0.3):f(0.6), f(0.35):f(0.38)] = 1
+    for (x, y) in ((0.31, 0.31), (0.68, 0.31), (0.31, 0.58), (0.68, 0.58)):
+        mask[f(x):f(x) + f(0.02), f(y):f(y) + f(0.02), :f(0.35)] = 1
+    mask[f(0.8):f(0.98), f(0.1):f(0.9), f(0.5):f(0.55)] = 1
 else:
     mask = synth.bernoulli_mask_torch((n, n, n), float(kind), 1, device=dev)
 out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
