@@ -615,6 +615,13 @@ def main():
                 torch, capi, dev, shape, res, mid, {}, leg_steps, 20,
                 "%dx%dx%d Bernoulli(p=0.03), 2 grids in rotation, default policy (the dense tier's wide form KD3 + fix-up kernel)" % shape)
             del mid
+            # a structured scene of the kind CollisionMapGrid callers hold (solid obstacles in free space: floor, walls, a table,
+            # a shelf): far-field pair, thin and thick solids
+            room = [synth.room_mask_torch(shape, dev)]
+            legs["structured_room"] = run_leg(
+                torch, capi, dev, shape, res, room, {}, leg_steps, 10,
+                "%dx%dx%d room scene (floor + two walls 2 %% of the grid thick, table on legs, shelf; 6.9 %% filled), default policy" % shape)
+            del room
             if shape == (512, 512, 512):
                 legs["streaming_two_box"] = streaming_leg(torch, dev, 512, 0.01, 30)
             # BASELINE.json configs[1] / BASELINE.md section 3: 256^3, fp32 distances, single MI355X -- "throughput reported"

@@ -97,3 +97,37 @@ def two_box_points(n_points, seed=0, lo=(0.0, 0.0, 0.0), scale=1.0):
     a = rng.uniform([0.2, 0.2, 0.0], [0.5, 0.4, 0.3], size=(half, 3))
     b = rng.uniform([0.6, 0.5, 0.0], [0.8, 0.7, 0.5], size=(n_points - half, 3))
     return (np.concatenate([a, b]) * scale + np.asarray(lo)).astype(np.float32)
+
+
+def room_mask_torch(shape, device="cuda", floor=True, xwall=True, ywall=True):
+    """A structured scene of the kind CollisionMapGrid callers hold (solid obstacles, most of the volume free): floor and
+    two walls 2 % of the grid thick, a table top on four legs, a shelf.  Far-field everywhere, with thin, thick and
+    perpendicular solids (bench.py's `structured_room` leg, tools/scene_bench.py)."""
+    import torch
+    nx, ny, nz = shape
+    m = torch.zeros(shape, dtype=torch.uint8, device=device)
+    fx, fy, fz = (lambda v: int(v * nx)), (lambda v: int(v * ny)), (lambda v: int(v * nz))
+    if floor:
+        m[:, :, :max(fz(0.02), 1)] = 1
+    if xwall:
+        m[:max(fx(0.02), 1), :, :] = 1
+    if ywall:
+        m[:, :max(fy(0.02), 1), :] = 1
+    m[fx(0.3):fx(0.7), fy(0.3):fy(0.6), fz(0.35):fz(0.38)] = 1
+    for (x, y) in ((0.31, 0.31), (0.68, 0.31), (0.31, 0.58), (0.68, 0.58)):
+        m[fx(x):fx(x) + max(fx(0.02), 1), fy(y):fy(y) + max(fy(0.02), 1), :fz(0.35)] = 1
+    m[fx(0.8):fx(0.98), fy(0.1):fy(0.9), fz(0.5):fz(0.55)] = 1
+    return m
+
+
+def tutorial_boxes_mask_torch(shape, device="cuda", solid=True):
+    """The two boxes of the reference's tutorial (src/sdf_tools_tutorial.cpp:23-59) scaled to the grid, solid or as shells."""
+    import torch
+    nx, ny, nz = shape
+    m = torch.zeros(shape, dtype=torch.uint8, device=device)
+    for (x0, x1, y0, y1, z0, z1) in ((0.5, 0.7, 0.5, 0.6, 0.0, 0.5), (0.5, 0.75, 0.2, 0.4, 0.25, 0.5)):
+        a = [int(x0 * nx), int(x1 * nx), int(y0 * ny), int(y1 * ny), int(z0 * nz), int(z1 * nz)]
+        m[a[0]:a[1], a[2]:a[3], a[4]:a[5]] = 1
+        if not solid:
+            m[a[0] + 1:a[1] - 1, a[2] + 1:a[3] - 1, a[4] + 1:a[5] - 1] = 0
+    return m

@@ -37,6 +37,11 @@ CASES = [
     ("convex-segments scene 100x100x50, dense tier off", scenes.convex_segments_scene()[0], False),
     ("two boxes 1x100x50", _two_boxes((1, 100, 50)), True),
     ("single voxel 3x9x1100 (1100-voxel lines)", scenes.single_voxel((3, 9, 1100), (1, 2, 1000)), False),
+    # bench.py's structured leg at test size: floor, walls, table, shelf -- and the reference tutorial's solid boxes and their shells
+    ("room 160x128x96", synth.room_mask_torch((160, 128, 96), "cpu").numpy(), False),
+    ("room 160x128x96 vb", synth.room_mask_torch((160, 128, 96), "cpu").numpy(), True),
+    ("tutorial boxes 128^3, solid", synth.tutorial_boxes_mask_torch((128, 128, 128), "cpu", True).numpy(), False),
+    ("tutorial boxes 128^3, shells", synth.tutorial_boxes_mask_torch((128, 128, 128), "cpu", False).numpy(), False),
 ]
 
 

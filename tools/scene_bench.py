@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from sdf_tools_amd import capi  # noqa: E402
+from sdf_tools_amd import capi, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
 opts = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
@@ -20,31 +20,11 @@ s = torch.cuda.current_stream().cuda_stream
 
 
 def boxes(solid):
-    """The two boxes of the reference's tutorial / demo scripts scaled to the grid (src/sdf_tools_tutorial.cpp:23-59), solid or as shells."""
-    m = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
-    for (x0, x1, y0, y1, z0, z1) in ((0.5, 0.7, 0.5, 0.6, 0.0, 0.5), (0.5, 0.75, 0.2, 0.4, 0.25, 0.5)):
-        a = [int(v * n) for v in (x0, x1, y0, y1, z0, z1)]
-        m[a[0]:a[1], a[2]:a[3], a[4]:a[5]] = 1
-        if not solid:
-            m[a[0] + 1:a[1] - 1, a[2] + 1:a[3] - 1, a[4] + 1:a[5] - 1] = 0
-    return m
+    return synth.tutorial_boxes_mask_torch((n, n, n), dev, solid)
 
 
 def room(floor=True, xwall=True, ywall=True):
-    """A room: floor, two walls, a table top on four legs, a shelf -- thin and thick solids, most of the volume free."""
-    m = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
-    f = lambda v: int(v * n)
-    if floor:
-        m[:, :, :f(0.02)] = 1
-    if xwall:
-        m[:f(0.02), :, :] = 1
-    if ywall:
-        m[:, :f(0.02), :] = 1
-    m[f(0.3):f(0.7), f(0.3):f(0.6), f(0.35):f(0.38)] = 1
-    for (x, y) in ((0.31, 0.31), (0.68, 0.31), (0.31, 0.58), (0.68, 0.58)):
-        m[f(x):f(x) + f(0.02), f(y):f(y) + f(0.02), :f(0.35)] = 1
-    m[f(0.8):f(0.98), f(0.1):f(0.9), f(0.5):f(0.55)] = 1
-    return m
+    return synth.room_mask_torch((n, n, n), dev, floor, xwall, ywall)
 
 
 def spheres():
