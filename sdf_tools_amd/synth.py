@@ -131,3 +131,17 @@ def tutorial_boxes_mask_torch(shape, device="cuda", solid=True):
         if not solid:
             m[a[0] + 1:a[1] - 1, a[2] + 1:a[3] - 1, a[4] + 1:a[5] - 1] = 0
     return m
+
+
+def solid_spheres_mask_torch(shape, device="cuda"):
+    """Three solid spheres (radii 12 %, 20 %, 8 % of the grid): thick solids whose interiors need the far-field kernel's second pass."""
+    import torch
+    nx, ny, nz = shape
+    X = torch.arange(nx, device=device, dtype=torch.float32)[:, None, None]
+    Y = torch.arange(ny, device=device, dtype=torch.float32)[None, :, None]
+    Z = torch.arange(nz, device=device, dtype=torch.float32)[None, None, :]
+    m = torch.zeros(shape, dtype=torch.bool, device=device)
+    n = float(min(shape))
+    for (cx, cy, cz, r) in ((0.3, 0.3, 0.3, 0.12), (0.7, 0.6, 0.4, 0.2), (0.5, 0.8, 0.8, 0.08)):
+        m |= (X - cx * nx) ** 2 + (Y - cy * ny) ** 2 + (Z - cz * nz) ** 2 <= (r * n) ** 2
+    return m.to(torch.uint8)

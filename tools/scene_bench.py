@@ -28,12 +28,7 @@ def room(floor=True, xwall=True, ywall=True):
 
 
 def spheres():
-    g = torch.arange(n, device=dev, dtype=torch.float32)
-    X, Y, Z = torch.meshgrid(g, g, g, indexing="ij")
-    m = torch.zeros((n, n, n), dtype=torch.bool, device=dev)
-    for (cx, cy, cz, r) in ((0.3, 0.3, 0.3, 0.12), (0.7, 0.6, 0.4, 0.2), (0.5, 0.8, 0.8, 0.08)):
-        m |= (X - cx * n) ** 2 + (Y - cy * n) ** 2 + (Z - cz * n) ** 2 <= (r * n) ** 2
-    return m.to(torch.uint8)
+    return synth.solid_spheres_mask_torch((n, n, n), dev)
 
 
 out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
