@@ -925,12 +925,22 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                 }
                 if constexpr (STAGE == 2) {
                     if (out32) {
-                        char* const op = reinterpret_cast<char*>(a.out_i32 + base);      // (uniform base + 32-bit byte offset)
-                        uint32_t bo = ob * 4u;
+                        char* op = reinterpret_cast<char*>(a.out_i32 + base);      // (uniform base + 32-bit byte offset)
+                        uint32_t bo = ob * 4u, bstep = 4u * ls;
+#ifdef SDFGPU_DEBUG_HOOKS
+                        if (a.dbg & 32) {                       // profiling builds: bit 5 = the tile's stores to ONE contiguous 16 x L block (wrong results)
+                            op = reinterpret_cast<char*>(a.out_i32 + ((((c0 >> 4) * a.nx + o) * (int64_t)L) << 4));
+                            bo = ((uint32_t)lineT + (uint32_t)p0 * 16u) * 4u;
+                            bstep = 64u;
+                        }
+#endif
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
+#ifdef SDFGPU_DEBUG_HOOKS
+                            if ((a.dbg & 4) && (k || slotT)) { bo += bstep; continue; }
+#endif
                             if (D[k] != 0) *reinterpret_cast<int32_t*>(op + bo) = cls == 1 ? -D[k] : D[k];
-                            bo += 4u * ls;
+                            bo += bstep;
                         }
                     } else {
                         // side-table convention (sdfgpu_sweep_x16.hpp): if ANY voxel of a group of 4 is saturated, the exact
