@@ -117,7 +117,18 @@ def test_far_field_schedule_model_is_exact():
         finf = max([v for v in F if v < model.INF] + [0]) + (L - 1) ** 2 + 1
         got, _ = model.dc_line(F, finf)
         assert got == model.brute(F), (trial, L, kind)
-        model.check_line(rng, F)                                    # again with a looser span / bound and a forced level-A form
+        model.check_line(rng, F)                                    # again with a looser span / bound, a forced level-A form, and
+                                                                    # (round 4) long ranges split over the wave's rows at scaled-down thresholds
+    # the wave-cooperative scans of levels B and C at the kernel's own thresholds: sites at both ends of the line only, so that
+    # the argmin jumps across the whole line -- the hand-over (at a random block) must see the plain scan's candidate set
+    for L in (300, 512):
+        for seed in range(6):
+            F = [model.INF] * L
+            for q in list(range(0, 9)) + list(range(L - 9, L)):
+                F[q] = rng.randrange(0, 60)
+            finf = 60 + (L - 1) ** 2 + 1
+            got, _ = model.dc_line(F, finf, coop_rng=random.Random(seed), coop_scale=1)
+            assert got == model.brute(F), (L, seed)
 
 
 def test_wide_ball_level_tables_and_plane_encoding():

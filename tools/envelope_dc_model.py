@@ -19,7 +19,7 @@ def f32(x):
     return struct.unpack("f", struct.pack("f", float(x)))[0]
 
 
-def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None):
+def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=None, coop_scale=1):
     """F: site values (INF = no site).  lo_t / hi_t: span handed to the line (a superset of its sites), mt_t: a lower bound
     of the site values (the kernel keeps both per tile of 16 lines).  Returns (D, candidate evaluations)."""
     L = len(F)
@@ -63,6 +63,37 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None):
             q += 2
         return best
 
+    def scan_unit(positions, lo, hi, nshares, rng):
+        """Levels B and C of round 4 (scan8_calm + coop8) for one unit of one line: its `nshares` lanes (interleaved shares, step
+        2 * nshares) run trips in blocks of 4, 8, 16, ... in lock step -- the control is the wave's --, and after any block the
+        wave may decide (here: at random) to spread what is left over its 4 rows: row r takes the pairs bq + 2 r + 8 j, bq = the
+        FIRST share's next candidate.  Must see exactly the candidates of the plain scan."""
+        best = [M32] * len(positions)
+        step = 2 * nshares
+        qs = [(lo & ~1) + 2 * u for u in range(nshares)]
+
+        def pair(q):
+            for k, p in enumerate(positions):
+                best[k] = min(best[k], val(p, q), val(p, q + 1))
+                evals[0] += 2
+        blk = 4
+        while any(q <= hi for q in qs):
+            for _ in range(blk):
+                for u in range(nshares):
+                    if qs[u] <= hi:
+                        pair(qs[u])
+                        qs[u] += step
+            blk *= 2
+            if any(q <= hi for q in qs) and rng.random() < 0.5:
+                assert qs[0] <= hi and all(q >= qs[0] for q in qs), "the first share is the one furthest behind"
+                for row in range(4):
+                    q = qs[0] + 2 * row
+                    while q <= hi:
+                        pair(q)
+                        q += 8
+                break
+        return best
+
     def dist(best, p):
         return (best >> B) - p * (2 * h - p)
 
@@ -85,6 +116,9 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None):
         hi = (args[8 * (i + 1)] & mask) if i + 1 < MA else hi_t
         pos = [64 * i + 8 * k for k in range(8)]
         best = scan(pos, lo, hi)
+        if coop_rng is not None and hi - lo >= 108 // coop_scale:   # a wave that holds a long range: wave-uniform control, hand-over
+            for nshares in (1, 2):                                  # (one lane per interval for lines above 512, two below)
+                assert scan_unit(pos, lo, hi, nshares, coop_rng) == best, "the split scans of level B saw a different candidate set"
         for k in range(1, 8):
             if 8 * i + k < M:
                 args[8 * i + k] = min(args[8 * i + k], best[k])
@@ -94,6 +128,8 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None):
         a0 = args[i] & mask
         a8 = (args[i + 1] & mask) if i + 1 < M else hi_t
         best = scan([8 * i + k for k in range(8)], a0, a8)
+        if coop_rng is not None and a8 - a0 >= 34 // coop_scale:
+            assert scan_unit([8 * i + k for k in range(8)], a0, a8, 1, coop_rng) == best, "the split scan of level C saw a different candidate set"
         for k in range(8):
             p = 8 * i + k
             if p < L:
@@ -144,6 +180,9 @@ def check_line(rng, F):
         kw = dict(lo_t=rng.randrange(0, sites[0] + 1), hi_t=rng.randrange(sites[-1], L),
                   mt_t=rng.randrange(0, min(F[q] for q in sites) + 1))
     kw["force_clip"] = rng.choice([None, True, False])
+    if rng.random() < 0.5:                                              # round 4: long ranges under wave-uniform control (thresholds scaled
+        kw["coop_rng"] = random.Random(rng.randrange(1 << 30))          # down so that the short test lines reach the hand-over too)
+        kw["coop_scale"] = rng.choice([1, 4, 16])
     got, ev = dc_line(F, FINF, **kw)
     assert got == brute(F), (L, F, kw)
     return ev
