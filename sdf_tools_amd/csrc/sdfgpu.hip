@@ -99,7 +99,7 @@ struct sdfgpu_context {
     bool standby_far = true;         // stand-by pipeline behind a trusted dense tier = the far-field pair (bounded whatever the scene
                                      // turns into), not fused K12 + K3/16 with unbounded scans (option "standby_far")
     int standby_grid = 1024;         // workgroups of the stand-by launches (LOOP form; option "standby_grid"): 4 per CU = all resident at once
-    bool dc_attr_set[8] = {false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
+    bool dc_attr_set[12] = {false, false, false, false, false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
@@ -542,12 +542,15 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         // (the kernel is a template over lines per tile and lanes; measured at 512^3: 8-line tiles -- 20 KB of LDS, 7 - 8
         //  workgroups per CU -- with 128 or 256 lanes are 12 - 25 % slower than 16 lines x 256 lanes, 16 lines x 512 lanes
         //  +-5 %, 32 lines x 512 lanes +-3 %; 2 instead of 4 workgroups per CU is 1.55x slower)
-        constexpr int NT = 256;
+        // lines above 512: the tile's keys take 66 KB and more, two workgroups per CU -- of 512 lanes then (round 4: with 256 they
+        // left the CU at 2 waves per SIMD, and 1024-voxel lines cost 1.5 - 2x their share)
+        const bool big = a.L > 512 && !loop;
+        const int NT = big ? 512 : 256;
         a.ntiles = ntiles;
         // LOOP form: at most 2048 workgroups (a guarded exit costs 1.7 us up to there and grows with the grid), a multiple of 8
         // so that a workgroup's tiles stay on its XCD
         const int64_t nwg = loop ? std::min<int64_t>(ntiles, h->standby_grid) : ntiles;
-        const int which = (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0);
+        const int which = (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0) + (big ? 8 : 0);
         auto launch = [&](auto kern) -> int {
             // (the attribute is per kernel: raised once per instantiation, not on every launch -- ADVICE r3)
             if (lds > 64 * 1024 && !h->dc_attr_set[which]) {
@@ -566,7 +569,11 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             case 4: rc = launch(k_envelope_dc<2, false, 256, 16, true>); break;
             case 5: rc = launch(k_envelope_dc<3, false, 256, 16, true>); break;
             case 6: rc = launch(k_envelope_dc<2, true, 256, 16, true>); break;
-            default: rc = launch(k_envelope_dc<3, true, 256, 16, true>); break;
+            case 7: rc = launch(k_envelope_dc<3, true, 256, 16, true>); break;
+            case 8: rc = launch(k_envelope_dc<2, false, 512, 16, false, 4>); break;
+            case 9: rc = launch(k_envelope_dc<3, false, 512, 16, false, 4>); break;
+            case 10: rc = launch(k_envelope_dc<2, true, 512, 16, false, 4>); break;
+            default: rc = launch(k_envelope_dc<3, true, 512, 16, false, 4>); break;
         }
         if (rc) return rc;
         HIP_TRY(h, hipGetLastError());

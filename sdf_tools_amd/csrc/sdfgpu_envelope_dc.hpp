@@ -58,9 +58,10 @@ namespace sdfgpu {
 // scenes (p = 0.01: distances up to ~30) never pay for a far-field pass they do not need.
 constexpr int kScanExpectNear = 40;
 
-constexpr int kDcLocalSat = 255;      // pass 0 finishes a filled voxel itself when its result is below this: its own in-row squared distance or a free
-                                      // voxel within 15 positions along the line (round 4: the bound used to be on the in-row distance alone, 64 --
-                                      // a wall or a floor a few voxels thick, whose in-row distance is "none", sent every tile to the second pass) ...
+constexpr int kDcLocalSat = 1023;     // pass 0 finishes a filled voxel itself when its result is below this: its own in-row squared distance or a free
+                                      // voxel within 31 positions along the line (round 4: the bound used to be on the in-row distance alone, 64 --
+                                      // a wall or a floor a few voxels thick, whose in-row distance is "none", sent every tile to the second pass;
+                                      // 31 because a tile lists at most 448 / 16 = 28 filled voxels per line) ...
 constexpr int kDcLocalFilled = 448;   // ... when the tile holds at most this many filled voxels (of 16 x L; a full second pass costs as much
                                       // as the first: a 3 %-occupied 512^3 scene has 245 per tile and must stay below)
 
@@ -391,8 +392,10 @@ __global__ __launch_bounds__(256) void k_probe_window(const ProbeArgs a) {
 // LOOP form is launched with a small grid (option "standby_grid", 1024 workgroups = 4 per CU) whose workgroups take tiles
 // blockIdx.x, + gridDim.x, ... -- static assignment, a few % slower than one tile per workgroup when it does run (the build in
 // which a scene leaves the dense tier).
-template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines, bool LOOP = false>
-__global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envelope_dc(const EnvDcArgs a) {
+// WPS = waves per SIMD the register budget is set for: 4 workgroups of 256 lanes per CU for lines up to 512 (LDS: 37 KB each), 2 workgroups
+// of 512 lanes for longer lines (76 KB each at 1024) -- round 4: lines above 512 used to run 2 x 256 lanes per CU, 2 waves per SIMD.
+template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines, bool LOOP = false, int WPS = (NL == 8 ? 8 : 4) * (NT / 64) / 4>
+__global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     constexpr int S = NT / NL;              // lanes per line
     constexpr int LPR = NL / 4;             // staging: lanes per row (4 lines each)
     constexpr int LPR_SH = NL == 16 ? 2 : 1;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
     uint32_t* const keys = dc_smem;                             // [16][pitch]
     uint32_t* const args = keys + NL * pitch;                   // [M + 2][16]  best value (distance << B | argmin) of coarse position 8 i
     uint32_t* const misc = args + (M + 2) * NL;                 // per wave: [0..7] span lo, [8..15] span hi, [16..23] smallest site value; [24] filled voxels listed, [25] second pass wanted, [26..28] probe
-    uint32_t* const flist = misc + 48;                          // [kDcLocalFilled] filled voxels of pass 0: line << 24 | p << 8 | min(S, 255)
+    uint32_t* const flist = misc + 48;                          // [kDcLocalFilled] filled voxels of pass 0: line << 28 | p << 12 | min(S, kDcLocalSat)
     const int t = threadIdx.x;
 #ifdef SDFGPU_PHASE_CLOCKS
     unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                             uint32_t S = (uint32_t)(-s1);       // squared distance to the nearest free voxel so far
                             if constexpr (STAGE == 2) S = S >= (uint32_t)kInf16 ? (uint32_t)kInf32 : __umul24(S, S);
                             const uint32_t e = atomicAdd(&misc[24], 1u);
-                            if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 24) | ((uint32_t)p << 8) | umin(S, (uint32_t)kDcLocalSat);
+                            if (e < (uint32_t)kDcLocalFilled) flist[e] = ((uint32_t)(4 * sub + k) << 28) | ((uint32_t)p << 12) | umin(S, (uint32_t)kDcLocalSat);
                         }
                     }
                 }
@@ -1001,9 +1004,9 @@ __global__ __launch_bounds__(NT, (NL == 8 ? 8 : 4) * (NT / 64) / 4) void k_envel
                 } else {
                     for (uint32_t e = (uint32_t)t; e < nf; e += (uint32_t)NT) {
                         const uint32_t ent = flist[e];
-                        const int fl = (int)(ent >> 24), p = (int)((ent >> 8) & 0xffffu);
-                        int D1 = (int)(ent & 0xffu);            // (saturated at kDcLocalSat: then only a candidate found below can finish the voxel)
-                        // offsets in rounds of 4 (8 loads in flight; D1 <= 255: at most 4 rounds).  A candidate beyond the bound that
+                        const int fl = (int)(ent >> 28), p = (int)((ent >> 12) & 0xffffu);
+                        int D1 = (int)(ent & 0xfffu);           // (saturated at kDcLocalSat: then only a candidate found below can finish the voxel)
+                        // offsets in rounds of 4 (8 loads in flight; D1 <= 1023: at most 8 rounds).  A candidate beyond the bound that
                         // rides along in a round is still a candidate: harmless.
                         for (int d0 = 1; (int)__umul24(d0, d0) < D1; d0 += 4) {
                             int v[8];

@@ -198,3 +198,42 @@ def test_1024_cube_single_gpu_and_slab_builder(gpu):
     for lo, w in crops:
         g = out[lo[0]:lo[0] + C, lo[1]:lo[1] + C, lo[2]:lo[2] + C].cpu().numpy()
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), lo
+
+
+def test_1024_long_lines_far_field_against_unbounded_scans(gpu):
+    """Maximum line length of the far-field kernel's grid sizes: a structured 1024 x 1024 x 256 scene (walls, floor, table, shelf:
+    far-field, thin and thick solids) through the library's own tier selection -- the far-field pair with 1024-voxel y and x
+    lines (one interval per lane in level B, wave-cooperative scans) -- must equal, bit for bit, the same build with the far-field
+    kernel switched off (marching sweeps with unbounded exact scans: a different algorithm), and satisfy the size-independent
+    properties of an exact signed EDT; the extrema agree as well.  Too large for the CPU oracle in test time."""
+    import torch
+    shape, res = (1024, 1024, 256), 0.01
+    dev = torch.device("cuda", 0)
+    m_t = synth.room_mask_torch(shape, dev)
+    gpu.set_option("policy_reset", 1)
+    stream = torch.cuda.current_stream().cuda_stream
+    sdf = torch.empty(shape, dtype=torch.float32, device=dev)
+    gpu.build_device(m_t.data_ptr(), shape, sdf.data_ptr(), res, False, stream)
+    ext = gpu.get_extrema()
+    path = gpu.last_path()
+    assert path["far_y"] and path["far_x"] and not path["dense_certified"]
+    gpu.set_option("envelope", 0)
+    try:
+        ref = torch.empty(shape, dtype=torch.float32, device=dev)
+        gpu.build_device(m_t.data_ptr(), shape, ref.data_ptr(), res, False, stream)
+        ext_ref = gpu.get_extrema()
+        p2 = gpu.last_path()
+    finally:
+        gpu.set_option("envelope", 1)
+        gpu.set_option("policy_reset", 1)
+    assert not p2["far_y"] and not p2["far_x"]
+    assert bool(torch.equal(sdf.view(torch.int32), ref.view(torch.int32))) and ext == ext_ref
+    del ref
+    assert bool(torch.equal(sdf < 0, m_t != 0))                          # sign == occupancy
+    assert float(sdf.abs().min()) >= res * (1 - 1e-6)
+    for ax in range(3):                                                  # 1-Lipschitz between same-class neighbours
+        a, b = sdf.narrow(ax, 0, shape[ax] - 1), sdf.narrow(ax, 1, shape[ax] - 1)
+        same = (a < 0) == (b < 0)
+        assert float(((a - b).abs() * same).max()) <= res + 2e-6         # (fp32 values up to ~10: differences carry ~1e-6 of rounding)
+        del a, b, same
+    assert ext[0] == pytest.approx(float(sdf.max()), abs=1e-6) and ext[1] == pytest.approx(float(sdf.min()), abs=1e-6)
