@@ -528,12 +528,12 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     // another: 1.4 % of the two-box scene's chunks hold a third of the useful trips -- used to cost every lane of their wave
     // their full length.  The lanes of a wave are 4 rows of 16 (the tile's lines x 4 slots), and its units of work are groups
     // of `urows` rows (a chunk of level C = one row; an interval of level B = Hs rows).  scan8_calm runs trips in the lanes,
-    // in blocks of 4, 8, 16, ..., until after a block at most `kmax` units are still active and one of them has 6 trips
-    // or more to go, and
-    // coop8 spreads the rest of each such unit over all 4 rows (every row takes every 4th pair of the unit's line), reduces
-    // the partial minima across the rows (16 ds_bpermute) and hands them to the unit's first row.  Exact for the same reason
-    // as any other split of a scan: the candidate set of a unit is unchanged.  Both are only entered by a wave that holds a
-    // long range at all (one ballot; noise-like scenes, whose ranges are all alike, take the plain scan8).
+    // in blocks of 4, 8, 16, ..., until after a block at most `kmax` units are still active and one of them has 6 trips or
+    // more to go, and coop8 spreads the rest of each such unit over all 4 rows (every row takes every 4th pair of the unit's
+    // line), reduces the partial minima across the rows (16 ds_bpermute) and hands them to the unit's first row.  Exact for
+    // the same reason as any other split of a scan: the candidate set of a unit is unchanged (tools/envelope_dc_model.py,
+    // scan_unit, restates the hand-over on the CPU).  Both are only entered by a wave that holds a long range at all (one
+    // ballot; noise-like scenes, whose ranges are all alike, take the plain scan8).
     auto scan8_calm = [&](const uint32_t* kl, int& q, int qe, int step, const int (&nc)[8], uint32_t (&best)[8], auto urows_tag, int kmax) {
         constexpr int urows = decltype(urows_tag)::value;
         int qc = q - h, blk = 4 * step;
