@@ -48,10 +48,14 @@ protected:
 
     static int64_t CellsForSize(const double size, const double cell) { return (int64_t)std::ceil(size / cell); }
 
+    // storage != nullptr: the grid adopts *storage (size nx * ny * nz, contents kept) instead of filling a fresh array
+    // with default_value -- the SDF build seams hand over storage that the device-to-host drain writes exactly once.
     void Setup(const Eigen::Isometry3d& origin, const double cx, const double cy, const double cz,
-               const int64_t nx, const int64_t ny, const int64_t nz, const T& default_value, const T& oob_value) {
+               const int64_t nx, const int64_t ny, const int64_t nz, const T& default_value, const T& oob_value,
+               BackingStore* storage = nullptr) {
         if (!(cx > 0.0) || !(cy > 0.0) || !(cz > 0.0)) throw std::invalid_argument("cell sizes must be positive");
         if (nx <= 0 || ny <= 0 || nz <= 0) throw std::invalid_argument("cell counts must be positive");
+        if (storage && (int64_t)storage->size() != nx * ny * nz) throw std::invalid_argument("adopted storage has the wrong size");
         origin_transform_ = origin;
         inverse_origin_transform_ = origin.inverse();
         cell_x_size_ = cx; cell_y_size_ = cy; cell_z_size_ = cz;
@@ -62,7 +66,8 @@ protected:
         stride2_ = nz;
         default_value_ = default_value;
         oob_value_ = oob_value;
-        data_.assign((size_t)(nx * ny * nz), default_value);
+        if (storage) data_ = std::move(*storage);
+        else data_.assign((size_t)(nx * ny * nz), default_value);
         initialized_ = true;
     }
 
@@ -106,6 +111,12 @@ public:
     }
     VoxelGrid() {}
     virtual ~VoxelGrid() {}
+    // (the user-provided destructor suppresses the implicit move operations: without these four lines every
+    //  `std::move(grid)` -- the SDF seams return their 512 MiB result that way -- silently COPIES the array)
+    VoxelGrid(const VoxelGrid&) = default;
+    VoxelGrid(VoxelGrid&&) = default;
+    VoxelGrid& operator=(const VoxelGrid&) = default;
+    VoxelGrid& operator=(VoxelGrid&&) = default;
 
     virtual VoxelGrid<T, BackingStore>* Clone() const { return new VoxelGrid<T, BackingStore>(*this); }
 

@@ -9,11 +9,14 @@
 // point, the reference's double arithmetic), and Host() downloads the field lazily, once, for callers that do want the
 // reference's container (GetValue*, serialisation, per-point calls).
 //
-// Ownership: the device memory belongs to the libsdfgpu context of the thread that built the field
-// (sdf_generation::GpuContext, one per host thread); build, query and destroy the object on that thread.
+// Ownership (round 5): the device memory belongs to the libsdfgpu context of the thread that built the field,
+// and the field SHARES ownership of that context (sdf_generation::SharedGpuContext): it may be returned from a worker
+// thread, queried or destroyed on another thread, or outlive the thread that built it -- the context is destroyed with its
+// last owner, and every call on it (builds on the owning thread included) is made under the context's mutex.
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -34,8 +37,10 @@ public:
         : origin_(origin_transform), inverse_origin_(origin_transform.inverse()), frame_(frame), resolution_(resolution),
           nx_(x_cells), ny_(y_cells), nz_(z_cells), oob_(oob_value) {
         if (nx_ <= 0 || ny_ <= 0 || nz_ <= 0) throw std::invalid_argument("DeviceSignedDistanceField: cell counts must be positive");
-        handle_ = sdf_generation::GpuContext::Get();
+        ctx_ = sdf_generation::GpuContext::Shared();
+        handle_ = ctx_->handle;
         void* p = nullptr;
+        const std::lock_guard<std::mutex> lock(ctx_->mutex);
         sdf_generation::ThrowOnStatus(handle_, sdfgpu_device_malloc(handle_, (size_t)(nx_ * ny_ * nz_) * sizeof(float), &p));
         d_sdf_ = static_cast<float*>(p);
     }
@@ -52,6 +57,7 @@ public:
     static DeviceSignedDistanceField Upload(const SignedDistanceField& sdf) {
         DeviceSignedDistanceField d(sdf.GetOriginTransform(), sdf.GetFrame(), sdf.GetResolution(), sdf.GetNumXCells(),
                                     sdf.GetNumYCells(), sdf.GetNumZCells(), sdf.GetOOBValue());
+        const std::lock_guard<std::mutex> lock(d.ctx_->mutex);
         sdf_generation::ThrowOnStatus(d.handle_, sdfgpu_copy_from_host(d.handle_, d.d_sdf_, sdf.GetImmutableRawData().data(),
                                                                        (size_t)d.NumCells() * sizeof(float), nullptr));
         return d;
@@ -70,6 +76,9 @@ public:
     float* DevicePointer() { host_.reset(); return d_sdf_; }
     const float* DevicePointer() const { return d_sdf_; }
     sdfgpu_handle Handle() const { return handle_; }
+    // the context this field lives on (shared ownership); callers that use Handle() / DevicePointer() with the C ABI themselves
+    // hold Context()->mutex around their calls
+    const std::shared_ptr<sdf_generation::SharedGpuContext>& Context() const { return ctx_; }
 
     // (max, min) of the un-narrowed distances, as the reference returns them beside the field (sdf_generation.hpp:246-269).
     std::pair<double, double> GetExtrema() const { return extrema_; }
@@ -90,6 +99,7 @@ public:
             for (int c = 0; c < 4; ++c) w2g[r * 4 + c] = inverse_origin_.matrix()(r, c);
             for (int c = 0; c < 3; ++c) rot[r * 3 + c] = origin_.matrix()(r, c);
         }
+        const std::lock_guard<std::mutex> lock(ctx_->mutex);
         sdf_generation::ThrowOnStatus(handle_, sdfgpu_query_points(handle_, d_sdf_, nx_, ny_, nz_, resolution_, w2g, rot, oob_,
                                                                    points_xyz, n, enable_edge_gradients ? 1 : 0, out_distance,
                                                                    out_gradient, out_flags));
@@ -121,7 +131,8 @@ public:
     const SignedDistanceField& Host() const {
         if (!host_) {
             if (!d_sdf_) throw std::runtime_error("DeviceSignedDistanceField is not initialized");
-            std::unique_ptr<SignedDistanceField> h(new SignedDistanceField(origin_, frame_, resolution_, nx_, ny_, nz_, oob_));
+            std::unique_ptr<SignedDistanceField> h(new SignedDistanceField(SignedDistanceField::ForBuild{}, origin_, frame_, resolution_, nx_, ny_, nz_, oob_));
+            const std::lock_guard<std::mutex> lock(ctx_->mutex);
             sdf_generation::ThrowOnStatus(handle_, sdfgpu_copy_to_host(handle_, h->MutableDataForBuild(), d_sdf_,
                                                                        (size_t)NumCells() * sizeof(float), nullptr));
             host_ = std::move(h);
@@ -137,15 +148,21 @@ private:
         return pts;
     }
     void Release() {
-        if (d_sdf_ && handle_) (void)sdfgpu_device_free(handle_, d_sdf_);
+        if (d_sdf_ && ctx_) {
+            const std::lock_guard<std::mutex> lock(ctx_->mutex);
+            (void)sdfgpu_device_free(handle_, d_sdf_);
+        }
         d_sdf_ = nullptr;
         host_.reset();
+        ctx_.reset();                                             // (may destroy the context: this field was its last owner)
+        handle_ = nullptr;
     }
     void MoveFrom(DeviceSignedDistanceField& o) {
         origin_ = o.origin_; inverse_origin_ = o.inverse_origin_; frame_ = std::move(o.frame_); resolution_ = o.resolution_;
-        nx_ = o.nx_; ny_ = o.ny_; nz_ = o.nz_; oob_ = o.oob_; handle_ = o.handle_; d_sdf_ = o.d_sdf_; extrema_ = o.extrema_;
+        nx_ = o.nx_; ny_ = o.ny_; nz_ = o.nz_; oob_ = o.oob_; ctx_ = std::move(o.ctx_); handle_ = o.handle_; d_sdf_ = o.d_sdf_; extrema_ = o.extrema_;
         host_ = std::move(o.host_);
         o.d_sdf_ = nullptr;
+        o.handle_ = nullptr;
     }
 
     Eigen::Isometry3d origin_, inverse_origin_;
@@ -153,6 +170,7 @@ private:
     double resolution_ = 1.0;
     int64_t nx_ = 0, ny_ = 0, nz_ = 0;
     float oob_ = 0.0f;
+    std::shared_ptr<sdf_generation::SharedGpuContext> ctx_;       // keeps the context (and so d_sdf_) alive
     sdfgpu_handle handle_ = nullptr;
     float* d_sdf_ = nullptr;
     std::pair<double, double> extrema_{0.0, 0.0};

@@ -1,7 +1,9 @@
 // gpu_context -- the per-thread libsdfgpu handle shared by the mirror headers (sdf_generation.hpp for the build,
-// sdf.hpp for the full-grid gradient).  One GPU context per host thread: the C ABI is re-entrant per context
-// (SURVEY.md 8(b) "Threading").  There is no CPU fallback: without a HIP device Get() throws std::runtime_error.
+// sdf.hpp for the full-grid gradient).  One GPU context per host thread (shared with the device-resident fields built on it): the C ABI is re-entrant
+// per context (SURVEY.md 8(b) "Threading").  There is no CPU fallback: without a HIP device Get() throws std::runtime_error.
 #pragma once
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -12,20 +14,35 @@
 
 namespace sdf_generation {
 
+// The handle and what keeps it alive.  The context is created by (and normally used on) one host thread, but a result that
+// stays in HBM (sdf_tools::DeviceSignedDistanceField) holds device memory of this context and may outlive its thread or be
+// handed to another one (a worker thread that builds and returns the field; a pybind object collected elsewhere): the field
+// therefore SHARES ownership -- the context is destroyed when the thread AND every field built on it are gone -- and every
+// call on the handle is made under `mutex`, because the C ABI is re-entrant per context, not within one.
+struct SharedGpuContext {
+    sdfgpu_handle handle = nullptr;
+    std::mutex mutex;
+    SharedGpuContext() = default;
+    SharedGpuContext(const SharedGpuContext&) = delete;
+    SharedGpuContext& operator=(const SharedGpuContext&) = delete;
+    ~SharedGpuContext() { if (handle) sdfgpu_destroy(handle); }
+};
+
 class GpuContext {
 public:
-    static sdfgpu_handle Get() {
-        thread_local GpuContext ctx;
-        if (!ctx.handle_) {
-            const int rc = sdfgpu_create(DeviceIndex(), &ctx.handle_);
+    // this thread's context (created on first use; throws std::runtime_error without a HIP device)
+    static std::shared_ptr<SharedGpuContext> Shared() {
+        thread_local std::shared_ptr<SharedGpuContext> ctx;
+        if (!ctx) {
+            std::shared_ptr<SharedGpuContext> fresh = std::make_shared<SharedGpuContext>();
+            const int rc = sdfgpu_create(DeviceIndex(), &fresh->handle);
             if (rc != SDFGPU_OK) throw std::runtime_error(std::string("sdfgpu: ") + sdfgpu_last_error(nullptr));
+            ctx = std::move(fresh);
         }
-        return ctx.handle_;
+        return ctx;
     }
+    static sdfgpu_handle Get() { return Shared()->handle; }
     static int& DeviceIndex() { static int device = 0; return device; }
-    ~GpuContext() { if (handle_) sdfgpu_destroy(handle_); }
-private:
-    sdfgpu_handle handle_ = nullptr;
 };
 
 #ifdef SDF_TOOLS_MULTI_GPU

@@ -7,6 +7,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <memory>
@@ -31,12 +32,54 @@ struct SDF {
     bool is_compressed = false;
 };
 
+namespace detail {
+// A std::vector<float> of n elements whose storage nobody has written: the pages of a 512^3 field (512 MiB) are then first
+// touched by the thread team that drains the device-to-host copy into it -- in parallel, once -- instead of by one thread
+// value-initialising 134 M floats that the drain overwrites (measured in round 4: the largest part of a 241 ms class call
+// around 0.14 ms of kernels).  The container type must stay std::vector<float> (GetImmutableRawData() returns it by
+// reference, reference include/sdf_tools/sdf.hpp / VoxelGrid), and the standard offers no way to size one without writing
+// its elements, so on libstdc++ the three pointers of an empty vector are pointed at memory from its own allocator
+// (begin, end, end of storage -- a layout that has not changed since GCC 3; checked against a normally built vector at run
+// time); anywhere else, or if the check fails, the vector is built the ordinary way and only speed is lost.
+inline std::vector<float> UninitializedFloatVector(const size_t n) {
+#if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(SDF_TOOLS_NO_VECTOR_ADOPT)
+    static_assert(sizeof(std::vector<float>) == 3 * sizeof(float*), "std::vector<float> is not three pointers");
+    static const bool layout_ok = []() {
+        std::vector<float> probe(3);
+        probe.reserve(5);
+        float* rep[3];
+        std::memcpy(rep, static_cast<const void*>(&probe), sizeof rep);
+        return rep[0] == probe.data() && rep[1] == probe.data() + probe.size() && rep[2] == probe.data() + probe.capacity();
+    }();
+    if (layout_ok && n > 0) {
+        std::vector<float> v;
+        float* const p = std::allocator<float>().allocate(n);      // (operator new: untouched pages for large n)
+        float* rep[3] = {p, p + n, p + n};
+        std::memcpy(static_cast<void*>(&v), rep, sizeof rep);      // v now owns p; its destructor deallocates through the same allocator
+        return v;
+    }
+#endif
+    return std::vector<float>(n);
+}
+}  // namespace detail
+
 class SignedDistanceField : public VoxelGrid::VoxelGrid<float> {
 protected:
     std::string frame_;
     bool locked_;
 
 public:
+    // Tag of the constructor the build seams use: every cell is about to be overwritten by the device-to-host drain, so the
+    // array is NOT filled with OOB_value first (detail::UninitializedFloatVector).  Cells are indeterminate until then.
+    struct ForBuild {};
+    SignedDistanceField(ForBuild, const Eigen::Isometry3d& origin_transform, const std::string& frame, double resolution,
+                        int64_t x_cells, int64_t y_cells, int64_t z_cells, float OOB_value)
+        : Base(), frame_(frame), locked_(false) {
+        if (x_cells <= 0 || y_cells <= 0 || z_cells <= 0) throw std::invalid_argument("cell counts must be positive");
+        std::vector<float> storage = detail::UninitializedFloatVector((size_t)(x_cells * y_cells * z_cells));
+        Setup(origin_transform, resolution, resolution, resolution, x_cells, y_cells, z_cells, OOB_value, OOB_value, &storage);
+    }
+
     EIGEN_MAKE_ALIGNED_OPERATOR_NEW
     typedef std::shared_ptr<SignedDistanceField> Ptr;
     typedef std::shared_ptr<const SignedDistanceField> ConstPtr;
@@ -135,7 +178,9 @@ public:
         const int64_t nx = GetNumXCells(), ny = GetNumYCells(), nz = GetNumZCells();
         std::vector<double> g((size_t)(nx * ny * nz) * 3);
         if (g.empty()) return g;
-        sdfgpu_handle h = sdf_generation::GpuContext::Get();
+        const std::shared_ptr<sdf_generation::SharedGpuContext> ctx = sdf_generation::GpuContext::Shared();
+        const std::lock_guard<std::mutex> lock(ctx->mutex);
+        sdfgpu_handle h = ctx->handle;
         sdf_generation::ThrowOnStatus(h, sdfgpu_gradient(h, data_.data(), nx, ny, nz, GetResolution(),
                                                          enable_edge_gradients ? 1 : 0, g.data(), 1));
         const Eigen::Quaterniond q(origin_transform_.rotation());

@@ -37,8 +37,9 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
     for (int64_t x = 0; x < grid_num_x_cells; x++)
         for (int64_t y = 0; y < grid_num_y_cells; y++)
             for (int64_t z = 0; z < grid_num_z_cells; z++) filled[i++] = is_filled_fn(VoxelGrid::GRID_INDEX(x, y, z)) ? 1 : 0;
-    sdf_tools::SignedDistanceField new_sdf(grid_origin_tranform, frame, grid_resolution, grid_num_x_cells, grid_num_y_cells,
-                                           grid_num_z_cells, oob_value);
+    // (storage the drain team writes once: no 512 MiB fill with oob_value in front of a download that overwrites it)
+    sdf_tools::SignedDistanceField new_sdf(sdf_tools::SignedDistanceField::ForBuild{}, grid_origin_tranform, frame, grid_resolution,
+                                           grid_num_x_cells, grid_num_y_cells, grid_num_z_cells, oob_value);
     double max_distance = 0.0, min_distance = 0.0;
 #ifdef SDF_TOOLS_MULTI_GPU
     if (MultiGpuContext::NumGpus() > 1 && grid_num_x_cells >= MultiGpuContext::NumGpus()) {
@@ -49,7 +50,9 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
         return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
     }
 #endif
-    sdfgpu_handle h = GpuContext::Get();
+    const std::shared_ptr<SharedGpuContext> ctx = GpuContext::Shared();
+    const std::lock_guard<std::mutex> lock(ctx->mutex);
+    sdfgpu_handle h = ctx->handle;
     ThrowOnStatus(h, sdfgpu_build(h, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells, grid_resolution,
                                   add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(), &max_distance, &min_distance));
     return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
@@ -86,7 +89,7 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
     const float oob_value, const std::string& frame, const bool add_virtual_border) {
     if ((cell_sizes.x() != cell_sizes.y()) || (cell_sizes.x() != cell_sizes.z()))
         throw std::invalid_argument("Grid must have uniform resolution");
-    sdf_tools::SignedDistanceField new_sdf(origin, frame, cell_sizes.x(), nx, ny, nz, oob_value);
+    sdf_tools::SignedDistanceField new_sdf(sdf_tools::SignedDistanceField::ForBuild{}, origin, frame, cell_sizes.x(), nx, ny, nz, oob_value);
     double max_distance = 0.0, min_distance = 0.0;
 #ifdef SDF_TOOLS_MULTI_GPU
     if (MultiGpuContext::NumGpus() > 1 && nx >= MultiGpuContext::NumGpus()) {
@@ -97,7 +100,9 @@ inline std::pair<sdf_tools::SignedDistanceField, std::pair<double, double>> Extr
         return std::make_pair(std::move(new_sdf), std::make_pair(max_distance, min_distance));      // (moved: a copy of the field costs as much as its download)
     }
 #endif
-    sdfgpu_handle h = GpuContext::Get();
+    const std::shared_ptr<SharedGpuContext> ctx = GpuContext::Shared();
+    const std::lock_guard<std::mutex> lock(ctx->mutex);
+    sdfgpu_handle h = ctx->handle;
     ThrowOnStatus(h, sdfgpu_build_cells(h, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny, nz,
                                         cell_sizes.x(), add_virtual_border ? 1 : 0, new_sdf.MutableDataForBuild(),
                                         &max_distance, &min_distance));
@@ -123,6 +128,7 @@ inline std::pair<sdf_tools::DeviceSignedDistanceField, std::pair<double, double>
     sdf_tools::DeviceSignedDistanceField new_sdf(grid_origin_tranform, frame, grid_resolution, grid_num_x_cells, grid_num_y_cells,
                                                  grid_num_z_cells, oob_value);
     double max_distance = 0.0, min_distance = 0.0;
+    const std::lock_guard<std::mutex> lock(new_sdf.Context()->mutex);
     sdfgpu_handle h = new_sdf.Handle();
     ThrowOnStatus(h, sdfgpu_build_to_device(h, filled.data(), grid_num_x_cells, grid_num_y_cells, grid_num_z_cells, grid_resolution,
                                             add_virtual_border ? 1 : 0, new_sdf.DevicePointer(), &max_distance, &min_distance));
@@ -149,6 +155,7 @@ inline std::pair<sdf_tools::DeviceSignedDistanceField, std::pair<double, double>
         throw std::invalid_argument("Grid must have uniform resolution");
     sdf_tools::DeviceSignedDistanceField new_sdf(origin, frame, cell_sizes.x(), nx, ny, nz, oob_value);
     double max_distance = 0.0, min_distance = 0.0;
+    const std::lock_guard<std::mutex> lock(new_sdf.Context()->mutex);
     sdfgpu_handle h = new_sdf.Handle();
     ThrowOnStatus(h, sdfgpu_build_cells_to_device(h, cells, cell_stride, occupancy_offset, unknown_is_filled ? 1 : 0, nx, ny, nz,
                                                   cell_sizes.x(), add_virtual_border ? 1 : 0, new_sdf.DevicePointer(),

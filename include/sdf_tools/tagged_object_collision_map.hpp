@@ -64,10 +64,12 @@ protected:
         const Eigen::Vector3d cell_sizes = GetCellSizes();
         if ((cell_sizes.x() != cell_sizes.y()) || (cell_sizes.x() != cell_sizes.z()))
             throw std::invalid_argument("Grid must have uniform resolution");
-        SignedDistanceField new_sdf(GetOriginTransform(), frame_, cell_sizes.x(), GetNumXCells(), GetNumYCells(),
-                                    GetNumZCells(), oob_value);
+        SignedDistanceField new_sdf(SignedDistanceField::ForBuild{}, GetOriginTransform(), frame_, cell_sizes.x(), GetNumXCells(),
+                                    GetNumYCells(), GetNumZCells(), oob_value);
         double max_distance = 0.0, min_distance = 0.0;
-        sdfgpu_handle h = sdf_generation::GpuContext::Get();
+        const std::shared_ptr<sdf_generation::SharedGpuContext> ctx = sdf_generation::GpuContext::Shared();
+        const std::lock_guard<std::mutex> lock(ctx->mutex);
+        sdfgpu_handle h = ctx->handle;
         sdf_generation::ThrowOnStatus(
             h, sdfgpu_build_tagged_cells(h, cells_on_device ? nullptr : data_.data(), sizeof(TAGGED_OBJECT_COLLISION_CELL),
                                          offsetof(TAGGED_OBJECT_COLLISION_CELL, occupancy),

@@ -92,11 +92,31 @@ def build_pysdf_tools(force=False, verbose=False):
     return out
 
 
+def build_example(name, force=False, verbose=False):
+    """examples/<name>.cpp -> examples/<name>_example with g++ against include/ and the in-tree libsdfgpu.so (the C++ side of
+    the drop-in boundary: client code written like the reference's, tests/test_cpp_example.py and bench.py run these)."""
+    src = os.path.join(ROOT, "examples", name + ".cpp")
+    exe = os.path.join(ROOT, "examples", name + "_example")
+    hdr_dir = os.path.join(INCLUDE, "sdf_tools")
+    deps = [src, os.path.join(INCLUDE, "sdfgpu.h")] + [os.path.join(hdr_dir, f) for f in sorted(os.listdir(hdr_dir))] + \
+        [os.path.join(INCLUDE, "arc_utilities", f) for f in sorted(os.listdir(os.path.join(INCLUDE, "arc_utilities")))]
+    build_libsdfgpu(force=False, verbose=verbose)
+    if not force and not _newer(exe, deps):
+        return exe
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", INCLUDE, src, "-o", exe, "-L", PKG, "-lsdfgpu",
+           "-Wl,-rpath," + PKG, "-lz"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return exe
+
+
 def build_all(force=False, verbose=False):
     out = [build_libsdfgpu(force, verbose), build_libsdfgpu_multi(force, verbose)]
     p = build_pysdf_tools(force, verbose)
     if p:
         out.append(p)
+    out.append(build_example("class_seam", force, verbose))     # (bench.py's host_api.class_seam runs it on the GPU box)
     return out
 
 

@@ -11,6 +11,7 @@
 #include "sdfgpu_policy.hpp"
 
 #include <sys/mman.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -56,6 +57,9 @@ struct sdfgpu_context {
     DeviceBuffer tagmask;    // uint8 [N] mask produced by the tagged-object classify kernel
     DeviceBuffer tagids;     // uint32 object id filter
     DeviceBuffer stage_in;   // host-API staging: mask / cells
+    DeviceBuffer stage_bits; // host-API staging: the host-classified bit field (1 bit per voxel, linear order)
+    int host_pack = 1;       // host-buffer builds classify on the host and upload bits (option "host_pack"; 0 = upload the
+                             // caller's mask / cells and classify on the device, as rounds 1 - 4 did)
     DeviceBuffer stage_out;  // host-API staging: sdf
     DeviceBuffer query_stage;   // host-API staging of sdfgpu_query_points: points | distance | gradient | flags
     size_t tag_cached_bytes = 0;            // stage_in holds the tagged cell records of the last sdfgpu_build_tagged_cells call
@@ -1118,42 +1122,64 @@ int copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, hi
 // the runtime's staging copy on one host thread (measured: 128 MiB in 24 - 30 ms, i.e. 5 GB/s, where the link does 52);
 // here a team of threads fills the two pinned chunks and the DMA of one chunk overlaps the filling of the next.
 // Enqueued on `st`; returns when the last chunk's DMA has completed.
-int copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, hipStream_t st = nullptr) {
+// `fill(dst, out_offset, len)` produces bytes [out_offset, out_offset + len) of the upload into dst (slices are multiples
+// of 4096 bytes except the last): a plain memcpy for copy_from_host, the cells / mask -> bits classification for the
+// host-buffer builds (round 5), which is what makes the team worth more than a copy -- it reads 8 or 64 bytes per byte sent.
+template <class Fill>
+int staged_upload(sdfgpu_handle h, void* d_dst, size_t bytes, hipStream_t st, int team_cap, Fill fill) {
     if (bytes == 0) return SDFGPU_OK;
-    for (int i = 0; i < 2 && bytes >= kPinMin; ++i) {
+    for (int i = 0; i < 2; ++i) {
         if (!h->pin[i] && hipHostMalloc(&h->pin[i], kPinChunk, hipHostMallocDefault) != hipSuccess) h->pin[i] = nullptr;
         if (h->pin[i] && !h->pin_ev[i] && hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) h->pin_ev[i] = nullptr;
     }
-    if (bytes < kPinMin || !h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
-        HIP_TRY(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(h, hipStreamSynchronize(st));
-        return SDFGPU_OK;
-    }
+    if (!h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1])
+        return fail(h, SDFGPU_ERR_HIP, "no pinned staging memory for the host-to-device copy");
     const int64_t nchunks = (int64_t)((bytes + kPinChunk - 1) / kPinChunk);
     const unsigned hw = std::thread::hardware_concurrency();
-    const int team = (int)std::max<size_t>(1, std::min<size_t>(16, hw / 4));
+    const int team = (int)std::max<size_t>(1, std::min<size_t>((size_t)team_cap, hw / 4));
     std::atomic<int64_t> may_fill{1};                    // chunks 0 .. may_fill may be written to their staging buffer
     std::atomic<int64_t> filled{0};                      // slices filled so far (team slices per chunk)
     std::atomic<bool> abort{false};
     auto chunk_bytes = [&](int64_t i) { return std::min(kPinChunk, bytes - (size_t)i * kPinChunk); };
+    auto work = [&](int w) {
+        for (int64_t i = 0; i < nchunks; ++i) {
+            while (may_fill.load(std::memory_order_acquire) < i) {
+                if (abort.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const size_t len = chunk_bytes(i);
+            const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
+            const size_t b = std::min(len, (size_t)w * per), e = std::min(len, b + per);
+            if (e > b) fill(static_cast<char*>(h->pin[i & 1]) + b, (size_t)i * kPinChunk + b, e - b);
+            filled.fetch_add(1, std::memory_order_release);
+        }
+    };
     std::vector<std::thread> workers;
     workers.reserve((size_t)team);
-    for (int w = 0; w < team; ++w) {
-        workers.emplace_back([&, w]() {
-            for (int64_t i = 0; i < nchunks; ++i) {
-                while (may_fill.load(std::memory_order_acquire) < i) {
-                    if (abort.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
-                }
-                const size_t len = chunk_bytes(i);
-                const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
-                const size_t b = std::min(len, (size_t)w * per), e = std::min(len, b + per);
-                if (e > b) memcpy(static_cast<char*>(h->pin[i & 1]) + b, static_cast<const char*>(src) + (size_t)i * kPinChunk + b, e - b);
-                filled.fetch_add(1, std::memory_order_release);
-            }
-        });
-    }
+    for (int w = 1; w < team; ++w) workers.emplace_back(work, w);
     hipError_t err = hipSuccess;
+    // (the calling thread is slice 0 of the first chunk -- a one-chunk upload, 16 MiB of bits for 512^3, would otherwise only wait)
+    {
+        const size_t len = chunk_bytes(0);
+        const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
+        const size_t e = std::min(len, per);
+        if (e > 0) fill(static_cast<char*>(h->pin[0]), 0, e);
+        filled.fetch_add(1, std::memory_order_release);
+    }
+    std::thread rest;                                    // ... and hands its slices of the later chunks to one more worker
+    if (nchunks > 1) rest = std::thread([&]() {
+        for (int64_t i = 1; i < nchunks; ++i) {
+            while (may_fill.load(std::memory_order_acquire) < i) {
+                if (abort.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const size_t len = chunk_bytes(i);
+            const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
+            const size_t e = std::min(len, per);
+            if (e > 0) fill(static_cast<char*>(h->pin[i & 1]), (size_t)i * kPinChunk, e);
+            filled.fetch_add(1, std::memory_order_release);
+        }
+    });
     for (int64_t i = 0; i < nchunks && err == hipSuccess; ++i) {
         while (filled.load(std::memory_order_acquire) < (i + 1) * team) std::this_thread::yield();
         err = hipMemcpyAsync(static_cast<char*>(d_dst) + (size_t)i * kPinChunk, h->pin[i & 1], chunk_bytes(i), hipMemcpyHostToDevice, st);
@@ -1166,12 +1192,105 @@ int copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, 
     }
     if (err != hipSuccess) abort.store(true);
     for (std::thread& w : workers) w.join();
+    if (rest.joinable()) rest.join();
     if (err == hipSuccess) err = hipEventSynchronize(h->pin_ev[(nchunks - 1) & 1]);
     if (err == hipSuccess && nchunks > 1) err = hipEventSynchronize(h->pin_ev[(nchunks - 2) & 1]);
     if (err != hipSuccess) {
         (void)hipDeviceSynchronize();
         return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) in the host-to-device copy", (int)err, hipGetErrorString(err));
     }
+    return SDFGPU_OK;
+}
+
+int copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, hipStream_t st = nullptr) {
+    if (bytes == 0) return SDFGPU_OK;
+    if (bytes < kPinMin) {
+        HIP_TRY(h, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipStreamSynchronize(st));
+        return SDFGPU_OK;
+    }
+    return staged_upload(h, d_dst, bytes, st, 16, [src](char* dst, size_t o, size_t len) { memcpy(dst, static_cast<const char*>(src) + o, len); });
+}
+
+// ---- host-side classification: cells / mask -> one bit per voxel (round 5) ----------------------------------
+// Bit (v & 7) of byte (v >> 3) = voxel v is filled, with the predicates of the device classifiers: mask byte != 0;
+// occupancy > 0.5f || (unknown_is_filled && occupancy == 0.5f) (collision_map.hpp:689-704 -- the reference compares the float
+// with the double 0.5, which is the float 0.5f exactly; NaN is "free" in both).  out[0 .. len) covers voxels
+// [8 ob, 8 (ob + len)); bits of voxels >= n are 0.
+void pack_mask_bits(const uint8_t* m, int64_t n, size_t ob, size_t len, uint8_t* out) {
+    const int64_t v0 = (int64_t)ob * 8, v1 = std::min<int64_t>(n, v0 + (int64_t)len * 8);
+    int64_t v = v0;
+    size_t o = 0;
+    const __m128i zero = _mm_setzero_si128();
+    for (; v + 16 <= v1; v += 16, o += 2) {
+        const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i*>(m + v));
+        const uint32_t nz = ~(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, zero)) & 0xffffu;
+        out[o] = (uint8_t)nz; out[o + 1] = (uint8_t)(nz >> 8);
+    }
+    for (; o < len; ++o) {
+        uint32_t b = 0;
+        for (int k = 0; k < 8; ++k, ++v) if (v < v1 && m[v]) b |= 1u << k;
+        out[o] = (uint8_t)b;
+    }
+}
+void pack_cells_bits(const char* cells, size_t stride, size_t off, int unknown, int64_t n, size_t ob, size_t len, uint8_t* out) {
+    const int64_t v0 = (int64_t)ob * 8, v1 = std::min<int64_t>(n, v0 + (int64_t)len * 8);
+    int64_t v = v0;
+    size_t o = 0;
+    if (stride == 8 && (off == 0 || off == 4)) {                // COLLISION_CELL {float occupancy; uint32 component}: 4 records per pair of loads
+        const __m128 half = _mm_set1_ps(0.5f);
+        const __m128 unk = _mm_castsi128_ps(_mm_set1_epi32(unknown ? -1 : 0));
+        const char* p = cells + (size_t)v0 * 8;
+        for (; v + 8 <= v1; v += 8, ++o, p += 64) {
+            uint32_t b = 0;
+            for (int g = 0; g < 2; ++g) {
+                const __m128 a0 = _mm_loadu_ps(reinterpret_cast<const float*>(p + 32 * g));
+                const __m128 a1 = _mm_loadu_ps(reinterpret_cast<const float*>(p + 32 * g + 16));
+                const __m128 occ = off == 0 ? _mm_shuffle_ps(a0, a1, _MM_SHUFFLE(2, 0, 2, 0)) : _mm_shuffle_ps(a0, a1, _MM_SHUFFLE(3, 1, 3, 1));
+                const __m128 f = _mm_or_ps(_mm_cmpgt_ps(occ, half), _mm_and_ps(_mm_cmpeq_ps(occ, half), unk));
+                b |= (uint32_t)_mm_movemask_ps(f) << (4 * g);
+            }
+            out[o] = (uint8_t)b;
+        }
+    }
+    for (; o < len; ++o) {
+        uint32_t b = 0;
+        for (int k = 0; k < 8; ++k, ++v) {
+            if (v >= v1) continue;
+            float occ;
+            memcpy(&occ, cells + (size_t)v * stride + off, 4);
+            if (occ > 0.5f || (unknown && occ == 0.5f)) b |= 1u << k;
+        }
+        out[o] = (uint8_t)b;
+    }
+}
+
+// Host cells / mask -> bits (team) -> device -> byte mask in stage_in.  Returns the device mask in *d_mask.
+int upload_packed(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t stride, size_t off, int unknown, int64_t n,
+                  const uint8_t** d_mask) {
+    const size_t nbytes = ((size_t)n + 7) / 8, padded = (nbytes + 3) & ~(size_t)3;
+    if (int rc = ensure(h, h->stage_bits, padded)) return rc;
+    if (int rc = ensure(h, h->stage_in, (size_t)n)) return rc;
+    auto fill = [=](char* dst, size_t o, size_t len) {
+        const size_t real = o >= nbytes ? 0 : std::min(len, nbytes - o);
+        if (real) {
+            if (cells) pack_cells_bits(static_cast<const char*>(cells), stride, off, unknown, n, o, real, reinterpret_cast<uint8_t*>(dst));
+            else pack_mask_bits(filled, n, o, real, reinterpret_cast<uint8_t*>(dst));
+        }
+        if (real < len) memset(dst + real, 0, len - real);
+    };
+    if (padded >= ((size_t)256 << 10)) {
+        if (int rc = staged_upload(h, h->stage_bits.ptr, padded, nullptr, 32, fill)) return rc;
+    } else {                                                    // small grids: one thread, one runtime-staged copy
+        std::vector<char> tmp(padded);
+        fill(tmp.data(), 0, padded);
+        HIP_TRY(h, hipMemcpy(h->stage_bits.ptr, tmp.data(), padded, hipMemcpyHostToDevice));
+    }
+    const int64_t nch = (n + 15) / 16;
+    hipLaunchKernelGGL(k_unpack_bits_mask, dim3((unsigned)((nch + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
+                       (const uint32_t*)h->stage_bits.ptr, (uint8_t*)h->stage_in.ptr, n);
+    HIP_TRY(h, hipGetLastError());
+    *d_mask = (const uint8_t*)h->stage_in.ptr;
     return SDFGPU_OK;
 }
 
@@ -1186,18 +1305,26 @@ int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, s
     const int64_t n = nx * ny * nz;
     const size_t in_bytes = cells ? (size_t)n * stride : (size_t)n;
     h->tag_cached_bytes = 0;                        // (stage_in is about to be overwritten)
-    if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
+    // Round 5: the host's thread team classifies the caller's buffer into one bit per voxel while it fills the pinned staging
+    // chunk, and 1/8 B per voxel crosses PCIe (16 MiB at 512^3 instead of 128 MiB of mask or 1 GiB of COLLISION_CELL records);
+    // k_unpack_bits_mask spreads them into the byte mask on the device.  Same predicate as the device classifier
+    // (pack_cells_bits); "host_pack" = 0 keeps the upload-and-classify-on-device path (device-resident cells always take it).
+    const bool packed = h->host_pack == 2 || (h->host_pack == 1 && in_bytes >= kPinMin);
+    if (!packed) if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
     if (!d_out_user) if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
     float* const d_out = d_out_user ? d_out_user : (float*)h->stage_out.ptr;
     const bool timing = getenv("SDFGPU_HOST_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t1 = now();
     // (out_sdf is scratch from here on: include/sdfgpu.h documents that its contents are undefined when the call fails)
-    if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes)) return rc0;
+    const uint8_t* d_mask = nullptr;
+    if (packed) { if (int rc0 = upload_packed(h, filled, cells, stride, off, unknown, n, &d_mask)) return rc0; }
+    else if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes)) return rc0;
     const double t2 = now();
-    int rc = build_device_impl(h, cells ? nullptr : (const uint8_t*)h->stage_in.ptr,
-                               cells ? h->stage_in.ptr : nullptr, stride, off, unknown, nx, ny, nz, resolution,
-                               vb, d_out, nullptr);
+    int rc = packed ? build_device_impl(h, d_mask, nullptr, 0, 0, 0, nx, ny, nz, resolution, vb, d_out, nullptr)
+                    : build_device_impl(h, cells ? nullptr : (const uint8_t*)h->stage_in.ptr,
+                                        cells ? h->stage_in.ptr : nullptr, stride, off, unknown, nx, ny, nz, resolution,
+                                        vb, d_out, nullptr);
     if (rc) return rc;
     const double t3 = now();
     if (!d_out_user) if (int rc2 = copy_to_host(h, out_sdf, h->stage_out.ptr, (size_t)n * 4)) return rc2;
@@ -1265,7 +1392,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
     for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->unc, &h->tileflag, &h->fix_order, &h->tagmask, &h->tagids, &h->stage_in,
-                            &h->stage_out, &h->query_stage})
+                            &h->stage_bits, &h->stage_out, &h->query_stage})
         if (b->ptr) (void)hipFree(b->ptr);
     if (h->d_small) (void)hipFree(h->d_small);
     if (h->d_slots) (void)hipFree(h->d_slots);
@@ -1367,8 +1494,9 @@ int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min) {
     if (!h->have_result) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no build has been issued on this handle");
     HIP_TRY(h, hipSetDevice(h->device));
     uint32_t v[4];
-    HIP_TRY(h, hipMemcpyAsync(v, h->d_result, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
-    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    // (the build's own event, not its stream: the stream is the caller's and may be gone by now -- ADVICE r4)
+    if (h->order_valid) HIP_TRY(h, hipEventSynchronize(h->build_done_ev));
+    HIP_TRY(h, hipMemcpy(v, h->d_result, sizeof v, hipMemcpyDeviceToHost));
     return sdfgpu_extrema_from_dsq(v[0], v[1], h->last_resolution, out_max, out_min);
 }
 
@@ -1784,7 +1912,11 @@ int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t
     const size_t o_d = n * 24, o_g = o_d + n * 8, o_f = o_g + n * 24, total = o_f + ((n + 255) & ~(size_t)255);
     if (int rc = ensure(h, h->query_stage, total)) return rc;
     char* base = (char*)h->query_stage.ptr;
-    hipStream_t s = h->last_stream;                  // (ordered behind the build that produced the field, if it ran on this handle)
+    // Round 5: the null stream of the context's device, ordered behind this handle's last build by its event --
+    // not h->last_stream, which is a handle of the CALLER's (an earlier *_device build's stream may have been destroyed since).
+    // A field produced elsewhere (another handle, an upload) is ordered by the null stream's implicit synchronisation.
+    hipStream_t s = nullptr;
+    if (h->order_valid && h->order_stream != nullptr) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
     if (int rc = copy_from_host(h, base, points, n * 24, s)) return rc;
     if (int rc = sdfgpu_query_points_device(h, d_sdf, nx, ny, nz, resolution, world_to_grid, grid_to_world_rotation, oob_value,
                                             (const double*)base, n_points, enable_edge_gradients,
@@ -1803,7 +1935,7 @@ int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {
     if (h->last_fused) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "the last build fused the z sweep into the y sweep: no z field exists");
     if (h->last_standby) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "the last build's stand-by pair takes its z distances from the bit field: no z field exists");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    if (h->order_valid) HIP_TRY(h, hipEventSynchronize(h->build_done_ev));
     HIP_TRY(h, hipMemcpy(out_host, h->zfield.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
     return SDFGPU_OK;
 }
@@ -1812,7 +1944,7 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n) {
     if (!h || !out_host) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!h->have_result || n > h->last_n) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no matching build");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    if (h->order_valid) HIP_TRY(h, hipEventSynchronize(h->build_done_ev));
     HIP_TRY(h, hipMemcpy(out_host, h->yzfield.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // status block of the last build ([7]: int32 hand-off used)
     HIP_TRY(h, hipMemcpy(st, h->d_result, sizeof st, hipMemcpyDeviceToHost));
@@ -1893,6 +2025,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
 #endif
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "standby_far") h->standby_far = value != 0;
+    else if (n == "host_pack") h->host_pack = (value >= 0 && value <= 2) ? value : 1;
     else if (n == "standby_grid") h->standby_grid = value >= 32 ? value : 1024;
     else if (n == "expect_dense") h->pol.expect_dense = value != 0;      // tests: put the handle into the "dense tier trusted" state
     else if (n == "pack_variant") h->pack_variant = value;
@@ -1932,8 +2065,9 @@ int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified) {
     if (!h->have_result) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "no build has been issued on this handle");
     HIP_TRY(h, hipSetDevice(h->device));
     uint32_t v[8];
-    HIP_TRY(h, hipMemcpyAsync(v, h->d_result, sizeof v, hipMemcpyDeviceToHost, h->last_stream));
-    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    // (the build's own event, not its stream: the stream is the caller's and may be gone by now -- ADVICE r4)
+    if (h->order_valid) HIP_TRY(h, hipEventSynchronize(h->build_done_ev));
+    HIP_TRY(h, hipMemcpy(v, h->d_result, sizeof v, hipMemcpyDeviceToHost));
     // bit 0: dense kernel decided everything; bit 1 / 2: the y / x sweep was redone by the envelope kernel
     uint32_t why = 0;
     HIP_TRY(h, hipMemcpy(&why, h->d_result + 21, sizeof why, hipMemcpyDeviceToHost));

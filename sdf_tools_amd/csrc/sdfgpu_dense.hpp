@@ -81,6 +81,27 @@ __global__ __launch_bounds__(kBlock) void k_pack_bits_generic(Loader ld, uint32_
     }
 }
 
+// The reverse of K0 for the host-buffer entry points (round 5): the host's thread team classifies the caller's cells / mask
+// into ONE BIT per voxel while it fills the pinned staging chunk (1/8 B per voxel over PCIe instead of 1 B of mask or 8 B of
+// COLLISION_CELL records: 16 MiB instead of 1 GiB at 512^3), and this kernel spreads the bits back into the 0 / 1 byte mask
+// every tier's first kernel reads.  Linear bit order: bit (v & 31) of word (v >> 5) = voxel v.  A lane writes 16 bytes, a
+// wave one contiguous 1 KiB per store instruction; 1/8 B read + 1 B written per voxel (~30 us at 512^3).
+__global__ __launch_bounds__(kBlock) void k_unpack_bits_mask(const uint32_t* __restrict__ bits, uint8_t* __restrict__ mask, int64_t n) {
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;       // 16-voxel chunk index
+    const int64_t v0 = 16 * c;
+    if (v0 >= n) return;
+    const uint32_t b = (bits[c >> 1] >> ((c & 1) * 16)) & 0xffffu;
+    auto spread4 = [](uint32_t x) -> uint32_t {                         // bits 0..3 -> bytes 0..3 (0 / 1)
+        return ((x & 1u) | ((x & 2u) << 7) | ((x & 4u) << 14) | ((x & 8u) << 21));
+    };
+    const uint4 o = make_uint4(spread4(b), spread4(b >> 4), spread4(b >> 8), spread4(b >> 12));
+    if (v0 + 16 <= n && (reinterpret_cast<uintptr_t>(mask) & 15) == 0) {
+        *reinterpret_cast<uint4*>(mask + v0) = o;
+    } else {
+        for (int k = 0; k < 16 && v0 + k < n; ++k) mask[v0 + k] = (uint8_t)((b >> k) & 1u);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // KD: dense ball kernel.
 // ---------------------------------------------------------------------------------------------

@@ -625,7 +625,11 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 } else if (STAGE == 2 && a.bits) {
                     // stand-by: z distances straight from the dense tier's bit field.  The LPR = 4 lanes of a tile row are one
                     // DPP quad (sub = t & 3) and the tile's 16 lines lie in ONE word of the bit row (c0 is a multiple of 16)
-                    static_assert(LPR == 4, "the lanes of a tile row must be one DPP quad");
+                    static_assert(LPR == 4 && NL == 16, "the lanes of a tile row must be one DPP quad");
+                    static_assert(NT % 64 == 0, "zrow_scan_quad's quad permutes need whole waves");
+#ifdef SDFGPU_DEBUG_HOOKS
+                    if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();     // (a partial wave would read zeros from its inactive lanes)
+#endif
                     const int prow = (pb + PP * it + r < L) ? pb + PP * it + r : L - 1;
                     const int w0 = (int)(c0 >> 5);
                     const ZRowBits zr = zrow_scan_quad(a.bits + (o * a.ny + prow) * a.nzw, a.nzw, w0, sub);
