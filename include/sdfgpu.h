@@ -151,6 +151,17 @@ int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min);
 int sdfgpu_copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, void* stream);
 int sdfgpu_copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, void* stream);
 
+/* Host occupancy -> device byte mask, classified ON THE HOST while the pinned staging chunks are filled (round 5): the team
+ * of host threads evaluates the predicate -- mask byte != 0 (filled != NULL), or the CollisionMapGrid predicate
+ * occupancy > 0.5f || (unknown_is_filled && occupancy == 0.5f) on raw cell records (cells != NULL; reference
+ * include/sdf_tools/collision_map.hpp:689-704) -- into ONE BIT per voxel, 1/8 byte per voxel crosses PCIe (16 MiB for 512^3
+ * instead of 128 MiB of mask or 1 GiB of 8-byte cells), and a kernel on `stream` spreads the bits into d_mask[n] (0 / 1).
+ * This is what sdfgpu_build / sdfgpu_build_cells / *_to_device do with their input (option "host_pack" = 0 restores the
+ * upload-and-classify-on-device path); exported for wrappers with their own device buffers (libsdfgpu_multi's per-rank
+ * slabs).  Exactly one of filled / cells is non-NULL.  Returns when the host buffer has been consumed. */
+int sdfgpu_upload_classified(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                             int unknown_is_filled, int64_t n_voxels, uint8_t* d_mask, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Stage-level entry points for the x-slab multi-GPU path.
  * The grid is partitioned along x (the slowest axis); a rank owns rows
@@ -375,7 +386,10 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * with whole rows per wave where nz is 64 ... 1024 and a power of two, default; 0 = the workgroup form), "standby_far" (1 = behind a
  * dense tier the handle trusts, the guarded general pipeline is the far-field kernel pair -- two launches, bounded on any scene --
  * default; 0 = the fused z+y sweep + the marching x sweep with unbounded scans), "standby_grid" (workgroups of those stand-by
- * launches, default 1024), "expect_dense" (tests: 1 = put the handle into the "dense tier trusted" state for the next build).
+ * launches, default 1024), "expect_dense" (tests: 1 = put the handle into the "dense tier trusted" state for the next build),
+ * "host_pack" (host-buffer entry points: 1 = inputs of 4 MiB and more are classified into one bit per voxel by the host's
+ * thread team and 1/8 B per voxel is uploaded, default; 0 = upload the caller's mask / cells and classify on the device;
+ * 2 = classify on the host whatever the size -- sdfgpu_upload_classified).
  * Every option leaves the results exact: switches that
  * skip work for profiling ("dc_debug", "ball_variant") exist only in libraries built with -DSDFGPU_DEBUG_HOOKS and are
  * rejected with SDFGPU_ERR_INVALID_ARGUMENT by the shipped one. */

@@ -72,9 +72,17 @@ int sdfgpu_multi_last_path(sdfgpu_multi_handle h, int* out_bits);
  * synchronous); an uncertified dense attempt adds one, a wrong "near-field" prediction adds one. */
 int sdfgpu_multi_last_stats(sdfgpu_multi_handle h, int* out_host_reads, int* out_mispredictions);
 
+/* Host time of the last build (round 5): every rank has its own host thread (rank 0 = the caller), which issues that rank's
+ * launches, event calls and its own ncclSend / ncclRecv group -- so a build costs the host what ONE rank's calls cost,
+ * whatever the rank count.  *out_max_rank_us = the slowest rank thread's time inside API calls (waiting for the device
+ * excluded), *out_sum_us = the sum over the rank threads (what a single issuing thread would have spent). */
+int sdfgpu_multi_last_host_us(sdfgpu_multi_handle h, double* out_max_rank_us, double* out_sum_us);
+
 /* Option passed to every rank's sdfgpu context (sdfgpu_set_option), plus "halo" (int32 planes exchanged per side on
  * the near-field general path, default 3), "dense" (0 = skip the dense tier) and "predict_far" (the general path's
- * prediction of its x sweep: 1 = complete lines, 0 = halo; normally learned from the previous general build). */
+ * prediction of its x sweep: 1 = complete lines, 0 = halo; normally learned from the previous general build) and
+ * "dense_retry" (after a dense attempt that did not certify the scene the next n builds leave the dense tier out, n doubling
+ * while the attempts keep failing; default 15, 0 = try it in every build). */
 int sdfgpu_multi_set_option(sdfgpu_multi_handle h, const char* name, int value);
 
 #ifdef __cplusplus

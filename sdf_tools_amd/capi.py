@@ -25,7 +25,7 @@ EXPORTS = [
     "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
     "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
     "sdfgpu_copy_to_host", "sdfgpu_copy_from_host", "sdfgpu_query_points", "sdfgpu_device_malloc", "sdfgpu_device_free",
-    "sdfgpu_build_to_device", "sdfgpu_build_cells_to_device",
+    "sdfgpu_build_to_device", "sdfgpu_build_cells_to_device", "sdfgpu_upload_classified",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library():
     L.sdfgpu_set_profiling.argtypes = [vp, ci]
     L.sdfgpu_copy_to_host.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
     L.sdfgpu_copy_from_host.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
+    L.sdfgpu_upload_classified.argtypes = [vp, vp, vp, sz, sz, ci, i64, vp, vp]
     L.sdfgpu_get_stage_times.argtypes = [vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -318,6 +319,23 @@ class SdfGpu:
         a = np.ascontiguousarray(src)
         self._check(self._lib.sdfgpu_copy_from_host(self._h, int(d_dst), a.ctypes.data, a.nbytes, int(stream)))
 
+    def upload_classified(self, d_mask, filled=None, cells=None, cell_stride=8, occupancy_offset=0, unknown_is_filled=False,
+                          stream=0):
+        """Host mask (uint8 array) or raw cell records -> device byte mask (0 / 1), classified on the host, 1 bit per voxel
+        over PCIe (sdfgpu_upload_classified)."""
+        if (filled is None) == (cells is None):
+            raise ValueError("exactly one of filled / cells")
+        if filled is not None:
+            a = np.ascontiguousarray(filled, dtype=np.uint8)
+            n = a.size
+            self._check(self._lib.sdfgpu_upload_classified(self._h, a.ctypes.data, None, 0, 0, 0, n, int(d_mask), int(stream) or None))
+        else:
+            a = np.ascontiguousarray(cells)
+            n = a.nbytes // cell_stride
+            self._check(self._lib.sdfgpu_upload_classified(self._h, None, a.ctypes.data, cell_stride, occupancy_offset,
+                                                           int(bool(unknown_is_filled)), n, int(d_mask), int(stream) or None))
+        return n
+
     def gradient(self, sdf, resolution=1.0, enable_edge_gradients=True, f64=True):
         """Host-buffer full-grid gradient: sdf float32 [nx,ny,nz] -> [nx,ny,nz,3] (NaN where the reference has none)."""
         f = np.ascontiguousarray(sdf, dtype=np.float32)
@@ -383,7 +401,7 @@ class SdfGpu:
 MULTI_EXPORTS = [
     "sdfgpu_multi_create", "sdfgpu_multi_destroy", "sdfgpu_multi_last_error", "sdfgpu_multi_ranks",
     "sdfgpu_multi_slab_range", "sdfgpu_multi_build", "sdfgpu_multi_build_cells", "sdfgpu_multi_build_device",
-    "sdfgpu_multi_last_path", "sdfgpu_multi_set_option", "sdfgpu_multi_last_stats",
+    "sdfgpu_multi_last_path", "sdfgpu_multi_set_option", "sdfgpu_multi_last_stats", "sdfgpu_multi_last_host_us",
 ]
 _multi_lib = None
 
@@ -410,6 +428,7 @@ def load_multi_library():
     L.sdfgpu_multi_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
     L.sdfgpu_multi_last_path.argtypes = [vp, vp]
     L.sdfgpu_multi_last_stats.argtypes = [vp, vp, vp]
+    L.sdfgpu_multi_last_host_us.argtypes = [vp, vp, vp]
     L.sdfgpu_multi_set_option.argtypes = [vp, ctypes.c_char_p, ci]
     for name in MULTI_EXPORTS:
         if name != "sdfgpu_multi_last_error":
@@ -463,10 +482,14 @@ class MultiSdfGpu:
 
     def last_stats(self):
         """{'host_reads': status-block round trips of the last build, 'mispredictions': general builds since creation
-        whose predicted x sweep had to be redone}."""
+        whose predicted x sweep had to be redone, 'host_us_max_rank' / 'host_us_sum': host time of the last build inside API
+        calls -- the slowest rank thread / the sum over the rank threads (sdfgpu_multi_last_host_us)}."""
         a, b = ctypes.c_int(), ctypes.c_int()
         self._check(self._lib.sdfgpu_multi_last_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
-        return {"host_reads": int(a.value), "mispredictions": int(b.value)}
+        mx, sm = ctypes.c_double(), ctypes.c_double()
+        self._check(self._lib.sdfgpu_multi_last_host_us(self._h, ctypes.byref(mx), ctypes.byref(sm)))
+        return {"host_reads": int(a.value), "mispredictions": int(b.value),
+                "host_us_max_rank": float(mx.value), "host_us_sum": float(sm.value)}
 
     def build(self, filled, resolution=1.0, add_virtual_border=False):
         m = np.ascontiguousarray(filled, dtype=np.uint8)

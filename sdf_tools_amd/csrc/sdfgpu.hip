@@ -1265,12 +1265,12 @@ void pack_cells_bits(const char* cells, size_t stride, size_t off, int unknown, 
     }
 }
 
-// Host cells / mask -> bits (team) -> device -> byte mask in stage_in.  Returns the device mask in *d_mask.
+// Host cells / mask -> bits (team) -> device -> byte mask at d_mask_dst (n bytes), enqueued on `st`; the host buffer has been
+// consumed when this returns (the unpack kernel is stream-ordered behind the upload).
 int upload_packed(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t stride, size_t off, int unknown, int64_t n,
-                  const uint8_t** d_mask) {
+                  uint8_t* d_mask_dst, hipStream_t st) {
     const size_t nbytes = ((size_t)n + 7) / 8, padded = (nbytes + 3) & ~(size_t)3;
     if (int rc = ensure(h, h->stage_bits, padded)) return rc;
-    if (int rc = ensure(h, h->stage_in, (size_t)n)) return rc;
     auto fill = [=](char* dst, size_t o, size_t len) {
         const size_t real = o >= nbytes ? 0 : std::min(len, nbytes - o);
         if (real) {
@@ -1280,17 +1280,17 @@ int upload_packed(sdfgpu_handle h, const uint8_t* filled, const void* cells, siz
         if (real < len) memset(dst + real, 0, len - real);
     };
     if (padded >= ((size_t)256 << 10)) {
-        if (int rc = staged_upload(h, h->stage_bits.ptr, padded, nullptr, 32, fill)) return rc;
+        if (int rc = staged_upload(h, h->stage_bits.ptr, padded, st, 32, fill)) return rc;
     } else {                                                    // small grids: one thread, one runtime-staged copy
         std::vector<char> tmp(padded);
         fill(tmp.data(), 0, padded);
-        HIP_TRY(h, hipMemcpy(h->stage_bits.ptr, tmp.data(), padded, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpyAsync(h->stage_bits.ptr, tmp.data(), padded, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipStreamSynchronize(st));                   // (tmp goes out of scope)
     }
     const int64_t nch = (n + 15) / 16;
-    hipLaunchKernelGGL(k_unpack_bits_mask, dim3((unsigned)((nch + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr,
-                       (const uint32_t*)h->stage_bits.ptr, (uint8_t*)h->stage_in.ptr, n);
+    hipLaunchKernelGGL(k_unpack_bits_mask, dim3((unsigned)((nch + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       (const uint32_t*)h->stage_bits.ptr, d_mask_dst, n);
     HIP_TRY(h, hipGetLastError());
-    *d_mask = (const uint8_t*)h->stage_in.ptr;
     return SDFGPU_OK;
 }
 
@@ -1318,7 +1318,11 @@ int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, s
     const double t1 = now();
     // (out_sdf is scratch from here on: include/sdfgpu.h documents that its contents are undefined when the call fails)
     const uint8_t* d_mask = nullptr;
-    if (packed) { if (int rc0 = upload_packed(h, filled, cells, stride, off, unknown, n, &d_mask)) return rc0; }
+    if (packed) {
+        if (int rc0 = ensure(h, h->stage_in, (size_t)n)) return rc0;
+        if (int rc0 = upload_packed(h, filled, cells, stride, off, unknown, n, (uint8_t*)h->stage_in.ptr, nullptr)) return rc0;
+        d_mask = (const uint8_t*)h->stage_in.ptr;
+    }
     else if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes)) return rc0;
     const double t2 = now();
     int rc = packed ? build_device_impl(h, d_mask, nullptr, 0, 0, 0, nx, ny, nz, resolution, vb, d_out, nullptr)
@@ -1469,6 +1473,17 @@ int sdfgpu_copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t 
     if (bytes > 0 && (!d_dst || !src)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     return copy_from_host(h, d_dst, src, bytes, (hipStream_t)stream);
+}
+
+int sdfgpu_upload_classified(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                             int unknown_is_filled, int64_t n, uint8_t* d_mask, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if ((!filled && !cells) || !d_mask) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
+    if (n <= 0) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "voxel count must be positive");
+    if (cells && (cell_stride < 4 || (cell_stride % 4) || (occupancy_offset % 4) || occupancy_offset + 4 > cell_stride))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return upload_packed(h, cells ? nullptr : filled, cells, cell_stride, occupancy_offset, unknown_is_filled, n, d_mask, (hipStream_t)stream);
 }
 
 int sdfgpu_extrema_from_dsq(uint32_t max_dsq_free, uint32_t max_dsq_filled, double resolution, double* out_max,

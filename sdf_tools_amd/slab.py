@@ -412,12 +412,14 @@ class SlabSdfBuilder:
             self._allreduce_small(small)
             max_f, max_q, status, hinted = (int(v) for v in small.tolist())
             self.host_reads += 1
-            if not status and not hinted:
-                return max_f, max_q
-            # far-field scene, or some voxel needed a plane beyond its halo: sweep complete lines after all
-            self.mispredictions += 1
+            # Only an UNRESOLVED voxel (status) forces the redo: with every voxel resolved inside the halo the result is exact
+            # already, whatever the hint says -- the hint then only steers the next build's prediction.
             self.predict_far = bool(hinted)
-            if status and not hinted:
+            if not status:
+                return max_f, max_q
+            # some voxel needed a plane beyond its halo: sweep complete lines after all
+            self.mispredictions += 1
+            if not hinted:
                 self.whole_hold = 8             # near-field clutter with a cavity deeper than the halo: do not flap
         elif self.whole_hold > 0:
             self.whole_hold -= 1

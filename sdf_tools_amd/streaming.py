@@ -13,6 +13,8 @@ one lane per point).  That is the default (``gradient="query"``, round 4): a fra
 of ``GetFullGradient`` callers (sdf.hpp:341-358, utils_3d.py:77-80) is still there as ``gradient="full"``.
 The context's scratch buffers are allocated once and re-used by every frame.
 """
+import warnings
+
 import torch
 
 from . import capi
@@ -43,6 +45,7 @@ class StreamingSdf:
                                         device=self.device)
 
         self._q = None                                  # (distance, gradient, flags) buffers of query-mode frames
+        self._warned = False
 
     def frame(self, points, query_points=None, enable_edge_gradients=True):
         """points: [n, 3] float32 device tensor (x, y, z).  Asynchronous on the current stream.
@@ -59,6 +62,13 @@ class StreamingSdf:
                                      self.grad_f64, s)
         if self.mode == "query":
             if query_points is None:
+                # (until round 3 the default was gradient=True and `sdf, grad = s.frame(points)` returned the
+                #  full-grid gradient; in query mode the second value is None without query points -- say so once)
+                if not self._warned:
+                    self._warned = True
+                    warnings.warn("StreamingSdf(gradient='query').frame() called without query_points: no gradient is "
+                                  "computed (returns (sdf, None)); pass query_points, or construct with gradient='full' "
+                                  "for the full-grid gradient that was the default before round 4", stacklevel=2)
                 return self.sdf, None
             m = query_points.shape[0]
             if self._q is None or self._q[0].shape[0] < m:

@@ -110,3 +110,36 @@ def test_cpp_device_queries_without_downloading_the_field(n, points):
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "device queries OK" in r.stdout and "no field download" in r.stdout
+
+
+def _build_seam():
+    from sdf_tools_amd import build as b
+    return b.build_example("class_seam")
+
+
+def test_cpp_class_seam_compiles_and_refuses_without_gpu():
+    from sdf_tools_amd import capi
+    exe = _build_seam()
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, "--no-gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,budget_ms", [(96, None), (512, 60.0)])
+def test_cpp_class_seam_is_bit_identical_and_bounded(n, budget_ms):
+    """VERDICT r4 "next round" 3: CollisionMapGrid::ExtractSignedDistanceField (collision_map.hpp:680-712) end to end from a
+    C++ client -- host cells in, host SignedDistanceField out -- equals sdfgpu_build on the same predicate's mask bit for bit
+    (the client checks it, and that the returned field was MOVED, not copied), and at 512^3 stays inside a latency budget
+    (round 4: 241 ms; the PCIe floor of the 512 MiB download alone is ~10 ms)."""
+    import json
+    exe = _build_seam()
+    r = subprocess.run([exe, str(n), "3", "0.5"], capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0 and "class seam OK" in r.stdout, r.stdout + r.stderr
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["bit_identical_to_sdfgpu_build"] is True
+    if budget_ms is not None:
+        assert line["min_ms"] <= budget_ms, line

@@ -376,3 +376,36 @@ def test_host_copies_chunked_path(gpu):
     assert np.array_equal(got, want) and ext == want_ext
     g = gpu.gradient(got, 0.02)
     assert g.shape == shape + (3,) and np.isfinite(g).all()
+
+
+@pytest.mark.parametrize("shape", [(20, 18, 24), (7, 5, 3), (1, 1, 77), (33, 17, 31), (64, 64, 64), (16, 24, 100)])
+def test_host_side_classification_matches_the_device_classifier(gpu, shape):
+    """Round 5 (VERDICT r4 "next round" 3): the host-buffer entry points classify the caller's mask / cells into one bit per
+    voxel on the host (SSE2 for masks and 8-byte COLLISION_CELL records, a scalar loop for other strides) and upload 1/8 B per
+    voxel.  Forced here on grids far below the size at which it switches itself on (option host_pack = 2), with voxel counts
+    that are no multiple of 8 / 16 / 32: fields and extrema must equal the upload-and-classify-on-device path (host_pack = 0)
+    byte for byte, for both predicates, NaN / negative / 0.5 occupancies, a garbage component field and a wide record."""
+    rng = np.random.RandomState(hash(shape) % 1000)
+    occ = rng.choice(np.array([0.0, 0.25, 0.5, 0.75, 1.0, -10000.0, np.nan, 0.50000006], np.float32), size=shape)
+    cells = np.zeros(shape + (2,), np.float32)
+    cells[..., 0] = occ
+    cells[..., 1] = rng.rand(*shape)
+    swapped = np.ascontiguousarray(cells[..., ::-1])                      # occupancy at offset 4 of the 8-byte record
+    wide = np.zeros(shape + (3,), np.float32)
+    wide[..., 1] = occ
+    mask = (rng.rand(*shape) < 0.3).astype(np.uint8) * rng.randint(1, 256, size=shape).astype(np.uint8)   # any non-zero byte = filled
+    try:
+        res = {}
+        for mode in (0, 2):
+            gpu.set_option("host_pack", mode)
+            res[mode] = [gpu.build(mask, 0.05), gpu.build(mask, 0.05, True)]
+            for unknown in (False, True):
+                res[mode].append(gpu.build_cells(cells, shape, 8, 0, unknown, 0.05))
+                res[mode].append(gpu.build_cells(swapped, shape, 8, 4, unknown, 0.05))
+                res[mode].append(gpu.build_cells(wide, shape, 12, 4, unknown, 0.05, True))
+    finally:
+        gpu.set_option("host_pack", 1)
+    for (a, ea), (b, eb) in zip(res[0], res[2]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ea == eb
+    want, want_ext = O.reference_sdf(O.classify_cells(cells, True), 0.05)
+    assert np.array_equal(res[2][3][0], want) and res[2][3][1] == want_ext     # (and against the oracle's predicate + algorithm)

@@ -258,3 +258,29 @@ def test_dense_tier_policy_sequences_on_the_cpu():
     assert sum(later) <= 8, sum(later)                             # (before: a probe in EVERY build between a pause's end and the report)
     assert L.pol_state(h, 3) >= 63                                 # the back-off doubled: 15 -> 31 -> 63 ...
     L.pol_free(h)
+
+
+@pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "asan_ubsan"])
+def test_oracle_policy_and_host_headers_under_sanitizers(sanitize):
+    """SURVEY section 5 / VERDICT r4 "next round" 7b: the oracle's C restatement, the dense tier's policy object and the host
+    logic of the mirror headers (uninitialised result storage, moves that must not copy, serialisation, hostile headers,
+    per-point queries) in one binary -- tests/host_headers_check.cpp -- built plain and with
+    -fsanitize=address,undefined -fno-sanitize-recover=all; any report aborts the run."""
+    import subprocess
+
+    from sdf_tools_amd import build as b
+    b.build_libsdfgpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tests = os.path.join(root, "tests")
+    exe = os.path.join(tests, "host_headers_check_asan" if sanitize else "host_headers_check")
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"] if sanitize else []
+    obj = exe + "_oracle.o"
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra"] + san + ["-c", os.path.join(root, "oracle", "sdf_oracle.c"), "-o", obj])
+    lib = os.path.join(root, "sdf_tools_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra"] + san + ["-I", os.path.join(root, "include"),
+                           os.path.join(tests, "host_headers_check.cpp"), obj, "-o", exe, "-L", lib, "-lsdfgpu",
+                           "-Wl,-rpath," + lib, "-lz", "-lm"])
+    os.remove(obj)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "host headers OK" in r.stdout, r.stdout + r.stderr
