@@ -237,3 +237,37 @@ def test_1024_long_lines_far_field_against_unbounded_scans(gpu):
         assert float(((a - b).abs() * same).max()) <= res + 2e-6         # (fp32 values up to ~10: differences carry ~1e-6 of rounding)
         del a, b, same
     assert ext[0] == pytest.approx(float(sdf.max()), abs=1e-6) and ext[1] == pytest.approx(float(sdf.min()), abs=1e-6)
+
+
+def test_1024_lines_in_both_swept_axes_against_the_oracle(gpu):
+    """VERDICT r4 "next round" 7a: ORACLE-backed far-field scenes with full-length 1024-voxel lines in BOTH swept axes and a
+    non-trivial cross-section -- 1024 x 1024 x 32 slices of the room (two walls, table on legs, shelf; with and without the
+    floor) plus a few noise voxels: 33 M voxels, within the CPU oracle's reach -- next to the GPU-vs-GPU 1024 x 1024 x 256 test
+    above.  The library's own tier selection must take the far-field pair (512-lane workgroups, one interval per lane in
+    level B, wave-cooperative scans, round 5's flat-stretch shortcut beside the walls and over the floor); every voxel and
+    the extrema bit for bit against the oracle's exact EDT.  Without the floor the argmins travel hundreds of voxels along
+    both axes; with it (and the virtual border) every line is one plateau with jumps at the furniture."""
+    import torch
+    shape, res = (1024, 1024, 32), 0.01
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for floor, vb in ((False, False), (True, True)):
+        m_t = synth.room_mask_torch(shape, dev, floor=floor)
+        noise = synth.bernoulli_mask_torch(shape, 2e-5, 77, device=dev)
+        noise[:, :, :8] = 0                                          # (keep the floor's neighbourhood clean: plateaus AND jumps)
+        m_t |= noise
+        m = m_t.cpu().numpy()
+        gpu.set_option("policy_reset", 1)
+        sdf = torch.empty(shape, dtype=torch.float32, device=dev)
+        gpu.build_device(m_t.data_ptr(), shape, sdf.data_ptr(), res, vb, stream)
+        ext = gpu.get_extrema()
+        path = gpu.last_path()
+        assert path["far_y"] and path["far_x"] and not path["dense_certified"], (floor, path)
+        want, want_ext, dsq = O.exact_sdf(m, res, vb)
+        got = sdf.cpu().numpy()
+        bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        assert len(bad) == 0, (floor, vb, len(bad), bad[:3].tolist())
+        assert ext == want_ext, (floor, vb, ext, want_ext)
+        if not floor:
+            assert np.abs(dsq).max() > 100 * 100                     # far-field indeed: distances of hundreds of voxels
+        del sdf, m_t, noise

@@ -408,4 +408,5 @@ def test_host_side_classification_matches_the_device_classifier(gpu, shape):
     for (a, ea), (b, eb) in zip(res[0], res[2]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ea == eb
     want, want_ext = O.reference_sdf(O.classify_cells(cells, True), 0.05)
-    assert np.array_equal(res[2][3][0], want) and res[2][3][1] == want_ext     # (and against the oracle's predicate + algorithm)
+    # (and against the oracle's predicate + algorithm: entry 5 = cells, unknown_is_filled, no border)
+    assert np.array_equal(res[2][5][0], want) and res[2][5][1] == want_ext

@@ -19,7 +19,7 @@ def f32(x):
     return struct.unpack("f", struct.pack("f", float(x)))[0]
 
 
-def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=None, coop_scale=1):
+def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=None, coop_scale=1, flat=True, stats=None):
     """F: site values (INF = no site).  lo_t / hi_t: span handed to the line (a superset of its sites), mt_t: a lower bound
     of the site values (the kernel keeps both per tile of 16 lines).  Returns (D, candidate evaluations)."""
     L = len(F)
@@ -97,6 +97,29 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=
     def dist(best, p):
         return (best >> B) - p * (2 * h - p)
 
+    # Round 5: the flat-stretch map, from the keys exactly as the kernel builds it -- link q -> q + 1 is flat iff
+    # u = key[q + 1] - key[q] - 1 - ((2 q') << B) = (dF + 1) << B is at most 2 << B (unsigned, mod 2^32) -- and the range test
+    # (at most 3 words of 32 links).  Links whose right end lies beyond the line do not exist.
+    FW = (L + 31) // 32
+    flatw = [0] * FW
+    if flat:
+        for q in range(L - 1):
+            u = (key[q + 1] - key[q] - 1 - ((2 * (q - h)) << B)) & M32
+            if u <= (2 << B):
+                assert abs(Fc[q + 1] - Fc[q]) <= 1, "a link that is not flat passed the key test"
+                flatw[q >> 5] |= 1 << (q & 31)
+            else:
+                assert abs(Fc[q + 1] - Fc[q]) > 1, "a flat link failed the key test"
+
+    def flat_range(a, b):
+        if b <= a:
+            return True
+        w0, w1 = a >> 5, (b - 1) >> 5
+        if w1 - w0 > 2:
+            return False
+        return all(flatw[q >> 5] >> (q & 31) & 1 for q in range(a, b))
+    any_flat = any(flatw)
+
     # level A
     for i in range(MA):
         p = 64 * i
@@ -115,6 +138,21 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=
         lo = args[8 * i] & mask
         hi = (args[8 * (i + 1)] & mask) if i + 1 < MA else hi_t
         pos = [64 * i + 8 * k for k in range(8)]
+        pb0 = 64 * i
+        if any_flat and lo <= pb0 + 8 and hi >= pb0 + 56 and pb0 + 57 < L and flat_range(lo, hi):
+            # flat stretch: every position is its own argmin, or its left neighbour at equal value; the pair partners ride along
+            # and the packed minimum is the leftmost argmin, like a scan's
+            short = [M32] + [min(val(p, p - 2), val(p, p - 1), val(p, p), val(p, p + 1)) for p in pos[1:]]
+            evals[0] += 28
+            keep = evals[0]
+            assert short[1:] == scan(pos, lo, hi)[1:], "level B: the flat-stretch shortcut differs from the scan it replaces"
+            evals[0] = keep                                         # (the checking scan is not part of the schedule)
+            if stats is not None:
+                stats["flat_B"] = stats.get("flat_B", 0) + 1
+            for k in range(1, 8):
+                if 8 * i + k < M:
+                    args[8 * i + k] = min(args[8 * i + k], short[k])
+            continue
         best = scan(pos, lo, hi)
         if coop_rng is not None and hi - lo >= 108 // coop_scale:   # a wave that holds a long range: wave-uniform control, hand-over
             for nshares in (1, 2):                                  # (one lane per interval for lines above 512, two below)
@@ -127,6 +165,24 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=
     for i in range(M):
         a0 = args[i] & mask
         a8 = (args[i + 1] & mask) if i + 1 < M else hi_t
+        p0 = 8 * i
+        if any_flat and a0 <= p0 and a8 >= p0 + 7 and flat_range(a0, a8):
+            # flat stretch: D(p) = F(p), the value of the position's own key
+            assert a0 <= a8
+            short = [val(p0 + k, p0 + k) for k in range(8)]
+            evals[0] += 8
+            keep = evals[0]
+            ref = scan([p0 + k for k in range(8)], a0, a8)
+            evals[0] = keep
+            assert [v >> B for v in short] == [v >> B for v in ref], "level C: the flat-stretch shortcut differs from the scan it replaces"
+            if stats is not None:
+                stats["flat_C"] = stats.get("flat_C", 0) + 1
+            for k in range(8):
+                p = p0 + k
+                if p < L:
+                    d = dist(short[k], p)
+                    D[p] = INF if d >= FINF else d
+            continue
         best = scan([8 * i + k for k in range(8)], a0, a8)
         if coop_rng is not None and a8 - a0 >= 34 // coop_scale:
             assert scan_unit([8 * i + k for k in range(8)], a0, a8, 1, coop_rng) == best, "the split scan of level C saw a different candidate set"
@@ -153,9 +209,10 @@ def brute(F):
 def random_line(rng, L):
     dens = rng.choice([0.0, 0.01, 0.05, 0.3, 1.0])
     vmax = rng.choice([1, 4, 50, 1000, 200000])
-    kind = rng.choice(["rand", "smooth", "ties", "runs", "flat"])
+    kind = rng.choice(["rand", "smooth", "ties", "runs", "flat", "plateaus", "stairs"])
     c = rng.randrange(-50, L + 50)
     hh = rng.randrange(0, 300)
+    level = INF
     F = []
     for q in range(L):
         if kind == "smooth":
@@ -166,6 +223,13 @@ def random_line(rng, L):
             F.append(0 if (q // 7) % 3 == 0 and dens > 0 else INF)
         elif kind == "flat":
             F.append(hh * hh + rng.randrange(0, 3) if rng.random() < max(dens, 0.2) else INF)
+        elif kind == "plateaus":            # piecewise constant with a few jumps and holes: floors, walls, box faces (the shortcut's regime)
+            if q == 0 or rng.random() < 0.02:
+                level = rng.choice([INF, INF, 0, 1, hh * hh, hh * hh + 1, rng.randrange(0, vmax + 1)])
+            F.append(level)
+        elif kind == "stairs":              # unit steps up and down: every link flat, ties between a position and its left neighbour
+            level = hh if q == 0 else max(0, level + rng.choice([-1, 0, 0, 1]))
+            F.append(level)
         else:
             F.append(rng.randrange(0, vmax + 1) if rng.random() < dens else INF)
     return F
@@ -183,9 +247,13 @@ def check_line(rng, F):
     if rng.random() < 0.5:                                              # round 4: long ranges under wave-uniform control (thresholds scaled
         kw["coop_rng"] = random.Random(rng.randrange(1 << 30))          # down so that the short test lines reach the hand-over too)
         kw["coop_scale"] = rng.choice([1, 4, 16])
-    got, ev = dc_line(F, FINF, **kw)
+    kw["flat"] = rng.random() < 0.8
+    got, ev = dc_line(F, FINF, stats=STATS, **kw)
     assert got == brute(F), (L, F, kw)
     return ev
+
+
+STATS = {}
 
 
 def main():
@@ -201,6 +269,16 @@ def main():
     got, ev = dc_line(F, 3 * 511 ** 2 + 1)
     assert got == brute(F)
     print("ok; sites in [100, 300) of 512: %d candidate evaluations (%.1f per position)" % (ev, ev / 512.0))
+    # the shortcut's regime: a floor under the whole line, a box face over part of it -- and how many scans it replaced
+    for name, F in (("floor", [90 * 90] * 512), ("floor + box", [90 * 90] * 200 + [30 * 30] * 150 + [90 * 90] * 162),
+                    ("wall slab in free space", [INF] * 180 + [12 * 12] * 40 + [INF] * 292)):
+        st = {}
+        got, ev = dc_line(F, 3 * 511 ** 2 + 1, stats=st)
+        _, ev0 = dc_line(F, 3 * 511 ** 2 + 1, flat=False)
+        assert got == brute(F)
+        print("ok; %s: %d candidate evaluations with the flat-stretch shortcut (%d of 8 level-B and %d of 64 level-C scans replaced), %d without"
+              % (name, ev, st.get("flat_B", 0), st.get("flat_C", 0), ev0))
+    assert STATS.get("flat_B", 0) > 50 and STATS.get("flat_C", 0) > 500, STATS       # (the random lines reach both shortcuts)
 
 
 if __name__ == "__main__":

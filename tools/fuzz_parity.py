@@ -32,8 +32,30 @@ while time.time() - t0 < budget:
         shape = ((a, b) if rng.random() < 0.5 else (b, a)) + (int(rng.choice([16, 32, 64])),)
     if np.prod(shape) > 1 << 21:
         continue
-    kind = rng.integers(0, 4)
-    if kind == 0:
+    kind = rng.integers(0, 5)
+    if kind == 4:
+        # round 5: axis-aligned slabs (floors / walls, whole extent in two axes), solid boxes and box shells, optionally a few noise
+        # voxels -- the far-field kernel's flat-stretch shortcut (plateaus of the sweep's input with jumps and holes, unit steps
+        # next to slabs) on both swept axes, through both passes
+        m = np.zeros(shape, np.uint8)
+        for _ in range(int(rng.integers(1, 5))):
+            if rng.random() < 0.5:
+                ax = int(rng.integers(0, 3))
+                a = int(rng.integers(0, shape[ax]))
+                sl = [slice(None)] * 3
+                sl[ax] = slice(a, min(shape[ax], a + int(rng.integers(1, 12))))
+                m[tuple(sl)] = 1
+            else:
+                lo = [int(rng.integers(0, s)) for s in shape]
+                hi = [min(s, l + int(rng.integers(1, max(2, s // 2 + 1)))) for l, s in zip(lo, shape)]
+                m[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = 1
+                if rng.random() < 0.4 and all(h - l > 2 for l, h in zip(lo, hi)):
+                    m[lo[0] + 1:hi[0] - 1, lo[1] + 1:hi[1] - 1, lo[2] + 1:hi[2] - 1] = 0
+        if rng.random() < 0.3:
+            m |= (rng.random(shape) < 0.002).astype(np.uint8)
+        if rng.random() < 0.2:
+            m = 1 - m
+    elif kind == 0:
         m = synth.bernoulli_mask(shape, float(rng.choice([0.5, 0.3, 0.1, 0.05, 0.03, 0.02, 0.01, 0.001, 0.9, 0.96, 0.99, 0.999])), int(rng.integers(1 << 30)))
     elif kind == 1:
         m = synth.spheres_mask(shape, int(rng.integers(1, 5)), (1, 9), int(rng.integers(1 << 30)))
