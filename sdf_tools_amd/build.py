@@ -33,15 +33,33 @@ def _hipcc():
 
 
 def build_libsdfgpu(force=False, verbose=False):
-    # the translation unit first, then EVERY header it includes (a stale library after a header-only edit is the
-    # kind of bug that invalidates measurements without failing anything)
-    srcs = [os.path.join(CSRC, "sdfgpu.hip")] + sorted(
-        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("sdfgpu") and f.endswith(".hpp")) + [
+    """Two translation units -> objects (compiled side by side) -> libsdfgpu.so: sdfgpu.hip (C ABI, host orchestration, every
+    kernel but one) and sdfgpu_envelope_tu.hip (the far-field kernel's instantiations).  Each object is rebuilt when its
+    source or ANY header it can include is newer (a stale library after a header-only edit is the kind of bug that
+    invalidates measurements without failing anything)."""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("sdfgpu") and f.endswith(".hpp")) + [
         os.path.join(INCLUDE, "sdfgpu.h")]
-    if not force and not _newer(LIB, srcs):
+    env_hdrs = [os.path.join(CSRC, f) for f in ("sdfgpu_envelope_dc.hpp", "sdfgpu_kernels.hpp", "sdfgpu_sweep_x16.hpp")]
+    units = [(os.path.join(CSRC, "sdfgpu.hip"), hdrs), (os.path.join(CSRC, "sdfgpu_envelope_tu.hip"), env_hdrs)]
+    extra = os.environ.get("SDFGPU_EXTRA_FLAGS", "").split()
+    objdir = os.path.join(CSRC, ".obj" + ("_" + "".join(c for c in "".join(extra) if c.isalnum()) if extra else ""))
+    os.makedirs(objdir, exist_ok=True)
+    todo, objs = [], []
+    for src, deps in units:
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + deps):
+            todo.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-I", INCLUDE, "-c", src,
+                         "-o", obj] + extra)
+    if not todo and not _newer(LIB, objs):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I", INCLUDE, srcs[0], "-o", LIB] + os.environ.get("SDFGPU_EXTRA_FLAGS", "").split()
+    if verbose:
+        for cmd in todo:
+            print(" ".join(cmd))
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        list(pool.map(subprocess.check_call, todo))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -216,7 +216,7 @@ constexpr int NB = 8;          // staging: row loads in flight per lane (a 512-l
 inline int envelope_dc_pitch(int L) { return ((L + 63) / 64) * 64 + 2; }        // >= L + 2, == 2 mod 64, even (8-byte pairs)
 inline size_t envelope_dc_lds_bytes(int L, int lines = kDcLines) {
     const int M = (L + 7) / 8;
-    return ((size_t)lines * envelope_dc_pitch(L) + (size_t)(M + 2) * lines + 48 + kDcLocalFilled + (size_t)lines * ((L + 31) / 32)) * 4;
+    return ((size_t)lines * envelope_dc_pitch(L) + (size_t)(M + 2) * lines + 48 + kDcLocalFilled) * 4;
 }
 
 // a * b + c on the low 24 bits of a and b (signed), low 32 bits of the result: one full-rate instruction.  (Written as
@@ -279,7 +279,7 @@ __device__ __forceinline__ void decide_tier(uint32_t* __restrict__ small, int st
     if (stage == 1) small[18] = 0u;
     small[14 + stage] = tot ? (far_n * 1000u) / tot : 0u;         // per-mille of far voxels in the sample (diagnostics)
 }
-__global__ void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff,
+SDFGPU_KERNEL void k_decide_tier(uint32_t* __restrict__ small, int stage, int dense_tried, int force, int num, int den, int handoff,
                               int mid_den) {
     decide_tier(small, stage, dense_tried, force, num, den, handoff, mid_den, 0);
 }
@@ -421,14 +421,6 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     uint32_t* const args = keys + NL * pitch;                   // [M + 2][16]  best value (distance << B | argmin) of coarse position 8 i
     uint32_t* const misc = args + (M + 2) * NL;                 // per wave: [0..7] span lo, [8..15] span hi, [16..23] smallest site value; [24] filled voxels listed, [25] second pass wanted, [26..28] probe
     uint32_t* const flist = misc + 48;                          // [kDcLocalFilled] filled voxels of pass 0: line << 28 | p << 12 | min(S, kDcLocalSat)
-    // Flat-stretch map (round 5): bit b of word w of a line = the link q -> q + 1, q = 32 w + b, is FLAT: |F(q + 1) - F(q)| <= 1.
-    // If every link of a candidate range [lo, hi] is flat, then for p, q in it F(q) >= F(p) - |p - q|, so
-    // F(q) + (p - q)^2 >= F(p) + |p - q| (|p - q| - 1) >= F(p): every position of the range that the range's bounds allow
-    // is its own argmin and D(p) = F(p) -- no scan.  That is the regime of floors, walls and box faces parallel to the sweep
-    // (the room scene: F constant along the line wherever one large surface is the nearest thing), where levels B and C
-    // otherwise scan their full ranges like on a noise scene.  misc[32 + wave] = that wave found a flat word at all.
-    const int FW = (L + 31) >> 5;
-    uint32_t* const flatw = flist + kDcLocalFilled;             // [NL][FW]
     const int t = threadIdx.x;
 #ifdef SDFGPU_PHASE_CLOCKS
     unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -598,19 +590,6 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         }
     };
 
-    // every link a .. b - 1 of the line whose map words start at fw is flat (a <= b; ranges beyond 3 words count as not flat:
-    // a range without a jump of the argmin is at most 64 + noise long)
-    auto flat_range = [&](const uint32_t* fw, int a, int b) -> bool {
-        if (b <= a) return true;
-        const int w0 = a >> 5, w1 = (b - 1) >> 5;
-        if (w1 - w0 > 2) return false;
-        const uint32_t m0 = 0xFFFFFFFFu << (a & 31), m1 = 0xFFFFFFFFu >> (31 - ((b - 1) & 31));
-        if (w1 == w0) { const uint32_t m = m0 & m1; return (fw[w0] & m) == m; }
-        bool ok = (fw[w0] & m0) == m0 && (fw[w1] & m1) == m1;
-        if (w1 - w0 == 2) ok = ok && fw[w0 + 1] == 0xFFFFFFFFu;
-        return ok;
-    };
-
     // one pass over the tile.  CLS 0: sites of "distance to filled" (results for free voxels); 1: the reverse, on the
     // negated field.
     auto run_pass = [&](auto cls_tag) {
@@ -756,51 +735,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         const bool act = lo_t <= hi_t;                          // the tile holds a site (block-uniform)
 #endif
 
-        bool any_flat = false;                                  // (block-uniform, read behind level A's barrier)
         if (act) {
-            // ---- flat-stretch map: lane = (line, word of 32 links), from the keys --------------------------------------------------
-            // key[q + 1] - key[q] = ((dF + 2 q' + 1) << B) + 1, so u = key[q + 1] - key[q] - 1 - ((2 q') << B) = (dF + 1) << B and the
-            // link is flat iff u <= 2 << B (unsigned; a wrap would need |dF| >= 2^(32 - B) - 1 > finf).  A wave whose lanes find none
-            // of their first 4 links flat leaves at once (noise scenes: ~25 instructions per lane instead of ~200).
-            {
-                const uint32_t two = 2u << B;
-                uint32_t wave_any = 0u;
-                for (int idx = t; idx < NL * FW || (idx - (t & 63)) < NL * FW; idx += NT) {     // (whole waves stay together for the ballots)
-                    const bool in = idx < NL * FW;
-                    const int line = idx & (NL - 1), wi = in ? idx / NL : 0;
-                    const uint32_t* kq = keys + line * pitch + 32 * wi;
-                    uint32_t rr = (uint32_t)(2 * (32 * wi - h)) << B;                         // (2 q') << B of the word's first link
-                    uint32_t bits = 0u;
-                    uint2 c = *reinterpret_cast<const uint2*>(kq);
-                    {
-                        const uint2 n = *reinterpret_cast<const uint2*>(kq + 2);
-                        const uint2 n2 = *reinterpret_cast<const uint2*>(kq + 4);
-                        const uint32_t u0 = c.y - c.x - 1u - rr, u1 = n.x - c.y - 1u - (rr + two), u2 = n.y - n.x - 1u - (rr + 2u * two),
-                                       u3 = n2.x - n.y - 1u - (rr + 3u * two);
-                        bits = (u0 <= two ? 1u : 0u) | (u1 <= two ? 2u : 0u) | (u2 <= two ? 4u : 0u) | (u3 <= two ? 8u : 0u);
-                    }
-                    if (__ballot(in && bits == 15u) == 0ull) {          // (wave-uniform)
-                        if (in) flatw[line * FW + wi] = 0u;
-                        continue;
-                    }
-                    bits = 0u;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const uint2 n = *reinterpret_cast<const uint2*>(kq + 2 * j + 2);
-                        const uint32_t u0 = c.y - c.x - 1u - rr, u1 = n.x - c.y - 1u - (rr + two);
-                        bits |= (u0 <= two ? 1u : 0u) << (2 * j);
-                        bits |= (u1 <= two ? 1u : 0u) << (2 * j + 1);
-                        rr += 2u * two;
-                        c = n;
-                    }
-                    // links whose right end lies beyond the line do not exist
-                    const int nlinks = L - 1 - 32 * wi;                 // links of this word that exist (q + 1 <= L - 1)
-                    if (nlinks < 32) bits &= nlinks <= 0 ? 0u : (0xFFFFFFFFu >> (32 - nlinks));
-                    if (in) flatw[line * FW + wi] = bits;
-                    wave_any |= (__ballot(in && bits != 0u) != 0ull) ? 1u : 0u;
-                }
-                if ((t & 63) == 0) misc[32 + (t >> 6)] = wave_any;
-            }
             // ---- level A: positions 64 i ---------------------------------------------------------------------------------------
             // Two forms, chosen per wave (= 64 / S whole lines): (a) one position per lane group over a range clipped by the
             // distance bound -- a few candidates per position wherever the line runs near sites or far from ALL of them;
@@ -867,8 +802,6 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             }
             __syncthreads();
             DC_STAMP(1);
-#pragma unroll
-            for (int w = 0; w < NW; ++w) any_flat = any_flat || misc[32 + w] != 0u;
             if (probe) {
                 // the probe's statistic from the coarse positions alone (64 i of every line: an unbiased sample of the voxels)
                 if (slotT < imin(MA, S)) {
@@ -907,36 +840,18 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
 #ifdef SDFGPU_DEBUG_HOOKS
                     if (a.dbg & 16) continue;
 #endif
-                    int hi_s = hi;                              // scan bound (emptied by the flat-stretch shortcut)
-                    if (any_flat) {                             // (block-uniform)
-                        // Flat stretch: all 7 positions lie inside [lo, hi] and every link of the range is flat, so each position p
-                        // is its own argmin -- or p - 1 at equal value when F(p) = F(p - 1) + 1: both are evaluated (with their pair
-                        // partners, which ride along harmlessly), the packed minimum is the LEFTMOST argmin like a scan's, so the
-                        // argmins handed to level C stay monotone.
-                        const int pb0 = 64 * i;
-                        if (i < MA && lo <= pb0 + 8 && hi >= pb0 + 56 && pb0 + 57 < L && flat_range(flatw + lineT * FW, lo, hi)) {
-#pragma unroll
-                            for (int k = 1; k < 8; ++k) {
-                                const int p = pb0 + 8 * k;
-                                const uint2 ka = *reinterpret_cast<const uint2*>(kl + p - 2), kb = *reinterpret_cast<const uint2*>(kl + p);
-                                best[k] = umin(umin(mad_i24(p - 2 - h, nc[k], ka.x), mad_i24(p - 1 - h, nc[k], ka.y)),
-                                               umin(mad_i24(p - h, nc[k], kb.x), mad_i24(p + 1 - h, nc[k], kb.y)));
-                            }
-                            hi_s = lo - 2;
-                        }
-                    }
-                    if (coop && __ballot(hi_s - lo >= 108) != 0ull) {             // (an interval's range without a jump: <= 64 + noise)
+                    if (coop && __ballot(hi - lo >= 108) != 0ull) {             // (an interval's range without a jump: <= 64 + noise)
                         int q = (lo & ~1) + 2 * u;
                         if (Hs == 1) {                          // (block-uniform)
-                            scan8_calm(kl, q, hi_s, 2, nc, best, std::integral_constant<int, 1>{}, 2);
-                            coop8(kl, q, hi_s, nc, best, std::integral_constant<int, 1>{}, 64);
+                            scan8_calm(kl, q, hi, 2, nc, best, std::integral_constant<int, 1>{}, 2);
+                            coop8(kl, q, hi, nc, best, std::integral_constant<int, 1>{}, 64);
                         } else {
-                            scan8_calm(kl, q, hi_s, 4, nc, best, std::integral_constant<int, 2>{}, 1);
-                            coop8(kl, q, hi_s, nc, best, std::integral_constant<int, 2>{}, 64);
+                            scan8_calm(kl, q, hi, 4, nc, best, std::integral_constant<int, 2>{}, 1);
+                            coop8(kl, q, hi, nc, best, std::integral_constant<int, 2>{}, 64);
                         }
                         if (i >= MA) continue;
                     } else {
-                        scan8(kl, (lo & ~1) + 2 * u, hi_s, 2 * Hs, nc, best);
+                        scan8(kl, (lo & ~1) + 2 * u, hi, 2 * Hs, nc, best);
                     }
 #pragma unroll
                     for (int k = 1; k < 8; ++k)
@@ -972,30 +887,16 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         best[k] = 0xFFFFFFFFu;
                     }
                     DC_STAMP(4);
-                    int a8_s = a8;                              // scan bound (emptied by the flat-stretch shortcut)
-                    if (any_flat) {                             // (block-uniform)
-                        // Flat stretch: the 8 positions lie inside [a0, a8], every link of it is flat: D(p) = F(p), the value of the
-                        // position's own key (only values leave level C: no tie-break to keep)
-                        if (mine && a0 <= p0 && a8 >= p0 + 7 && flat_range(flatw + lineT * FW, a0, a8)) {
-#pragma unroll
-                            for (int k = 0; k < 8; k += 2) {
-                                const uint2 kk = *reinterpret_cast<const uint2*>(kl + p0 + k);
-                                best[k] = mad_i24(p0 + k - h, nc[k], kk.x);
-                                best[k + 1] = mad_i24(p0 + k + 1 - h, nc[k + 1], kk.y);
-                            }
-                            a8_s = a0 - 2;
-                        }
-                    }
 #ifdef SDFGPU_DEBUG_HOOKS
                     if (a.dbg & 8) {}                           // profiling builds: bit 3 = no level-C scan, bit 4 = no level-B scan (use with bit 3)
                     else
 #endif
-                    if (NL == 16 && __ballot(a8_s - a0 >= 34) != 0ull) {          // (a chunk's range without a jump: <= 8 + noise)
+                    if (NL == 16 && __ballot(a8 - a0 >= 34) != 0ull) {          // (a chunk's range without a jump: <= 8 + noise)
                         int q = a0 & ~1;
-                        scan8_calm(kl, q, a8_s, 2, nc, best, std::integral_constant<int, 1>{}, 2);
-                        coop8(kl, q, a8_s, nc, best, std::integral_constant<int, 1>{}, 8);
+                        scan8_calm(kl, q, a8, 2, nc, best, std::integral_constant<int, 1>{}, 2);
+                        coop8(kl, q, a8, nc, best, std::integral_constant<int, 1>{}, 8);
                     } else {
-                        scan8(kl, a0 & ~1, a8_s, 2, nc, best);
+                        scan8(kl, a0 & ~1, a8, 2, nc, best);
                     }
                     DC_STAMP(3);
                     // D = (best >> B) - (h^2 - p'^2), h^2 - p'^2 = p (2 h - p): a running value, + (2 h - 2 p - 1) per position
@@ -1179,5 +1080,18 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * (NT / 64) + (t >> 6), mxF, mxQ);
     }
 }
+
+// The instantiations the launcher (launch_envelope, sdfgpu.hip) uses, compiled in their own translation unit
+// (sdfgpu_envelope_tu.hip: the far-field kernel is a third of the library's device code and most of its compile time, and it
+// is the kernel that changes most often); everywhere else they are only declared.
+#define SDFGPU_ENVELOPE_INSTANCES(X) \
+    X(2, false, 256, 16) X(3, false, 256, 16) X(2, true, 256, 16) X(3, true, 256, 16) \
+    X(2, false, 256, 16, true) X(3, false, 256, 16, true) X(2, true, 256, 16, true) X(3, true, 256, 16, true) \
+    X(2, false, 512, 16, false, 4) X(3, false, 512, 16, false, 4) X(2, true, 512, 16, false, 4) X(3, true, 512, 16, false, 4)
+#ifndef SDFGPU_ENVELOPE_TU
+#define SDFGPU_ENVELOPE_DECLARE(...) extern template __global__ void k_envelope_dc<__VA_ARGS__>(const EnvDcArgs);
+SDFGPU_ENVELOPE_INSTANCES(SDFGPU_ENVELOPE_DECLARE)
+#undef SDFGPU_ENVELOPE_DECLARE
+#endif
 
 }  // namespace sdfgpu

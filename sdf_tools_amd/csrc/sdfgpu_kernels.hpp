@@ -28,6 +28,15 @@
 #include <stdint.h>
 #include <type_traits>
 
+// Non-template kernels are DEFINED in these headers.  The one translation unit that includes them only for their device
+// helpers (sdfgpu_envelope_tu.hip, the far-field kernel's instantiations) gives them internal linkage, so the library
+// holds one definition of each.
+#ifdef SDFGPU_ENVELOPE_TU
+#define SDFGPU_KERNEL static __global__
+#else
+#define SDFGPU_KERNEL __global__
+#endif
+
 namespace sdfgpu {
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
@@ -77,7 +86,7 @@ __device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mx
 // uncertified, far flags, fix_needed, -}): the final block is written to `result` (device; what get_extrema reads)
 // and to `report` (pinned host memory mapped into the device; the policy's asynchronous "what did this build need"),
 // and the status block is cleared for the next build -- one kernel instead of fold + copy kernel + fill kernel.
-__global__ __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
+SDFGPU_KERNEL __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
                                                        uint32_t* __restrict__ result, uint32_t* __restrict__ report) {
     __shared__ uint32_t part[2 * (kSlots / 64)];
     uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
@@ -183,7 +192,7 @@ __device__ __forceinline__ int z_signed_distance(uint64_t word, uint64_t vm, int
 
 // Fast path: uint8 mask, nz % 16 == 0, 16-byte aligned base.  A lane handles 16
 // consecutive voxels: one 16-B load, two 16-B stores.
-__global__ __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restrict__ mask,
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_sweep_z_vec16(const uint8_t* __restrict__ mask,
                                                          int16_t* __restrict__ out,
                                                          int64_t nrows, int nz, int rpb,
                                                          const uint32_t* __restrict__ guard) {
@@ -769,7 +778,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_march(const SweepArgs a) {
 //   mode 1: object_id > 0                   (object_filled_fn :757-775, "named objects")
 //   mode 2: object_id in the given id list  (object_use_map :817-827); the list arrives sorted, any length
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_classify_tagged(const char* __restrict__ cells, int64_t stride,
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_classify_tagged(const char* __restrict__ cells, int64_t stride,
                                                            int64_t occ_off, int64_t obj_off, int unknown_is_filled,
                                                            int mode, const uint32_t* __restrict__ ids, int n_ids,
                                                            int64_t n, uint8_t* __restrict__ mask) {
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void k_classify_tagged(const char* __restri
 }
 
 // collision_map.hpp:680-712 predicate on raw COLLISION_CELL records -> byte mask (slab pipelines take masks)
-__global__ __launch_bounds__(kBlock) void k_classify_cells(CellLoader ld, int64_t n, uint8_t* __restrict__ mask) {
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_classify_cells(CellLoader ld, int64_t n, uint8_t* __restrict__ mask) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) mask[i] = ld.filled(i) ? 1 : 0;
 }
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(kBlock) void k_classify_cells(CellLoader ld, int64_
 // vg[ix, iy, iz] = 1.  Points whose index falls outside the grid are dropped.  fp32 points (the
 // PointCloud2 convention), index arithmetic in fp64 like numpy's.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_voxelize_points(const float* __restrict__ pts, int64_t n_points,
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_voxelize_points(const float* __restrict__ pts, int64_t n_points,
                                                            double ox, double oy, double oz, double res,
                                                            int64_t nx, int64_t ny, int64_t nz,
                                                            uint8_t* __restrict__ mask) {
@@ -1032,7 +1041,7 @@ __device__ __forceinline__ double query_bilinear(double l1, double h1, double l2
     return r0 * (h2 - q2) + r1 * (q2 - l2);
 }
 
-__global__ __launch_bounds__(kBlock) void k_query_points(const QueryArgs a) {
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_query_points(const QueryArgs a) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= a.n) return;
     const double px = a.points[3 * t], py = a.points[3 * t + 1], pz = a.points[3 * t + 2];

@@ -245,8 +245,8 @@ def test_1024_lines_in_both_swept_axes_against_the_oracle(gpu):
     floor) plus a few noise voxels: 33 M voxels, within the CPU oracle's reach -- next to the GPU-vs-GPU 1024 x 1024 x 256 test
     above.  The library's own tier selection must take the far-field pair (512-lane workgroups, one interval per lane in
     level B, wave-cooperative scans, round 5's flat-stretch shortcut beside the walls and over the floor); every voxel and
-    the extrema bit for bit against the oracle's exact EDT.  Without the floor the argmins travel hundreds of voxels along
-    both axes; with it (and the virtual border) every line is one plateau with jumps at the furniture."""
+    the extrema bit for bit against the oracle's exact EDT.  Without the floor the argmins travel up to 83 voxels (to the nearest noise voxel, wall or piece of furniture) along both
+    axes; with it (and the virtual border) every line is one plateau with jumps at the furniture."""
     import torch
     shape, res = (1024, 1024, 32), 0.01
     dev = torch.device("cuda", 0)
@@ -269,5 +269,5 @@ def test_1024_lines_in_both_swept_axes_against_the_oracle(gpu):
         assert len(bad) == 0, (floor, vb, len(bad), bad[:3].tolist())
         assert ext == want_ext, (floor, vb, ext, want_ext)
         if not floor:
-            assert np.abs(dsq).max() > 100 * 100                     # far-field indeed: distances of hundreds of voxels
+            assert np.abs(dsq).max() > 60 * 60                       # far-field indeed (the noise voxels bound it: 83 here)
         del sdf, m_t, noise

@@ -19,7 +19,7 @@ def f32(x):
     return struct.unpack("f", struct.pack("f", float(x)))[0]
 
 
-def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=None, coop_scale=1, flat=True, stats=None):
+def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=None, coop_scale=1, flat=False, stats=None):
     """F: site values (INF = no site).  lo_t / hi_t: span handed to the line (a superset of its sites), mt_t: a lower bound
     of the site values (the kernel keeps both per tile of 16 lines).  Returns (D, candidate evaluations)."""
     L = len(F)
@@ -97,9 +97,14 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=
     def dist(best, p):
         return (best >> B) - p * (2 * h - p)
 
-    # Round 5: the flat-stretch map, from the keys exactly as the kernel builds it -- link q -> q + 1 is flat iff
-    # u = key[q + 1] - key[q] - 1 - ((2 q') << B) = (dF + 1) << B is at most 2 << B (unsigned, mod 2^32) -- and the range test
-    # (at most 3 words of 32 links).  Links whose right end lies beyond the line do not exist.
+    # Round 5, a VARIANT that was built into the kernel, measured and taken out again (`flat` = True): the
+    # flat-stretch shortcut.  If every link q -> q + 1 of a candidate range is flat (|dF| <= 1), every position of the range
+    # is its own argmin and D(p) = F(p): levels B and C need no scan over floors, walls and box faces.  Exact (checked here
+    # against the scans it replaces and against brute force; 16 000 fuzz scenes on the GPU), and it removed 27 - 50 % of the
+    # scan trips of the room scene -- without making a build any faster: between two workgroup barriers a tile waits for its
+    # SLOWEST wave, and the lines of a tile all meet the wall in the same interval, i.e. in the same wave.  The map, from the
+    # keys as the kernel built it: the link is flat iff u = key[q + 1] - key[q] - 1 - ((2 q') << B) = (dF + 1) << B is at
+    # most 2 << B (unsigned, mod 2^32); range test over at most 3 words of 32 links; links beyond the line do not exist.
     FW = (L + 31) // 32
     flatw = [0] * FW
     if flat:
@@ -247,7 +252,7 @@ def check_line(rng, F):
     if rng.random() < 0.5:                                              # round 4: long ranges under wave-uniform control (thresholds scaled
         kw["coop_rng"] = random.Random(rng.randrange(1 << 30))          # down so that the short test lines reach the hand-over too)
         kw["coop_scale"] = rng.choice([1, 4, 16])
-    kw["flat"] = rng.random() < 0.8
+    kw["flat"] = rng.random() < 0.5                                     # (the round-5 variant, see dc_line)
     got, ev = dc_line(F, FINF, stats=STATS, **kw)
     assert got == brute(F), (L, F, kw)
     return ev
@@ -273,12 +278,12 @@ def main():
     for name, F in (("floor", [90 * 90] * 512), ("floor + box", [90 * 90] * 200 + [30 * 30] * 150 + [90 * 90] * 162),
                     ("wall slab in free space", [INF] * 180 + [12 * 12] * 40 + [INF] * 292)):
         st = {}
-        got, ev = dc_line(F, 3 * 511 ** 2 + 1, stats=st)
+        got, ev = dc_line(F, 3 * 511 ** 2 + 1, stats=st, flat=True)
         _, ev0 = dc_line(F, 3 * 511 ** 2 + 1, flat=False)
         assert got == brute(F)
-        print("ok; %s: %d candidate evaluations with the flat-stretch shortcut (%d of 8 level-B and %d of 64 level-C scans replaced), %d without"
+        print("ok; %s: %d candidate evaluations with the flat-stretch shortcut of round 5 (%d of 8 level-B and %d of 64 level-C scans replaced), %d without"
               % (name, ev, st.get("flat_B", 0), st.get("flat_C", 0), ev0))
-    assert STATS.get("flat_B", 0) > 50 and STATS.get("flat_C", 0) > 500, STATS       # (the random lines reach both shortcuts)
+    assert STATS.get("flat_B", 0) > 20 and STATS.get("flat_C", 0) > 200, STATS       # (the random lines reach both shortcuts)
 
 
 if __name__ == "__main__":

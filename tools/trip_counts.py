@@ -21,6 +21,10 @@ if kind == "stream":
     pts = torch.from_numpy(synth.two_box_points(200000, seed=0, scale=n * res)).to(dev)
     mask = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
     ctx.voxelize_points_device(pts.data_ptr(), pts.shape[0], (0.0, 0.0, 0.0), res, (n, n, n), mask.data_ptr(), True, s)
+elif kind == "room":
+    mask = synth.room_mask_torch((n, n, n), dev)
+elif kind == "boxes":
+    mask = synth.tutorial_boxes_mask_torch((n, n, n), dev, True)
 elif kind == "spheres":
     mask = synth.solid_spheres_mask_torch((n, n, n), dev)
 elif kind == "shells":
