@@ -33,15 +33,17 @@ def _hipcc():
 
 
 def build_libsdfgpu(force=False, verbose=False):
-    """Two translation units -> objects (compiled side by side) -> libsdfgpu.so: sdfgpu.hip (C ABI, host orchestration, every
-    kernel but one) and sdfgpu_envelope_tu.hip (the far-field kernel's instantiations).  Each object is rebuilt when its
+    """Three translation units -> objects (compiled side by side) -> libsdfgpu.so: sdfgpu.hip (C ABI, host orchestration, most
+    kernels), sdfgpu_envelope_tu.hip (the far-field kernel's instantiations) and sdfgpu_dense6_tu.hip (the shell pass).  Each object is rebuilt when its
     source or ANY header it can include is newer (a stale library after a header-only edit is the kind of bug that
     invalidates measurements without failing anything)."""
     from concurrent.futures import ThreadPoolExecutor
     hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("sdfgpu") and f.endswith(".hpp")) + [
         os.path.join(INCLUDE, "sdfgpu.h")]
     env_hdrs = [os.path.join(CSRC, f) for f in ("sdfgpu_envelope_dc.hpp", "sdfgpu_kernels.hpp", "sdfgpu_sweep_x16.hpp")]
-    units = [(os.path.join(CSRC, "sdfgpu.hip"), hdrs), (os.path.join(CSRC, "sdfgpu_envelope_tu.hip"), env_hdrs)]
+    d6_hdrs = [os.path.join(CSRC, f) for f in ("sdfgpu_dense6.hpp", "sdfgpu_dense3.hpp", "sdfgpu_dense.hpp", "sdfgpu_kernels.hpp")]
+    units = [(os.path.join(CSRC, "sdfgpu.hip"), hdrs), (os.path.join(CSRC, "sdfgpu_envelope_tu.hip"), env_hdrs),
+             (os.path.join(CSRC, "sdfgpu_dense6_tu.hip"), d6_hdrs)]
     extra = os.environ.get("SDFGPU_EXTRA_FLAGS", "").split()
     objdir = os.path.join(CSRC, ".obj" + ("_" + "".join(c for c in "".join(extra) if c.isalnum()) if extra else ""))
     os.makedirs(objdir, exist_ok=True)
@@ -57,7 +59,7 @@ def build_libsdfgpu(force=False, verbose=False):
     if verbose:
         for cmd in todo:
             print(" ".join(cmd))
-    with ThreadPoolExecutor(max_workers=2) as pool:
+    with ThreadPoolExecutor(max_workers=3) as pool:
         list(pool.map(subprocess.check_call, todo))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
     if verbose:

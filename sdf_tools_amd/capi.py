@@ -368,7 +368,7 @@ class SdfGpu:
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_last_dense_certified(self._h, ctypes.byref(v)))
         why = (v.value >> 8) & 0xff
-        names = ("one_class_tile", "wave_all_undecided", "wave_too_many_undecided", "tile_over_fixup_cap", "beyond_fixup_reach", "beyond_ball")
+        names = ("one_class_tile", "wave_all_undecided", "wave_too_many_undecided", "tile_over_fixup_cap", "beyond_fixup_reach", "beyond_ball", "too_sparse_for_the_shell_pass")
         out = {"dense_certified": bool(v.value & 1), "far_y": bool(v.value & 2), "far_x": bool(v.value & 4)}
         if why:
             out["dense_gave_up"] = [n for k, n in enumerate(names) if why & (1 << k)]

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_bits_generic(Loader ld, uint32_
 // COLLISION_CELL records: 16 MiB instead of 1 GiB at 512^3), and this kernel spreads the bits back into the 0 / 1 byte mask
 // every tier's first kernel reads.  Linear bit order: bit (v & 31) of word (v >> 5) = voxel v.  A lane writes 16 bytes, a
 // wave one contiguous 1 KiB per store instruction; 1/8 B read + 1 B written per voxel (~30 us at 512^3).
-__global__ __launch_bounds__(kBlock) void k_unpack_bits_mask(const uint32_t* __restrict__ bits, uint8_t* __restrict__ mask, int64_t n) {
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_unpack_bits_mask(const uint32_t* __restrict__ bits, uint8_t* __restrict__ mask, int64_t n) {
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;       // 16-voxel chunk index
     const int64_t v0 = 16 * c;
     if (v0 >= n) return;
@@ -137,11 +137,15 @@ struct DenseArgs {
     int checked;            // debugging: take the bounds-checked expansion even for interior tiles
     int nt_store;           // write the output with non-temporal stores (it is never re-read here)
     const uint32_t* guard;  // KD3 only: non-null = run iff *guard != 0 (the staged fix-up stage behind KD in the same build)
+    uint32_t* und_sample;   // KD3 only: nullptr, or the slot array: every 16th wave adds its undecided voxels to word 2 of a slot -- a 1 / 16
+                            // sample of the scene's total, which k_shell_budget folds and holds against the shell pass's budget
+    int max_undecided;      // KD3 only: a wave (2048 voxels) with more undecided voxels than this gives the tier up at once
+                            // (kBall3MaxUndecided = KF's per-tile cap; with the shell pass KD6 behind KD3 the bound is KD6's reach)
 };
 
 // why the dense tier handed a scene on (status word 21 of whole builds; sdfgpu_last_dense_certified reports them from bit 8 up)
 constexpr uint32_t kGiveUpOneClassTile = 1u, kGiveUpWaveAllUndecided = 2u, kGiveUpWaveTooMany = 4u, kGiveUpTileOverCap = 8u,
-                   kGiveUpBeyondReach = 16u, kGiveUpBeyondBall = 32u;
+                   kGiveUpBeyondReach = 16u, kGiveUpBeyondBall = 32u, kGiveUpTooSparse = 64u;
 __device__ __forceinline__ void note_reason(uint32_t* reason, uint32_t bit) {
     if (reason && !(__hip_atomic_load(reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(reason, bit);
 }
@@ -442,10 +446,15 @@ __global__ __launch_bounds__(BD) void k_ball_dense(const DenseArgs a) {
 // the nearest in-grid voxel exactly as in KD); anything else -- or a tile with more than kFixCap undecided
 // voxels (p = 0.03 leaves 6 % undecided: KF would take 2.5 ms where the sweeps take 1.1) -- raises `uncertified` and the guarded general sweeps redo the grid, so results are exact for any input.
 // ---------------------------------------------------------------------------------------------
-constexpr int kFixR = 8;                                      // (round 3: 6 -> 8.  At 512^3 the LARGEST distance of a Bernoulli p = 0.03 / 0.04
+constexpr int kFixR = 16;                                     // (round 3: 6 -> 8.  At 512^3 the LARGEST distance of a Bernoulli p = 0.03 / 0.04
                                                               //  scene is d^2 = 40 .. 41 on two seeds of three: one voxel beyond 36 sent the whole
                                                               //  grid to the sweeps.  The rows go past sorted by dx^2 + dy^2 with an early exit, so
-                                                              //  the voxels that never needed the outer rows do not pay for them)
+                                                              //  the voxels that never needed the outer rows do not pay for them.  Round 5: 8 -> 16,
+                                                              //  d^2 <= 256.  With the shell pass KD6 in front KF sees only what lies beyond d^2 = 36
+                                                              //  -- at p = 0.015 a few hundred voxels, most of them at the grid's faces and corners,
+                                                              //  where a voxel sees a fraction of the ball and the largest distances of a noise
+                                                              //  scene sit: d^2 = 51 .. 77 at 512^3 -- and ONE voxel beyond its reach sends the
+                                                              //  whole grid to the far-field pair ("beyond_fixup_reach" ended the tier at p = 0.015))
 constexpr int kFixCap = 512;                                  // undecided voxels a tile may hand to KF (round 3: 160 -> 512 with the
                                                               // early exit below: Bernoulli p = 0.05 leaves 0.9 % undecided -- ~280 per
                                                               // tile -- and took the marching sweeps at 0.84 ms instead; p = 0.03 leaves
@@ -455,8 +464,22 @@ constexpr int kFixTileR = 6;                                  // halo of the sta
                                                               // two batches, reached by the few voxels still open then) come from the L2-resident
                                                               // bit field -- a halo of 8 made the staging of every tile 1.56x larger (p = 0.05:
                                                               // 0.46 -> 0.58 ms per build)
-constexpr int kFixRows = (2 * kFixR + 1) * (2 * kFixR + 1);   // 289 (dx, dy) rows
-constexpr int kFixOrderPad = (kFixRows + 7) & ~7;             // LDS words reserved for the row table
+constexpr int kFixRows = (2 * kFixR + 1) * (2 * kFixR + 1);   // 1089 (dx, dy) rows
+constexpr int kFixRA = 8;                                     // phase A of a voxel's scan: the rows with dx^2 + dy^2 <= 64, bit windows of +-8 -- round 4's
+                                                              // reach, and all that nearly every voxel ever needs; phase B (rows up to 256, windows of
+                                                              // +-16) only for a voxel that is still open behind it
+__host__ __device__ constexpr int fix_rows_within(int r2max) {
+    int n = 0;
+    for (int dx = -kFixR; dx <= kFixR; ++dx)
+        for (int dy = -kFixR; dy <= kFixR; ++dy) n += (dx * dx + dy * dy <= r2max) ? 1 : 0;
+    return n;
+}
+constexpr int kFixRowsA = fix_rows_within(kFixRA * kFixRA);  // 197: a prefix of the table (sorted by dx^2 + dy^2)
+constexpr int kFixRowsB = fix_rows_within(kFixR * kFixR);    // 797
+constexpr int kFixNearRows = 320;                             // rows whose table entries are copied into LDS (sorted by dx^2 + dy^2: everything inside
+                                                              // the staged halo, dx^2 + dy^2 <= 72, and what round 4's reach of 8 covered); the rows
+                                                              // behind them are the rare far voxel's and come from the table in global memory
+constexpr int kFixOrderPad = (kFixNearRows + 7) & ~7;         // LDS words reserved for the row table
 constexpr int kFixOutside = 0x40000000;                       // rowofs[] marker: the row lies beyond the staged halo
 
 struct FixArgs {
@@ -498,7 +521,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         *count = 0u;
         count[1] = __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    for (int i = t; i < kFixRows; i += BD) {
+    for (int i = t; i < kFixNearRows; i += BD) {
         const uint32_t o = a.order[i];
         order[i] = o;
         const int dx = (int)(o & 0xffu) - kFixR, dy = (int)((o >> 8) & 0xffu) - kFixR;
@@ -606,52 +629,65 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
         words(0, 0, cw0, cw1, cw2);
         const uint32_t cls = (cw1 >> b) & 1u;
         const uint32_t flip = cls ? ~0u : 0u;                 // after the XOR a set bit = voxel of the OTHER class
-        // the bits around z of a row as two funnel shifts (v_alignbit_b32) whose shift counts depend on the voxel only:
-        //   up: bit dz of (next : cur) >> b              = voxel z + dz,          dz = 0 .. kFixR
-        //   dn: bit i  of (cur : prev) >> (32 + b - kFixR) = voxel z - kFixR + i,   i = 0 .. kFixR - 1
-        const bool dn_in_cur = b >= kFixR;                    // ... all inside `cur`: (0 : cur) >> (b - kFixR)
-        const bool up_past_cur = b + kFixR > 31;              // the upward window reaches into `next`
-        const uint32_t dn_sh = (uint32_t)(b - kFixR) & 31u;
-        int best = 1 << 20;
-        bool done = !live;
+        // One phase of the scan: the first `nrows` rows of the table (a prefix: everything with dx^2 + dy^2 <= R^2), the bits around z
+        // of a row as two funnel shifts (v_alignbit_b32) whose shift counts depend on the voxel only:
+        //   up: bit dz of (next : cur) >> b            = voxel z + dz,      dz = 0 .. R
+        //   dn: bit i  of (cur : prev) >> (32 + b - R) = voxel z - R + i,   i = 0 .. R - 1
+        // A candidate <= R^2 is then the exact squared distance: every offset that could beat it has dx^2 + dy^2 <= R^2 and |dz| <= R.
+        auto scan = [&](auto rc, int nrows, bool want) -> int {
+            constexpr int R = decltype(rc)::value;
+            const bool dn_in_cur = b >= R;                        // ... all inside `cur`: (0 : cur) >> (b - R)
+            const bool up_past_cur = b + R > 31;                  // the upward window reaches into `next`
+            const uint32_t dn_sh = (uint32_t)(b - R) & 31u;
+            int best = 1 << 20;
+            bool done = !want;
 #pragma unroll 1
-        for (int k0 = 0; k0 < kFixRows; k0 += 64) {
-            if (k0 > 0) {
-                done = done || rowmin(best) <= (int)(order[k0] >> 16);
-                if (__all(done)) break;
-            }
-            if (!done) {
+            for (int k0 = 0; k0 < nrows; k0 += 64) {
+                if (k0 > 0) {
+                    done = done || rowmin(best) <= (int)((k0 < kFixNearRows ? order[k0] : a.order[k0]) >> 16);
+                    if (__all(done)) break;
+                }
+                if (!done) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int k = k0 + gl + 16 * m;
-                    if (k < kFixRows) {
-                        const uint32_t o = order[k];
-                        const int d2 = (int)(o >> 16), ofs = rowofs[k];
-                        uint32_t prev = 0u, cur, next = 0u;
-                        if (!direct && ofs != kFixOutside) {
-                            // (the neighbour words only where this voxel's bit window leaves `cur`: half of the voxels need neither,
-                            //  and every LDS access spared is a bank conflict spared -- the rows of a group's 16 lanes are scattered)
-                            const uint32_t* p = c0 + ofs;
-                            cur = p[0];
-                            if (!dn_in_cur) prev = p[-1];
-                            if (up_past_cur) next = p[1];
-                        } else {
-                            words((int)(o & 0xffu) - kFixR, (int)((o >> 8) & 0xffu) - kFixR, prev, cur, next);
+                    for (int m = 0; m < 4; ++m) {
+                        const int k = k0 + gl + 16 * m;
+                        if (k < nrows) {
+                            const uint32_t o = k < kFixNearRows ? order[k] : a.order[k];
+                            const int d2 = (int)(o >> 16), ofs = k < kFixNearRows ? rowofs[k] : kFixOutside;
+                            uint32_t prev = 0u, cur, next = 0u;
+                            if (!direct && ofs != kFixOutside) {
+                                // (the neighbour words only where this voxel's bit window leaves `cur`: half of the voxels need neither,
+                                //  and every LDS access spared is a bank conflict spared -- the rows of a group's 16 lanes are scattered)
+                                const uint32_t* p = c0 + ofs;
+                                cur = p[0];
+                                if (!dn_in_cur) prev = p[-1];
+                                if (up_past_cur) next = p[1];
+                            } else {
+                                words((int)(o & 0xffu) - kFixR, (int)((o >> 8) & 0xffu) - kFixR, prev, cur, next);
+                            }
+                            prev ^= flip; cur ^= flip; next ^= flip;
+                            // (no hit: the forced top bit / clz(0) = 32 give dz = 31 / R + 1, i.e. a candidate above R^2 that the
+                            //  final test rejects; it cannot end the scan early before every row that could hold a real hit has gone past)
+                            const uint32_t up = (__builtin_amdgcn_alignbit(next, cur, (uint32_t)b) & ((2u << R) - 1u)) | 0x80000000u;
+                            const int dzu = __builtin_ctz(up);
+                            best = min(best, d2 + dzu * dzu);
+                            const uint32_t dn = __builtin_amdgcn_alignbit(dn_in_cur ? 0u : cur, dn_in_cur ? cur : prev, dn_sh) & ((1u << R) - 1u);
+                            const int dzd = R - 31 + __clz((int)dn);
+                            best = min(best, d2 + dzd * dzd);
                         }
-                        prev ^= flip; cur ^= flip; next ^= flip;
-                        // (no hit: the forced top bit / clz(0) = 32 give dz = 31 / kFixR + 1, i.e. a candidate above kFixR^2 that the
-                        //  final test rejects; it cannot end the scan early before every row that could hold a real hit has gone past)
-                        const uint32_t up = (__builtin_amdgcn_alignbit(next, cur, (uint32_t)b) & ((2u << kFixR) - 1u)) | 0x80000000u;
-                        const int dzu = __builtin_ctz(up);
-                        best = min(best, d2 + dzu * dzu);
-                        const uint32_t dn = __builtin_amdgcn_alignbit(dn_in_cur ? 0u : cur, dn_in_cur ? cur : prev, dn_sh) & ((1u << kFixR) - 1u);
-                        const int dzd = kFixR - 31 + __clz((int)dn);
-                        best = min(best, d2 + dzd * dzd);
                     }
                 }
             }
+            return rowmin(best);
+        };
+        int best = scan(std::integral_constant<int, kFixRA>{}, kFixRowsA, live);
+        // phase B, for the rare voxel beyond d^2 = 64 (the faces and corners of a sparse noise grid): the whole table, wide windows
+        // (its result REPLACES phase A's: a phase's value above R^2 may be the "no hit" sentinel (R + 1)^2 of a bit window, not a candidate)
+        if (__any(live && best > kFixRA * kFixRA)) {
+            const bool open_ = live && best > kFixRA * kFixRA;
+            const int wide = scan(std::integral_constant<int, kFixR>{}, kFixRowsB, open_);
+            if (open_) best = wide;
         }
-        best = rowmin(best);
         if (live) {
             if (best <= kFixR * kFixR) {
                 if (gl == 0) {
@@ -718,7 +754,7 @@ struct DenseGenArgs {
     uint32_t* uncertified;
 };
 
-__global__ __launch_bounds__(kBlock) void k_ball_dense_generic(const DenseGenArgs a) {
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_ball_dense_generic(const DenseGenArgs a) {
     __shared__ float lut[16];                                           // [class << 3 | level] -> signed magnitude
     if (threadIdx.x < 16) {
         const int l = threadIdx.x & 7;

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
     int nund = row_in_grid ? __popc(~acc[kBall3Levels - 1]) : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) nund += __shfl_xor(nund, off);
-    const bool hopeless = nund > kBall3MaxUndecided;
+    const bool hopeless = nund > a.max_undecided;
     const bool any_uncert = __any(uncert);
     const bool all_undecided = __all(row_in_grid && acc[kBall3Levels - 1] == 0u);
     if (any_uncert && a.unc) {
@@ -309,6 +309,12 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
         // maximum anyway.
         const bool void_maxima = a.early_out && __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         if (!void_maxima) slot_max2(a.slots, tile_id * (BD / 64) + ((uint32_t)t >> 6), mxF, mxQ);
+        // (every 16th wave adds its undecided voxels to one of the 512 extrema slots' third word: a 1 / 16 sample of the scene's total
+        //  for k_shell_budget.  ONE status word for all of them -- a thousand same-address atomics -- cost this kernel 76 - 190 us.)
+        if (a.und_sample && nund) {
+            const uint32_t wg = tile_id * (BD / 64) + ((uint32_t)t >> 6);
+            if ((wg & 15u) == 0u) atomicAdd(a.und_sample + (size_t)((wg >> 4) & (kSlots - 1)) * kSlotWords + 2, (uint32_t)nund);
+        }
         if (any_uncert) {
             if (a.unc) {
                 atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up

@@ -29,9 +29,9 @@
 #include <type_traits>
 
 // Non-template kernels are DEFINED in these headers.  The one translation unit that includes them only for their device
-// helpers (sdfgpu_envelope_tu.hip, the far-field kernel's instantiations) gives them internal linkage, so the library
-// holds one definition of each.
-#ifdef SDFGPU_ENVELOPE_TU
+// helpers (sdfgpu_envelope_tu.hip, sdfgpu_dense6_tu.hip: one kernel's instantiations each) gives them internal linkage, so
+// the library holds one definition of each.
+#if defined(SDFGPU_ENVELOPE_TU) || defined(SDFGPU_AUX_TU)
 #define SDFGPU_KERNEL static __global__
 #else
 #define SDFGPU_KERNEL __global__

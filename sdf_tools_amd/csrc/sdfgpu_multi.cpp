@@ -269,16 +269,22 @@ int run_steps(sdfgpu_multi_handle h, const std::vector<Step>& steps) {
 
 // rank q: my communication stream waits for the compute work enqueued so far (RCCL: my own; copies: every rank's, because a
 // copy reads the sender's buffer) / my compute stream waits for the exchange
-int cs_after_s(sdfgpu_multi_handle h, int q) {
+// (neighbours: the exchange is between x neighbours only -- bit-plane and int32 halos -- so in copy mode a rank waits for ranks
+//  q - 1, q, q + 1 instead of all of them; the re-partition is all-to-all)
+int cs_after_s(sdfgpu_multi_handle h, int q, bool neighbours = false) {
     Rank& k = h->r[(size_t)q];
+    const int G = (int)h->r.size();
     if (h->use_rccl) { R_HIP(k, hipStreamWaitEvent(k.cs, k.ev_s, 0)); }
-    else for (Rank& o : h->r) R_HIP(k, hipStreamWaitEvent(k.cs, o.ev_s, 0));
+    else for (int o = neighbours ? std::max(q - 1, 0) : 0; o <= (neighbours ? std::min(q + 1, G - 1) : G - 1); ++o)
+        R_HIP(k, hipStreamWaitEvent(k.cs, h->r[(size_t)o].ev_s, 0));
     return SDFGPU_OK;
 }
-int s_after_cs(sdfgpu_multi_handle h, int q) {
+int s_after_cs(sdfgpu_multi_handle h, int q, bool neighbours = false) {
     Rank& k = h->r[(size_t)q];
+    const int G = (int)h->r.size();
     if (h->use_rccl) { R_HIP(k, hipStreamWaitEvent(k.s, k.ev_cs, 0)); }
-    else for (Rank& o : h->r) R_HIP(k, hipStreamWaitEvent(k.s, o.ev_cs, 0));
+    else for (int o = neighbours ? std::max(q - 1, 0) : 0; o <= (neighbours ? std::min(q + 1, G - 1) : G - 1); ++o)
+        R_HIP(k, hipStreamWaitEvent(k.s, h->r[(size_t)o].ev_cs, 0));
     return SDFGPU_OK;
 }
 
@@ -395,14 +401,14 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
         steps.push_back({[&](int q) -> int {                    // exchange on the communication stream, the interior while the messages fly
             Rank& k = h->r[(size_t)q];
             if (G > 1) {
-                if (int rc = cs_after_s(h, q)) return rc;
+                if (int rc = cs_after_s(h, q, true)) return rc;
                 if (int rc = exchange_rank(h, q, msgs)) return rc;
             }
             if (int rc = phase(q, 1)) return rc;
             if (G > 1) R_HIP(k, hipEventRecord(k.ev_cs, k.cs));
             return SDFGPU_OK; }, host_barriers, false});
         steps.push_back({[&](int q) -> int {                    // the 2 + 2 border planes, then the status block
-            if (G > 1) if (int rc = s_after_cs(h, q)) return rc;
+            if (G > 1) if (int rc = s_after_cs(h, q, true)) return rc;
             if (int rc = phase(q, 2)) return rc;
             return read_small_enqueue(h, q); }, false, false});
         steps.push_back({[&](int q) -> int { return wait_rank(h, q); }, false, true});
@@ -462,13 +468,13 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
                 return SDFGPU_OK; }, host_barriers, false});
             steps.push_back({[&](int q) -> int {
                 Rank& k = h->r[(size_t)q];
-                if (int rc = cs_after_s(h, q)) return rc;
+                if (int rc = cs_after_s(h, q, true)) return rc;
                 if (int rc = exchange_rank(h, q, msgs)) return rc;
                 R_HIP(k, hipEventRecord(k.ev_cs, k.cs));
                 return SDFGPU_OK; }, host_barriers, false});
             steps.push_back({[&](int q) -> int {
                 Rank& k = h->r[(size_t)q];
-                if (int rc = s_after_cs(h, q)) return rc;
+                if (int rc = s_after_cs(h, q, true)) return rc;
                 const int64_t hl = q > 0 ? halo : 0, hh = q < G - 1 ? halo : 0, nxs = k.x1 - k.x0;
                 R_SDF(k, sdfgpu_sweep_x_device(k.ctx, (const int32_t*)k.ext.p, hl, nxs, hh, ny, nz, k.x0 - hl > 0, k.x1 + hh < nx, k.x0,
                                                nx, res, vb, d_out[q], k.d_small, k.d_small + 2, k.s));

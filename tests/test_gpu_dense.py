@@ -262,8 +262,14 @@ def test_wide_ball_kernel_every_level_edges_and_shapes(gpu):
         run(m, 0.25, True)
         run(1 - m, 0.25, True)
         m = np.zeros((12, 12, 64), np.uint8)
-        m[::6, ::6, ::6] = 1                                # (3,3,3) away -> d^2 = 27 > 14 for a third of the voxels: too many for
-        run(m, 1.0, False)                                  # the fix-up kernel, the kernel says so itself (kBall3MaxUndecided per wave)
+        m[::6, ::6, ::6] = 1                                # (3,3,3) away -> d^2 = 27 > 14 for a third of the voxels: too many for the
+        run(m, 1.0)                                         # fix-up kernel alone (rounds 3 - 4: KD3 said so itself, kBall3MaxUndecided per
+                                                            # wave); since round 5 the shell pass KD6 behind KD3 takes them
+        gpu.set_option("dense_shell", 0)
+        try:
+            run(m, 1.0, False)
+        finally:
+            gpu.set_option("dense_shell", 1)
         m = synth.bernoulli_mask((24, 24, 128), 0.08, 11)
         m[8:14, 8:14, 40:46] = 0                            # a 6^3 cavity: d^2 up to 27 for a few voxels -> KF finishes them
         run(m, 1.0, True)
@@ -280,6 +286,53 @@ def test_wide_ball_kernel_every_level_edges_and_shapes(gpu):
                 m[0, 0, 0] = 1 - m[0, 0, 0]
                 run(m, 0.3)
     finally:
+        gpu.set_option("policy_reset", 1)
+
+
+def test_shell_pass_between_the_wide_ball_and_the_fixup_kernel(gpu):
+    """Round 5, KD6 (sdfgpu_dense6.hpp): the bit-parallel shell pass 16 <= d^2 <= 36 over the words KD3 leaves undecided voxels in,
+    with KF behind it for what lies beyond.  Forced fix-up stage (KD3 + KD6 + KF) on noise down to p = 0.01 and up to 0.99 (both
+    classes), cavities that realise every level of the shell and the hand-over to KF (d^2 <= 64) and to the sweeps (beyond),
+    grid faces / word boundaries / every tile shape; every voxel and the extrema bit for bit against the exact oracle, and the
+    same bits with the pass switched off (option dense_shell = 0: KF takes everything, as in rounds 3 - 4)."""
+    def run(m, res, expect_certified=None):
+        out = []
+        for shell in (1, 0):
+            gpu.set_option("dense_shell", shell)
+            gpu.set_option("policy_reset", 1)
+            gpu.set_option("dense3_mode", 1)
+            out.append(_check(gpu, m, res, expect_certified if shell else None))
+        return out
+    try:
+        for shape, p, seed in (((64, 64, 128), 0.02, 1), ((48, 40, 256), 0.015, 2), ((64, 48, 128), 0.01, 3), ((40, 40, 64), 0.985, 4),
+                               ((32, 32, 512), 0.012, 5), ((24, 24, 1024), 0.99, 6)):
+            run(synth.bernoulli_mask(shape, p, seed), 0.05)
+        # cavities in clutter: a c^3 hole has voxels up to d^2 = 3 ((c + 1) / 2)^2 from the clutter around it -- c = 6: 27 (shell),
+        # 7: 48 (KF), 8: 48 .. 60 (KF), 10: 75 .. 90 (beyond KF: the sweeps); the levels in between come from the clutter's own noise
+        for c, cert in ((5, True), (6, True), (7, None), (8, None), (10, None)):
+            for cls in (0, 1):
+                m = synth.bernoulli_mask((32, 32, 128), 0.1, 20 + c)
+                m[10:10 + c, 12:12 + c, 50:50 + c] = 0
+                run(m if cls == 0 else 1 - m, 1.0, cert)
+        # every level of the shell at least once: one voxel pair per offset (dx, dy, dz) with 16 <= d^2 <= 36 in a clutter-free
+        # box inside clutter would need 668 scenes; the same coverage cheaply: a solid slab with pits of every depth 4 .. 6 and
+        # a lattice of single voxels whose Voronoi cells reach every d^2 up to 36
+        m = synth.bernoulli_mask((40, 40, 128), 0.15, 31)
+        m[4:36, 4:36, 20:60] = 0
+        m[::5, ::5, 20:60:5] |= 1                            # a 5-lattice in the cleared box: offsets up to (2,2,2) .. (3,3,3)
+        run(m, 0.5)
+        m = synth.bernoulli_mask((36, 36, 128), 0.15, 32)
+        m[2:34, 2:34, 10:100] = 0
+        m[2:34:8, 2:34:8, 10:100:8] |= 1                     # an 8-lattice: offsets up to (4,4,4) = 48 (levels 16 .. 36 from KD6, beyond from KF)
+        run(m, 0.5)
+        run(1 - m, 0.5)
+        for shape in ((5, 7, 32), (9, 4, 128), (3, 5, 1024), (33, 21, 96), (1, 40, 64), (2, 3, 2048), (16, 16, 512), (7, 9, 256)):
+            for p in (0.02, 0.01, 0.98):
+                m = synth.bernoulli_mask(shape, p, 9)
+                m[0, 0, 0] = 1 - m[0, 0, 0]
+                run(m, 0.3)
+    finally:
+        gpu.set_option("dense_shell", 1)
         gpu.set_option("policy_reset", 1)
 
 

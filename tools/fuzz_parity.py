@@ -76,8 +76,9 @@ while time.time() - t0 < budget:
         ctx.set_option(k, v)
     if rng.random() < 0.3:
         ctx.set_option("fixup_mode", 1)                 # force the fix-up kernel behind the dense ball kernel
-    if rng.random() < 0.25:
+    if rng.random() < 0.35:
         ctx.set_option("dense3_mode", 1)                # ... the wide ball kernel (KD3) in KD's place
+    ctx.set_option("dense_shell", int(rng.random() < 0.8))     # round 5: the shell pass (KD6) between KD3 and KF, or KF alone
     # tier selection: fresh decisions, forced far-field sweeps, both hand-off forms, low thresholds (far-field kernel on
     # scenes the marching kernels would normally take)
     if rng.random() < 0.5:

@@ -8,12 +8,12 @@ timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -150 > $O/te
 SDFGPU_HOST_TIMING=1 timeout 300 ./examples/class_seam_example 512 3 0.5 > $O/class_seam.txt 2>&1; tail -8 $O/class_seam.txt
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; python - <<PY
 import json
-d = json.load(open("$O/bench.json"))
+d = [json.loads(l) for l in open("$O/bench.json") if l.startswith("{")][0]
 print("value", d["value"], "ms", d["ms_per_step"], "roofline", d.get("roofline", {}).get("frac"), "host_api", json.dumps(d.get("host_api"))[:900])
 PY
 timeout 600 python bench.py --force-slab --steps 20 --no-cpu-baseline > $O/bench_slab.json 2> $O/bench_slab.err; python - <<PY
 import json
-d = json.load(open("$O/bench_slab.json"))
+d = [json.loads(l) for l in open("$O/bench_slab.json") if l.startswith("{")][0]
 print("slab value", d["value"], json.dumps(d.get("multi_native_on_one_gpu"))[:2500])
 PY
 timeout 300 python tools/scene_bench.py 512 > $O/scene512.jsonl 2>&1; cat $O/scene512.jsonl | cut -c1-400
