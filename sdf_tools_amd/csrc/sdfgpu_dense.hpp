@@ -501,7 +501,7 @@ __global__ __launch_bounds__(BD) void k_ball_fixup(const FixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fix_smem[];
     if (*a.fix_needed == 0u) return;
     const uint32_t tile_id = (uint32_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t flags = a.tileflag[tile_id];               // wave-uniform
+    const uint32_t flags = a.tileflag[tile_id] & 0xFFFFu;     // wave-uniform (bits 16 ..: KD3's count of open words, for the shell pass)
     if (flags == 0u) return;
     const int t = threadIdx.x;
     const int nzw = a.nzw, lg = a.log2_nzw;

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
     for (int off = 32; off >= 1; off >>= 1) nund += __shfl_xor(nund, off);
     const bool hopeless = nund > a.max_undecided;
     const bool any_uncert = __any(uncert);
+    const uint32_t open_words = (uint32_t)__popcll(__ballot(uncert));    // words of this wave that hold undecided voxels
     const bool all_undecided = __all(row_in_grid && acc[kBall3Levels - 1] == 0u);
     if (any_uncert && a.unc) {
         if (row_in_grid)
@@ -317,7 +318,10 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
         }
         if (any_uncert) {
             if (a.unc) {
-                atomicOr(a.tileflag + tile_id, 1u << (t >> 6));      // one word per tile: no same-address pile-up
+                // one word per tile: no same-address pile-up.  Bits 0 .. 15: the wave's flag; bits 16 ..: the number of WORDS this wave
+                // leaves undecided voxels in, summed over the tile's waves -- the shell pass reads four of these words and knows at
+                // once whether the group is worth staging (round 5).  (Every wave adds its own bit exactly once: add == or.)
+                atomicAdd(a.tileflag + tile_id, (1u << (t >> 6)) + (open_words << 16));
                 raise_flag(a.fix_needed);
                 // a wave without a single decided voxel sits in empty (or solid) space: nothing for the fix-up kernel
                 if ((a.early_out && all_undecided) || hopeless) {

@@ -144,7 +144,7 @@ SDFGPU_KERNEL __launch_bounds__(kSlots) void k_shell_budget(uint32_t* __restrict
 // workgroup -- ran ONE wave per tile behind a 256-row staging round with three workgroups per CU: 0.93 ms at p = 0.03, every LDS
 // latency of its 339 row reads exposed (63 M VALU wave instructions at a sixth of KD3's rate).
 constexpr int kShellGroup = 4;
-constexpr int kShellMinWords = 96;                            // active words (of kShellGroup x 256) below which a group is left to KF
+constexpr int kShellMinWords = 256;                           // active words (of kShellGroup x 256) below which a group is left to KF
 
 template <int BD>
 __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
@@ -156,13 +156,17 @@ __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
     const int ty0 = (int)blockIdx.x * kShellGroup;            // first tile of the group
     const int ntile = min(kShellGroup, tiles_y - ty0);
     uint32_t flags[kShellGroup];
-    uint32_t anyflag = 0u;
+    int n = 0;                                                // words of the group that hold undecided voxels (KD3 counted them)
 #pragma unroll
     for (int g = 0; g < kShellGroup; ++g) {
-        flags[g] = g < ntile ? a.tileflag[(uint32_t)blockIdx.y * (uint32_t)tiles_y + (uint32_t)(ty0 + g)] : 0u;   // (block-uniform)
-        anyflag |= flags[g];
+        const uint32_t f = g < ntile ? a.tileflag[(uint32_t)blockIdx.y * (uint32_t)tiles_y + (uint32_t)(ty0 + g)] : 0u;   // (block-uniform)
+        flags[g] = f & 0xFFFFu;
+        n += (int)(f >> 16);
     }
-    if (anyflag == 0u) return;
+    // A group with few active words is KF's case (one 16-lane row per VOXEL, rows read straight from the L2-resident bit field):
+    // staging 448 halo rows for them costs more than KF spends on their voxels (Bernoulli p = 0.03: 16 active words per group,
+    // p = 0.02: 184 of 1024 -- KF 0.23 ms, this pass 0.20 + KF 0.05; p = 0.015: 535).  Their undecided words stay as they are.
+    if (n < kShellMinWords) return;
     const int rw = nzw + 2;                                   // one replicated edge word on each side
     const int gty = kShellGroup * a.ty;                       // rows of the group along y
     const int hx = a.tx + 2 * kShellR, hy = gty + 2 * kShellR;
@@ -178,41 +182,23 @@ __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
     const int x0 = a.out_lo + (int)blockIdx.y * a.tx, y0 = ty0 * a.ty;
     __syncthreads();
     if (count[1] != 0u) return;                               // (block-uniform: the general sweeps will redo the grid)
-    // this lane's word in each tile of the group (KD3's mapping); how many of the group's words still hold undecided voxels
-    const int r_own = t >> lg, w_own = t & (nzw - 1);
-    const int ty_own = r_own & (a.ty - 1), tx_own = r_own >> a.log2_ty;
-    uint32_t uown[kShellGroup];
+    // this lane's word in each tile of the group (KD3's mapping) -> compacted list of the words that still hold undecided voxels,
+    // so that they fill whole waves (p = 0.015: half of the words are active).  (Leaving every lane its own words when nearly
+    // all are active -- p = 0.01: 93 %, rows at the staged pitch, no bank conflicts -- was measured too: 0.84 ms per build
+    // against 0.78 with the list.)
     {
-        int nact = 0;
+        const int r = t >> lg, w = t & (nzw - 1);
+        const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
 #pragma unroll
         for (int g = 0; g < kShellGroup; ++g) {
-            const int gy = y0 + g * a.ty + ty_own;
-            uown[g] = 0u;
-            if ((x0 + tx_own < a.out_hi) && (gy < a.ny) && ((flags[g] >> (t >> 6)) & 1u))
-                uown[g] = a.unc[((int64_t)(x0 + tx_own - a.out_lo) * a.ny + gy) * nzw + w_own];
-            nact += uown[g] ? 1 : 0;
-        }
-        const int wsum = __popcll(__ballot(nact >= 1)) + __popcll(__ballot(nact >= 2)) + __popcll(__ballot(nact >= 3)) + __popcll(__ballot(nact >= 4));
-        if ((t & 63) == 0 && wsum) atomicAdd(count, (uint32_t)wsum);
-    }
-    __syncthreads();
-    const int n = (int)count[0];
-    // A group with a handful of active words is KF's case (one 16-lane row per VOXEL, rows read straight from the L2-resident bit
-    // field): staging 448 halo rows for a dozen words costs more than KF spends on their voxels (Bernoulli p = 0.03: 16 active
-    // words per group).  Their undecided words stay as they are.
-    if (n < kShellMinWords) return;                           // (block-uniform)
-    // With most words active (p = 0.01: 93 %) every lane keeps its own words -- KD3's mapping, rows at the staged pitch: free of
-    // bank conflicts; otherwise the active words are compacted so that they fill whole waves (p = 0.02: 18 %)
-    const bool natural = 2 * n >= kShellGroup * BD;           // (block-uniform)
-    if (!natural) {
-        if (t == 0) count[2] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < kShellGroup; ++g) {
-            if (uown[g]) {
-                const uint32_t slot = atomicAdd(count + 2, 1u);
+            const int gy = y0 + g * a.ty + ty_;
+            uint32_t u = 0;
+            if ((x0 + tx_ < a.out_hi) && (gy < a.ny) && ((flags[g] >> (t >> 6)) & 1u))
+                u = a.unc[((int64_t)(x0 + tx_ - a.out_lo) * a.ny + gy) * nzw + w];
+            if (u) {
+                const uint32_t slot = atomicAdd(count, 1u);
                 list[slot] = ((uint32_t)g << 16) | (uint32_t)t;
-                ulist[slot] = uown[g];
+                ulist[slot] = u;
             }
         }
     }
@@ -302,19 +288,12 @@ __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
         // what is still open (d^2 > 36) stays in the undecided word for KF; decided words become 0 there
         if (live) a.unc[rowi * nzw + w] = U;
     };
-    if (natural) {
-#pragma unroll 1
-        for (int g = 0; g < kShellGroup; ++g) {
-            const uint32_t U = uown[g];
-            if (__any(U != 0u)) do_word(g, t, U, U != 0u);    // (wave-uniform)
-        }
-    } else {
-        for (int i0 = t - (t & 63); i0 < n; i0 += BD) {       // (whole waves: a wave without an entry leaves)
-            const int i = i0 + (t & 63);
-            const bool live = i < n;
-            const uint32_t e = list[live ? i : 0];
-            do_word((int)(e >> 16), (int)(e & 0xffffu), live ? ulist[i] : 0u, live);
-        }
+    const int nl = (int)count[0];                             // (== n unless a tile sticks out of the grid)
+    for (int i0 = t - (t & 63); i0 < nl; i0 += BD) {          // (whole waves: a wave without an entry leaves)
+        const int i = i0 + (t & 63);
+        const bool live = i < nl;
+        const uint32_t e = list[live ? i : 0];
+        do_word((int)(e >> 16), (int)(e & 0xffffu), live ? ulist[i] : 0u, live);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
