@@ -1168,7 +1168,11 @@ int staged_upload(sdfgpu_handle h, void* d_dst, size_t bytes, hipStream_t st, in
     const unsigned hw = std::thread::hardware_concurrency();
     const int team = (int)std::max<size_t>(1, std::min<size_t>((size_t)team_cap, hw / 4));
     std::atomic<int64_t> may_fill{1};                    // chunks 0 .. may_fill may be written to their staging buffer
-    std::atomic<int64_t> filled{0};                      // slices filled so far (team slices per chunk)
+    // slices filled, PER CHUNK: chunks i and i + 1 may be filled at the same time, so one running total would let the fast
+    // threads' slices of chunk i + 1 stand in for a slow thread's slice of chunk i (round 5: seen once in ~10 runs of the
+    // 100 MiB copy test after the calling thread became a filler)
+    std::vector<std::atomic<int>> filled((size_t)nchunks);
+    for (auto& f : filled) f.store(0, std::memory_order_relaxed);
     std::atomic<bool> abort{false};
     auto chunk_bytes = [&](int64_t i) { return std::min(kPinChunk, bytes - (size_t)i * kPinChunk); };
     auto work = [&](int w) {
@@ -1181,7 +1185,7 @@ int staged_upload(sdfgpu_handle h, void* d_dst, size_t bytes, hipStream_t st, in
             const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
             const size_t b = std::min(len, (size_t)w * per), e = std::min(len, b + per);
             if (e > b) fill(static_cast<char*>(h->pin[i & 1]) + b, (size_t)i * kPinChunk + b, e - b);
-            filled.fetch_add(1, std::memory_order_release);
+            filled[(size_t)i].fetch_add(1, std::memory_order_release);
         }
     };
     std::vector<std::thread> workers;
@@ -1194,7 +1198,7 @@ int staged_upload(sdfgpu_handle h, void* d_dst, size_t bytes, hipStream_t st, in
         const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
         const size_t e = std::min(len, per);
         if (e > 0) fill(static_cast<char*>(h->pin[0]), 0, e);
-        filled.fetch_add(1, std::memory_order_release);
+        filled[(size_t)0].fetch_add(1, std::memory_order_release);
     }
     std::thread rest;                                    // ... and hands its slices of the later chunks to one more worker
     if (nchunks > 1) rest = std::thread([&]() {
@@ -1207,11 +1211,11 @@ int staged_upload(sdfgpu_handle h, void* d_dst, size_t bytes, hipStream_t st, in
             const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
             const size_t e = std::min(len, per);
             if (e > 0) fill(static_cast<char*>(h->pin[i & 1]), (size_t)i * kPinChunk, e);
-            filled.fetch_add(1, std::memory_order_release);
+            filled[(size_t)i].fetch_add(1, std::memory_order_release);
         }
     });
     for (int64_t i = 0; i < nchunks && err == hipSuccess; ++i) {
-        while (filled.load(std::memory_order_acquire) < (i + 1) * team) std::this_thread::yield();
+        while (filled[(size_t)i].load(std::memory_order_acquire) < team) std::this_thread::yield();
         err = hipMemcpyAsync(static_cast<char*>(d_dst) + (size_t)i * kPinChunk, h->pin[i & 1], chunk_bytes(i), hipMemcpyHostToDevice, st);
         if (err == hipSuccess) err = hipEventRecord(h->pin_ev[i & 1], st);
         // chunk i + 1 was released for filling already; chunk i + 2 shares this chunk's buffer: release it once this DMA is done

@@ -143,8 +143,8 @@ SDFGPU_KERNEL __launch_bounds__(kSlots) void k_shell_budget(uint32_t* __restrict
 // words fill whole waves even where a single tile holds a dozen (p = 0.03: 13 per tile).  The first version -- one tile per
 // workgroup -- ran ONE wave per tile behind a 256-row staging round with three workgroups per CU: 0.93 ms at p = 0.03, every LDS
 // latency of its 339 row reads exposed (63 M VALU wave instructions at a sixth of KD3's rate).
-constexpr int kShellGroup = 4;
-constexpr int kShellMinWords = 256;                           // active words (of kShellGroup x 256) below which a group is left to KF
+constexpr int kShellGroup = 2;
+constexpr int kShellMinWords = 128;                           // active words (of kShellGroup x 256) below which a group is left to KF
 
 template <int BD>
 __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
@@ -195,10 +195,18 @@ __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
             uint32_t u = 0;
             if ((x0 + tx_ < a.out_hi) && (gy < a.ny) && ((flags[g] >> (t >> 6)) & 1u))
                 u = a.unc[((int64_t)(x0 + tx_ - a.out_lo) * a.ny + gy) * nzw + w];
-            if (u) {
-                const uint32_t slot = atomicAdd(count, 1u);
-                list[slot] = ((uint32_t)g << 16) | (uint32_t)t;
-                ulist[slot] = u;
+            // (ordered within the wave -- ballot + prefix, one atomic per wave and tile: neighbouring entries are neighbouring words
+            //  of a row, so a wave's LDS reads in the shell pass spread over the banks; one atomic per WORD left them in arrival order)
+            const uint64_t bal = __ballot(u != 0u);
+            if (bal) {
+                uint32_t base = 0u;
+                if ((t & 63) == 0) base = atomicAdd(count, (uint32_t)__popcll(bal));
+                base = (uint32_t)__shfl((int)base, 0);
+                if (u) {
+                    const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << (t & 63)) - 1ull));
+                    list[slot] = ((uint32_t)g << 16) | (uint32_t)t;
+                    ulist[slot] = u;
+                }
             }
         }
     }
@@ -252,6 +260,7 @@ __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
     const int nz = nzw << 5;
     int mxF = 0, mxQ = 0;
     // one word: the shell in two halves, levels in increasing d^2 -- a voxel takes the first level that shows a voxel of the other class
+    const bool merged = 4 * n >= 3 * kShellGroup * BD;        // three quarters of the group's words are open (Bernoulli p <= ~0.012)
     auto do_word = [&](int g, int tt, uint32_t U, bool live) {
         const int r = tt >> lg, w = tt & (nzw - 1);
         const int ty_ = g * a.ty + (r & (a.ty - 1)), tx_ = r >> a.log2_ty;
@@ -279,11 +288,16 @@ __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
                 }
             });
         };
-        shell_pass<0, kShellSplit>(c0, rowofs, O, acc);
-        resolve(std::integral_constant<int, 0>{}, std::integral_constant<int, kShellSplit>{});
-        if (__any(U != 0u)) {                                 // (wave-uniform)
-            shell_pass<kShellSplit, kShellLevels>(c0, rowofs, O, acc);
-            resolve(std::integral_constant<int, kShellSplit>{}, std::integral_constant<int, kShellLevels>{});
+        if (merged) {                                         // (block-uniform) sparse scene: nearly every wave needs the outer half too --
+            shell_pass<0, kShellLevels>(c0, rowofs, O, acc);  // one walk over the 113 rows instead of 81 + 113
+            resolve(std::integral_constant<int, 0>{}, std::integral_constant<int, kShellLevels>{});
+        } else {
+            shell_pass<0, kShellSplit>(c0, rowofs, O, acc);
+            resolve(std::integral_constant<int, 0>{}, std::integral_constant<int, kShellSplit>{});
+            if (__any(U != 0u)) {                             // (wave-uniform)
+                shell_pass<kShellSplit, kShellLevels>(c0, rowofs, O, acc);
+                resolve(std::integral_constant<int, kShellSplit>{}, std::integral_constant<int, kShellLevels>{});
+            }
         }
         // what is still open (d^2 > 36) stays in the undecided word for KF; decided words become 0 there
         if (live) a.unc[rowi * nzw + w] = U;

@@ -15,7 +15,7 @@ for i in range(8):
 print(p, ctx.last_path())
 PY
 cd /tmp; export TMPDIR=/tmp
-for p in 0.03 0.02; do
+for p in 0.015 0.01; do
   rocprofv3 --kernel-trace --stats -d $O/st_$p -o s --output-format csv -- python /tmp/w.py $p > $O/w_$p.log 2>&1
   grep "dense_certified" $O/w_$p.log | cut -c1-300
   cd $R; python tools/rocprof_summary.py stats gpurun_out/$tag/st_$p $O/stats_$p.md > /dev/null 2>&1; head -12 $O/stats_$p.md | cut -c1-160; cd /tmp
