@@ -3,7 +3,7 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
 # bench line, kernel-trace stats of the bench and of the streaming / far-field workloads, PMC passes (HBM traffic and SQ
 # counters; counters are collected in their own runs, with --kernel-trace only).
-tag=${1:-r04}
+tag=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
