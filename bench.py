@@ -524,7 +524,8 @@ def main():
                                "ms_per_step_by_rank": [round(v, 4) for v in per_rank_ms],
                                "general_path_builds": builder.general_builds, "whole_line_sweeps": builder.fallbacks,
                                "general_path_host_reads": builder.host_reads, "general_path_mispredictions": builder.mispredictions}
-    if world > 1:
+    if use_slab:
+        # (also at world = 1 with --force-slab: the same code path runs on a one-GPU box every round)
         # BASELINE.md section 3's target is ">= 6x at 8 GPUs ON 1024^3": the denominator is the SAME grid on ONE GPU, not the
         # 512^3 N = 1 line.  Rank 0 builds the whole grid of this run through the single-GPU ABI (same masks' seeds, same
         # timing discipline, fewer steps) while the other ranks wait at the barrier; value / that rate = vs_1gpu_same_grid.
@@ -552,7 +553,8 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:
                 same = {"error": repr(e)}
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         if rank == 0:
             result["vs_1gpu_same_grid"] = same
     # whole step against the compulsory 5 B/voxel (mask in, fp32 out) and against SURVEY 8(d)'s 17 B/voxel

@@ -89,6 +89,7 @@ struct sdfgpu_context {
     bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool shell_on = true;            // KD6, the bit-parallel shell pass between KD3 and KF (option "dense_shell")
+    int shell_min_words = kShellMinWords;   // option "shell_min_words"
     int shell_budget_den = 8;        // ... for scenes with at most 1 / 8 of their voxels undecided behind KD3 (option "shell_budget_den"): Bernoulli
                                      // p = 0.01 leaves 8 % (0.78 ms against the far-field pair's 0.96), p = 0.007 17 % (1.07 ms against 0.97)
     int force_env = -1;              // -1 automatic, 1 = envelope kernels only (option "envelope_mode")
@@ -551,7 +552,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         //  workgroups per CU -- with 128 or 256 lanes are 12 - 25 % slower than 16 lines x 256 lanes, 16 lines x 512 lanes
         //  +-5 %, 32 lines x 512 lanes +-3 %; 2 instead of 4 workgroups per CU is 1.55x slower)
         // lines above 512: the tile's keys take 66 KB and more, two workgroups per CU -- of 512 lanes then (round 4: with 256 they
-        // left the CU at 2 waves per SIMD, and 1024-voxel lines cost 1.5 - 2x their share)
+        // left the CU at 2 waves per SIMD, and 1024-voxel lines cost 1.5 - 2x their share).  Round 5 tried the other way out, 8 lines
+        // x 256 lanes (38 KB: four workgroups per CU again) on the 1024^3 scenes: same fields bit for bit, room 18.1 ms instead of
+        // 16.0, boxes / shells / spheres within 2 % -- the long lines are not short of resident workgroups
         const bool big = a.L > 512 && !loop;
         const int NT = big ? 512 : 256;
         a.ntiles = ntiles;
@@ -740,7 +743,7 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
             const uint32_t budget = (uint32_t)std::max<int64_t>((out_hi - out_lo) * ny * nz / h->shell_budget_den / 16, 2048);
             hipLaunchKernelGGL(k_shell_budget, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_fix_needed, d_uncert, a.reason, budget);
             sa.nzw = a.nzw; sa.log2_nzw = a.log2_nzw; sa.ny = a.ny; sa.rows_x = a.rows_x; sa.out_lo = a.out_lo; sa.out_hi = a.out_hi;
-            sa.tx = a.tx; sa.ty = a.ty; sa.log2_ty = a.log2_ty; sa.resolution = resolution; sa.slots = h->d_slots;
+            sa.tx = a.tx; sa.ty = a.ty; sa.log2_ty = a.log2_ty; sa.resolution = resolution; sa.slots = h->d_slots; sa.min_words = h->shell_min_words;
             const size_t slds = shell_lds_bytes(256, a.tx, a.ty, a.nzw);
             if (slds <= 64 * 1024) {
                 const dim3 sgrid((unsigned)((gx + kShellGroup - 1) / kShellGroup), (unsigned)gy);       // kShellGroup tiles (along y) per workgroup
@@ -2086,6 +2089,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense3") { h->pol.dense3_on = value != 0; h->pol.dense3_mode = false; }
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
     else if (n == "dense_shell") h->shell_on = value != 0;
+    else if (n == "shell_min_words") h->shell_min_words = value >= 0 ? value : kShellMinWords;
     else if (n == "shell_budget_den") h->shell_budget_den = value >= 1 ? value : 8;
     else if (n == "dense3_staged") h->pol.dense3_staged = value != 0;
     else if (n == "fixup_mode") h->pol.fix_mode = value != 0;

@@ -43,6 +43,7 @@ struct ShellArgs {
     double resolution;      // a level's magnitude is float(sqrt(double(d^2)) * resolution), the reference's arithmetic (sdf_generation.hpp:254-265);
                             // d^2 is a compile-time constant per level, so its correctly rounded square root is folded by the compiler
     uint32_t* slots;
+    int min_words;          // active words of a group below which it is left to KF
 };
 
 // The (dx, dy) rows of the shell, grouped by r2 = dx^2 + dy^2: which dz of a row belong to the shell, and to which level, depends
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(BD) void k_ball_shell(const ShellArgs a) {
     // A group with few active words is KF's case (one 16-lane row per VOXEL, rows read straight from the L2-resident bit field):
     // staging 448 halo rows for them costs more than KF spends on their voxels (Bernoulli p = 0.03: 16 active words per group,
     // p = 0.02: 184 of 1024 -- KF 0.23 ms, this pass 0.20 + KF 0.05; p = 0.015: 535).  Their undecided words stay as they are.
-    if (n < kShellMinWords) return;
+    if (n < a.min_words) return;
     const int rw = nzw + 2;                                   // one replicated edge word on each side
     const int gty = kShellGroup * a.ty;                       // rows of the group along y
     const int hx = a.tx + 2 * kShellR, hy = gty + 2 * kShellR;

@@ -69,5 +69,6 @@ for name, mk in SCENES:
     p = ctx.last_path()
     result[name] = {"filled_fraction": round(float(mask.float().mean().item()), 4), "first_build_ms": round(first, 3), "ms_per_build": round(ms, 3),
                     "path": {k: p[k] for k in ("dense_certified", "far_y", "far_x")},
-                    "stages_ms": {k: round(v / max(b, 1), 3) for k, v in zip(names, st) if v > 0}, "extrema": ctx.get_extrema()}
+                    "stages_ms": {k: round(v / max(b, 1), 3) for k, v in zip(names, st) if v > 0}, "extrema": ctx.get_extrema(),
+                    "checksum": int(out.view(torch.int32).to(torch.int64).sum().item())}
     print(json.dumps({name: result[name]}), flush=True)
