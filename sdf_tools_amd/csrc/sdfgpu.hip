@@ -107,6 +107,7 @@ struct sdfgpu_context {
     bool i32_handoff = true;         // far-field pair: int32 plane field between the y and x sweeps (option "i32_handoff")
     bool standby_far = true;         // stand-by pipeline behind a trusted dense tier = the far-field pair (bounded whatever the scene
                                      // turns into), not fused K12 + K3/16 with unbounded scans (option "standby_far")
+    bool standby_fold = true;        // the stand-by x sweep's launch folds the maxima and publishes the status block itself (option "standby_fold")
     int standby_grid = 1024;         // workgroups of the stand-by launches (LOOP form; option "standby_grid"): 4 per CU = all resident at once
     bool dc_attr_set[12] = {false, false, false, false, false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
@@ -421,6 +422,8 @@ int launch_sweep_x(sdfgpu_handle h, const int32_t* d_in, float* d_out, int64_t h
 
 // Shapes the far-field kernel takes (any line count; keys must fit 32 bits: finf + (L + 2)^2 < 2^(32 - B)).
 struct DcGeometry { bool ok; int B; uint32_t finf; int pitch; int M, Kp; };
+// dynamic LDS a far-field launch may ask for: the CU's 160 KB less the kernel's few static words (the fold of the stand-by x sweep)
+constexpr size_t kDcMaxDynamicLds = 160 * 1024 - 256;
 struct DcExtra {                 // int32 plane fields instead of p16 + side table, y-slab geometry
     const int32_t* in_i32 = nullptr;
     int32_t* out_i32 = nullptr;
@@ -430,6 +433,9 @@ struct DcExtra {                 // int32 plane fields instead of p16 + side tab
     const uint32_t* bits = nullptr;         // stage 2: z distances from the dense tier's bit field instead of the z field (forces the scalar form)
     int nzw = 0;
     uint32_t* ran_flag = nullptr;           // status word raised by a launch that does work
+    uint32_t* fold_result = nullptr;        // stage 3, LOOP form: the launch also does the end-of-build fold (fold_ticket = a free status word)
+    uint32_t* fold_report = nullptr;
+    uint32_t* fold_ticket = nullptr;
 };
 struct DcDecide {                // a probe launch turns its counters into the tier decision itself (last workgroup)
     int stage = 0; bool dense_tried = false, handoff = false, window_choice = false;
@@ -445,7 +451,7 @@ DcGeometry envelope_dc_geometry(const sdfgpu_context* h, int stage, int64_t nx, 
     const int64_t finf = (nx - 1) * (nx - 1) + (ny_full - 1) * (ny_full - 1) + (nz - 1) * (nz - 1) + 1;   // > every real d^2
     if (finf + (L + 2) * (L + 2) >= (1ll << (32 - B))) return g;
     if ((L + 2) * (2ll << B) >= (1ll << 23)) return g;            // 24-bit multiplier operands
-    if (envelope_dc_lds_bytes((int)L) > 160 * 1024) return g;
+    if (envelope_dc_lds_bytes((int)L) > kDcMaxDynamicLds) return g;
     g.ok = true; g.B = B; g.finf = (uint32_t)finf;
     g.pitch = envelope_dc_pitch((int)L);
     g.M = (int)((L + 7) / 8);
@@ -482,6 +488,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
             a.ran_flag = ex->ran_flag;
             if (stage == 2) { a.bits = ex->bits; a.nzw = ex->nzw; }
+            if (stage == 3 && ex->loop && ex->fold_ticket && !probe_out) {
+                a.fold_status = h->d_small; a.fold_result = ex->fold_result; a.fold_report = ex->fold_report; a.fold_ticket = ex->fold_ticket;
+            }
         }
         const bool loop = ex && ex->loop && !probe_out;
         a.maxdsq = h->d_slots; a.guard = guard; a.guard_invert = guard_invert;
@@ -565,7 +574,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         auto launch = [&](auto kern) -> int {
             // (the attribute is per kernel: raised once per instantiation, not on every launch -- ADVICE r3)
             if (lds > 64 * 1024 && !h->dc_attr_set[which]) {
-                HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                HIP_TRY(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDcMaxDynamicLds));
                 h->dc_attr_set[which] = true;
             }
             hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3((unsigned)NT), lds, s, a);
@@ -966,7 +975,14 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     sb2.out_i32 = (int32_t*)h->yzfield.ptr; sb2.loop = true; sb2.ran_flag = h->d_small + 4;
     sb2.bits = (const uint32_t*)h->bits.ptr; sb2.nzw = (int)((nz + 31) / 32);
     sb3.in_i32 = (const int32_t*)h->yzfield.ptr; sb3.loop = true; sb3.ran_flag = h->d_small + 5;
+    // (moved up: the stand-by x sweep does the fold itself and needs to know where the report goes)
+    const bool report = h->envelope_on && h->h_flags_dev && !h->flags_pending && dense;
+    bool folded = false;
     if (standby) {
+        if (h->standby_fold) {
+            sb3.fold_result = h->d_result; sb3.fold_report = report ? h->h_flags_dev : nullptr; sb3.fold_ticket = h->d_small + 23;
+            folded = true;
+        }
         HIP_TRY(h, mark(4));                                    // (stage slot 3, the marching y sweep: nothing launched)
         if (int rc = launch_envelope(h, 2, nullptr, nullptr, nullptr, nullptr, nx, ny, nz, resolution, vb,
                                      h->d_small, general_guard, s, 0, nullptr, &sb2)) return rc;
@@ -1053,8 +1069,8 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // (only a build that carried the dense tier has anything to teach the policy: the builds of a pause leave the report slot
     //  free, so that the PROBE at its end is the build whose verdict comes back -- with every build reporting, the slot was
     //  usually taken by a paused build when the probe came, its failure went unseen and the pause never grew; tests/policy_harness)
-    const bool report = h->envelope_on && h->h_flags_dev && !h->flags_pending && dense;
-    if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : nullptr)) return rc;
+    // (a stand-by build: the x sweep's launch has done it -- one launch less behind the dense kernel)
+    if (!folded) if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : nullptr)) return rc;
     h->small_clean = true;
     h->guard = nullptr;
     h->far_y = nullptr;
@@ -2078,6 +2094,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "standby_far") h->standby_far = value != 0;
     else if (n == "host_pack") h->host_pack = (value >= 0 && value <= 2) ? value : 1;
+    else if (n == "standby_fold") h->standby_fold = value != 0;
     else if (n == "standby_grid") h->standby_grid = value >= 32 ? value : 1024;
     else if (n == "expect_dense") h->pol.expect_dense = value != 0;      // tests: put the handle into the "dense tier trusted" state
     else if (n == "pack_variant") h->pack_variant = value;

@@ -111,6 +111,14 @@ struct EnvDcArgs {
     int nzw;                  // voxel z = 32 w + i is filled) INSTEAD of the z field: the stand-by behind a trusted dense tier computes
                               // the z distances itself, so that it needs no z sweep launched in front of it (see zdist_from_bits)
     uint32_t* ran_flag;       // nullptr, or a status word that a launch which does work raises (the stand-by pair reports itself)
+    // LOOP form, STAGE 3 -- the last launch of a stand-by build -- also does the end-of-build fold (k_fold_slots's job: maxima,
+    // status block -> result / report, clear): fold_status = the status block (nullptr: no fold here), fold_ticket = a word of it
+    // that counts the workgroups that have finished.  A launch that leaves on its guard has written nothing: workgroup 0 folds
+    // straight away; one that works folds in the workgroup that finishes last.
+    uint32_t* fold_status;
+    uint32_t* fold_result;
+    uint32_t* fold_report;
+    uint32_t* fold_ticket;
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -406,7 +414,14 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dc_smem[];
     if (a.guard) {
         const uint32_t gv = *a.guard;
-        if ((gv != 0u) == (a.guard_invert != 0)) { probe_done(a); return; }
+        if ((gv != 0u) == (a.guard_invert != 0)) {
+            if constexpr (LOOP && STAGE == 3) {
+                if (a.fold_status && blockIdx.x == 0)           // (block-uniform; nothing of this launch writes the slots or the status block)
+                    fold_slots_device<NT>(a.maxdsq, a.fold_status, a.fold_result, a.fold_report, (int)threadIdx.x);
+            }
+            probe_done(a);
+            return;
+        }
     }
     const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
     if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
@@ -1078,6 +1093,19 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             mxQ = imax(mxQ, __shfl_xor(mxQ, off));
         }
         if ((t & 63) == 0) slot_max2(a.maxdsq, blockIdx.x * (NT / 64) + (t >> 6), mxF, mxQ);
+        if constexpr (LOOP) {
+            if (a.fold_status) {                                // (launch-uniform)
+                __shared__ uint32_t fold_last;
+                __threadfence();                                // this workgroup's slot maxima (and workgroup 0's ran_flag) before its ticket
+                __syncthreads();
+                if (t == 0) fold_last = (atomicAdd(a.fold_ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+                __syncthreads();
+                if (fold_last) {                                // (block-uniform) every other workgroup has finished
+                    __threadfence();
+                    fold_slots_device<NT>(a.maxdsq, a.fold_status, a.fold_result, a.fold_report, t);     // (clears the ticket with the status block)
+                }
+            }
+        }
     }
 }
 

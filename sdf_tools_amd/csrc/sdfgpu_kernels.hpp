@@ -86,39 +86,53 @@ __device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mx
 // uncertified, far flags, fix_needed, -}): the final block is written to `result` (device; what get_extrema reads)
 // and to `report` (pinned host memory mapped into the device; the policy's asynchronous "what did this build need"),
 // and the status block is cleared for the next build -- one kernel instead of fold + copy kernel + fill kernel.
-SDFGPU_KERNEL __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
-                                                       uint32_t* __restrict__ result, uint32_t* __restrict__ report) {
-    __shared__ uint32_t part[2 * (kSlots / 64)];
-    uint32_t* p = slots + (size_t)threadIdx.x * kSlotWords;
-    uint32_t f = p[0], q = p[1];
+// (the body as a device function: the stand-by x sweep of a build folds for itself -- one launch less per build -- see
+//  k_envelope_dc's LOOP form; loads through the L2, because in that kernel other workgroups of the SAME launch may have written)
+template <int NT>
+__device__ __forceinline__ void fold_slots_device(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
+                                                  uint32_t* __restrict__ result, uint32_t* __restrict__ report, const int t) {
+    static_assert(NT % 64 == 0 && NT >= 64 && kSlots % NT == 0, "whole waves, whole rounds over the slots");
+    __shared__ uint32_t part[2 * (NT / 64)];
+    uint32_t f = 0, q = 0;
+#pragma unroll
+    for (int i = 0; i < kSlots / NT; ++i) {
+        uint32_t* p = slots + (size_t)(t + i * NT) * kSlotWords;
+        const uint32_t f1 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t q1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f1) p[0] = 0;
+        if (q1) p[1] = 0;
+        f = max(f, f1); q = max(q, q1);
+    }
     uint32_t st = 0;
-    if (result && threadIdx.x < kStatusWords) st = __hip_atomic_load(maxdsq + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (f) p[0] = 0;
-    if (q) p[1] = 0;
+    if (result && t < kStatusWords) st = __hip_atomic_load(maxdsq + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         f = max(f, (uint32_t)__shfl_xor((int)f, off));
         q = max(q, (uint32_t)__shfl_xor((int)q, off));
     }
-    if ((threadIdx.x & 63) == 0) { part[2 * (threadIdx.x >> 6)] = f; part[2 * (threadIdx.x >> 6) + 1] = q; }
+    if ((t & 63) == 0) { part[2 * (t >> 6)] = f; part[2 * (t >> 6) + 1] = q; }
     __syncthreads();
-    if (threadIdx.x < kStatusWords) {                          // lanes 0..23 of wave 0: one status word each
+    if (t < kStatusWords) {                                    // lanes 0..23 of wave 0: one status word each
 #pragma unroll
-        for (int w = 0; w < kSlots / 64; ++w) { f = max(f, part[2 * w]); q = max(q, part[2 * w + 1]); }
+        for (int w = 0; w < NT / 64; ++w) { f = max(f, part[2 * w]); q = max(q, part[2 * w + 1]); }
         if (!result) {
-            if (threadIdx.x == 0 && f) atomic_max_if_larger(maxdsq + 0, f);
-            if (threadIdx.x == 1 && q) atomic_max_if_larger(maxdsq + 1, q);
+            if (t == 0 && f) atomic_max_if_larger(maxdsq + 0, f);
+            if (t == 1 && q) atomic_max_if_larger(maxdsq + 1, q);
         } else {
-            if (threadIdx.x == 0) st = max(st, f);
-            if (threadIdx.x == 1) st = max(st, q);
-            result[threadIdx.x] = st;
+            if (t == 0) st = max(st, f);
+            if (t == 1) st = max(st, q);
+            result[t] = st;
             // (host copy: words 0..7, and KD's own verdict -- word 20 -- as word 8.  Every word is a separate write across
             //  PCIe that the kernel's end waits for: publishing all 24 made every build 0.04 ms longer)
-            if (report && (threadIdx.x < 8 || threadIdx.x == 20))
-                __hip_atomic_store(report + (threadIdx.x == 20 ? 8 : threadIdx.x), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            maxdsq[threadIdx.x] = 0;
+            if (report && (t < 8 || t == 20))
+                __hip_atomic_store(report + (t == 20 ? 8 : t), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            maxdsq[t] = 0;
         }
     }
+}
+SDFGPU_KERNEL __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
+                                                       uint32_t* __restrict__ result, uint32_t* __restrict__ report) {
+    fold_slots_device<kSlots>(slots, maxdsq, result, report, (int)threadIdx.x);
 }
 
 constexpr int kInf16 = 32767;        // "no opposite voxel in this z row"
