@@ -399,7 +399,9 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
  * bit 1 = 16-bit plane field (K3/16), bit 2 = dense kernel (K0 + KD) enqueued in front, bit 3 = the guarded
  * stand-by behind a trusted dense tier was the far-field pair (K1 -> KE2 -> KE3, bounded on any scene), bit 4 = the
  * dense stage was its wide form (KD3 + fix-up kernel in KD's place), bit 5 = that form was enqueued BEHIND KD, guarded on
- * KD's verdict (a build that had no reason to expect that KD decides the scene). */
+ * KD's verdict (a build that had no reason to expect that KD decides the scene), bit 6 = the far-field pair was enqueued
+ * without probes and marching launches because the handle's recent builds were far-field on both axes (option
+ * "far_predict": 0 never, 1 learnt -- the default --, 2 every build; exact either way, every 16th build probes again). */
 int sdfgpu_last_build_info(sdfgpu_handle h, int* out_fused_zy);
 
 /* Which path did the work of the last build (synchronises): bit 0 = the dense kernel decided every voxel

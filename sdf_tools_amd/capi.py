@@ -361,7 +361,8 @@ class SdfGpu:
         v = ctypes.c_int()
         self._check(self._lib.sdfgpu_last_build_info(self._h, ctypes.byref(v)))
         return {"fused_zy": bool(v.value & 1), "plane16": bool(v.value & 2), "dense": bool(v.value & 4),
-                "standby_far": bool(v.value & 8), "dense3": bool(v.value & 16), "dense3_staged": bool(v.value & 32)}
+                "standby_far": bool(v.value & 8), "dense3": bool(v.value & 16), "dense3_staged": bool(v.value & 32),
+                "far_predicted": bool(v.value & 64)}
 
     def last_path(self):
         """{'dense_certified', 'far_y', 'far_x'} of the last build (synchronises)."""

@@ -274,3 +274,50 @@ def test_divide_and_conquer_envelope_kernel_is_exact(gpu, shape):
         gpu.set_option("i32_handoff", 1)
         gpu.set_option("envelope_mode", 0)
         gpu.set_option("dense", 1)
+
+
+def test_far_field_prediction_skips_the_probes_and_stays_exact(gpu):
+    """Round 5: a handle whose recent builds were far-field on both axes enqueues KE2 -> KE3 directly (no probes, no guarded
+    marching launches; sdfgpu_last_build_info bit 6), probes again every 16th build, and drops the habit when the scene
+    changes.  Every build -- predicted or not, right or wrong -- equals the exact oracle bit for bit."""
+    res = 0.02
+    far = _two_boxes((96, 80, 64))
+    far_want, far_ext, _ = O.exact_sdf(far, res, False)
+    near = synth.bernoulli_mask((96, 80, 64), 0.3, 7)
+    near_want, near_ext, _ = O.exact_sdf(near, res, False)
+    gpu.set_option("dense", 0)                                   # (the general tiers alone: the dense tier would certify `near`)
+    predicted = []
+    try:
+        for i in range(40):
+            sdf, ext = gpu.build(far, res, False)
+            assert np.array_equal(sdf.view(np.uint32), far_want.view(np.uint32)) and ext == far_ext, i
+            predicted.append(gpu.last_build_info()["far_predicted"])
+            path = gpu.last_path()
+            assert path["far_y"] and path["far_x"], (i, path)
+        assert not any(predicted[:4]) and sum(predicted) >= 24, predicted        # learnt after a few reports ...
+        assert not all(predicted[8:]), predicted                                   # ... and re-probed every 16th build
+        # the scene turns near-field under the handle: at most a few builds still take the far-field pair (exactly), then the probes are back
+        predicted = []
+        for i in range(40):
+            sdf, ext = gpu.build(near, res, False)
+            assert np.array_equal(sdf.view(np.uint32), near_want.view(np.uint32)) and ext == near_ext, i
+            predicted.append(gpu.last_build_info()["far_predicted"])
+        assert not any(predicted[20:]), predicted
+        path = gpu.last_path()
+        assert not path["far_y"] and not path["far_x"], path
+        # forced: every build, whatever the scene
+        gpu.set_option("far_predict", 2)
+        for m, want, want_ext in ((near, near_want, near_ext), (far, far_want, far_ext)):
+            for vb in (False, True):
+                w, we = (want, want_ext) if not vb else O.exact_sdf(m, res, True)[:2]
+                sdf, ext = gpu.build(m, res, vb)
+                assert gpu.last_build_info()["far_predicted"]
+                assert np.array_equal(sdf.view(np.uint32), w.view(np.uint32)) and ext == we, vb
+        gpu.set_option("far_predict", 0)
+        for i in range(8):
+            sdf, ext = gpu.build(far, res, False)
+            assert not gpu.last_build_info()["far_predicted"]
+        assert np.array_equal(sdf.view(np.uint32), far_want.view(np.uint32))
+    finally:
+        gpu.set_option("far_predict", 1)
+        gpu.set_option("dense", 1)
