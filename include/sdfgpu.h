@@ -389,7 +389,13 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  * launches, default 1024), "expect_dense" (tests: 1 = put the handle into the "dense tier trusted" state for the next build),
  * "host_pack" (host-buffer entry points: 1 = inputs of 4 MiB and more are classified into one bit per voxel by the host's
  * thread team and 1/8 B per voxel is uploaded, default; 0 = upload the caller's mask / cells and classify on the device;
- * 2 = classify on the host whatever the size -- sdfgpu_upload_classified).
+ * 2 = classify on the host whatever the size -- sdfgpu_upload_classified), "far_predict" (1 = a handle whose recent builds were
+ * far-field on both axes enqueues the far-field pair without probes and marching launches and probes again every 16th build,
+ * default; 0 = every build probes; 2 = every build takes the far-field pair), "standby_fold" (1 = the last launch of a stand-by
+ * build also folds the extrema and publishes the status block, default; 0 = a launch of its own), "dense_shell" (1 = the shell
+ * pass KD6, 16 <= d^2 <= 36, between KD3 and the fix-up kernel, default), "shell_min_words" / "shell_budget_den" (KD6: open words
+ * below which a tile group is left to the fix-up kernel, default 128 of 512; the pass is for scenes with at most 1 / den of their
+ * voxels undecided behind KD3, default 8).
  * Every option leaves the results exact: switches that
  * skip work for profiling ("dc_debug", "ball_variant") exist only in libraries built with -DSDFGPU_DEBUG_HOOKS and are
  * rejected with SDFGPU_ERR_INVALID_ARGUMENT by the shipped one. */
