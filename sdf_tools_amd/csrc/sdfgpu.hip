@@ -844,11 +844,11 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->flags_pending = false;
         //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict, status word 20, as word 8)
         h->pol.consume_report(h->h_flags[3] != 0, h->h_flags[6] != 0, h->h_flags[8] != 0);
-        h->far_streak = (h->h_flags[4] != 0 && h->h_flags[5] != 0) ? h->far_streak + 1 : 0;
+        h->far_streak = (h->h_flags[4] != 0 && h->h_flags[5] != 0) ? std::min(h->far_streak + 1, 1 << 20) : 0;
     }
     if (h->far_pending && hipEventQuery(h->far_ev) == hipSuccess) {
         h->far_pending = false;
-        h->far_streak = (h->h_far[4] != 0 && h->h_far[5] != 0) ? h->far_streak + 1 : 0;
+        h->far_streak = (h->h_far[4] != 0 && h->h_far[5] != 0) ? std::min(h->far_streak + 1, 1 << 20) : 0;
     }
     ++h->build_seq;
     const DensePlan plan = h->pol.plan(dense, dense_generic, nz / 32 <= 256 && h->ball_block <= 256, vb != 0);
