@@ -101,6 +101,7 @@ struct sdfgpu_context {
     bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool shell_on = true;            // KD6, the bit-parallel shell pass between KD3 and KF (option "dense_shell")
+    bool dense3_fixed = true;        // KD3's nz = 512 instance (option "dense3_fixed")
     int shell_min_words = kShellMinWords;   // option "shell_min_words"
     int shell_budget_den = 8;        // ... for scenes with at most 1 / 8 of their voxels undecided behind KD3 (option "shell_budget_den"): Bernoulli
                                      // p = 0.01 leaves 8 % (0.78 ms against the far-field pair's 0.96), p = 0.007 17 % (1.07 ms against 0.97)
@@ -734,7 +735,9 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
     a.checked = h->ball_variant & 1;
     if (radius == 3) {
         if (bd != 256 || vb) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "KD3: 256-lane tiles without virtual border only (internal)");
-        if (zinv) hipLaunchKernelGGL((k_ball_dense3<256, true>), grid, dim3(256), lds, s, a);
+        // nz = 512 (16 words per row, 4 x 4-row tiles): the instance with compile-time row pitch and halo width (option "dense3_fixed")
+        if (zinv && a.nzw == 16 && a.ty == 4 && a.tx == 4 && h->dense3_fixed) hipLaunchKernelGGL((k_ball_dense3<256, true, 16, 4>), grid, dim3(256), lds, s, a);
+        else if (zinv) hipLaunchKernelGGL((k_ball_dense3<256, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((k_ball_dense3<256, false>), grid, dim3(256), lds, s, a);
     }
     else if (bd == 1024) hipLaunchKernelGGL((k_ball_dense<1024, true>), grid, dim3(1024), lds, s, a);
@@ -2157,6 +2160,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense3") { h->pol.dense3_on = value != 0; h->pol.dense3_mode = false; }
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
     else if (n == "dense_shell") h->shell_on = value != 0;
+    else if (n == "dense3_fixed") h->dense3_fixed = value != 0;
     else if (n == "shell_min_words") h->shell_min_words = value >= 0 ? value : kShellMinWords;
     else if (n == "shell_budget_den") h->shell_budget_den = value >= 1 ? value : 8;
     else if (n == "dense3_staged") h->pol.dense3_staged = value != 0;

@@ -55,17 +55,25 @@ __device__ __forceinline__ uint32_t ball3_level_pass(const uint32_t* c0, int hy,
 }
 
 // ZINV = nz <= BD * 4 (every expansion pass covers whole z-rows)
-template <int BD, bool ZINV>
+// NZW, TY: 0 = words per row and tile rows along y from the arguments; otherwise compile-time (the launcher picks the instance
+// that matches: nz = 512 with 4 x 4-row tiles).  The level passes visit ~150 (dx, dy) rows of the staged tile; with the row pitch
+// and the halo's width known, their LDS addresses are immediates of the ds_read instead of a scalar multiply and a vector add
+// per row -- a sixth of the kernel's VALU instructions, and this kernel is VALU-bound wherever it is the dense stage (round 5).
+template <int BD, bool ZINV, int NZW = 0, int TY = 0>
 __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
+    static_assert((NZW == 0) == (TY == 0) && (NZW & (NZW - 1)) == 0 && (TY & (TY - 1)) == 0, "both or neither; powers of two");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (a.guard && __hip_atomic_load(a.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // KD decided the scene
     // (block-uniform; an atomic load: a plain one may be served from a scalar / L1 cache line read before the flag went up)
     if (a.early_out && __hip_atomic_load(a.uncertified, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    const int nzw = a.nzw, lg = a.log2_nzw;
+    const int nzw = NZW ? NZW : a.nzw, lg = NZW ? __builtin_ctz(NZW ? NZW : 1) : a.log2_nzw;
+    const int a_ty = TY ? TY : a.ty, a_log2_ty = TY ? __builtin_ctz(TY ? TY : 1) : a.log2_ty;
+    const int a_tx = TY ? BD / (NZW ? NZW : 1) / TY : a.tx;
+    const int a_inv_hy = TY ? (65536 + (TY + 2 * kBall3R) - 1) / (TY + 2 * kBall3R) : a.inv_hy;
     const int rwu = nzw + 2;                                  // words used per staged row (edge words replicated)
     // row pitch: a wave reads 64/nzw tile rows at once; pitch = nzw (mod 32) puts them on disjoint banks
     const int rw = nzw < 32 ? nzw + 32 : nzw + 2;
-    const int hx = a.tx + 2 * kBall3R, hy = a.ty + 2 * kBall3R;
+    const int hx = a_tx + 2 * kBall3R, hy = a_ty + 2 * kBall3R;
     // LDS: [signed pair table 8 KiB][magnitudes][level planes BD x 16 B][class words BD x 4 B][tile]
     float2* lut2 = reinterpret_cast<float2*>(smem_raw);                   // [1024] signed pair table
     float* magl = reinterpret_cast<float*>(smem_raw + 1024 * 8);          // [16] level magnitudes (64 B slot)
@@ -87,8 +95,8 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
         magl[t] = m;
     }
 
-    const int x0 = a.out_lo + (int)blockIdx.y * a.tx;         // first tile plane (buffer coordinates)
-    const int y0 = (int)blockIdx.x * a.ty;
+    const int x0 = a.out_lo + (int)blockIdx.y * a_tx;         // first tile plane (buffer coordinates)
+    const int y0 = (int)blockIdx.x * a_ty;
     // stage the bit-rows of the tile + halo; rows outside the buffer / grid replicate the nearest row
     if (nzw >= 4) {
         // one 16-byte load per lane and staged quarter-row: (hx*hy rows) x (nzw/4 quads); all loads of a
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
             for (int u = 0; u < 2; ++u) {
                 const int i = min(i0 + u * BD + t, total - 1);
                 rowi[u] = i >> lq; quad[u] = i & ((1 << lq) - 1);
-                const int jx = (rowi[u] * a.inv_hy) >> 16, jy = rowi[u] - jx * hy;
+                const int jx = (rowi[u] * a_inv_hy) >> 16, jy = rowi[u] - jx * hy;
                 const int gx = min(max(x0 + jx - kBall3R, 0), a.rows_x - 1);
                 const int gy = min(max(y0 + jy - kBall3R, 0), a.ny - 1);
                 v[u] = *reinterpret_cast<const uint4*>(a.bits + ((int64_t)gx * a.ny + gy) * nzw + 4 * quad[u]);
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
         }
     }
     const int r = t >> lg, w = t & (nzw - 1);                 // tile row, word in row
-    const int ty_ = r & (a.ty - 1), tx_ = r >> a.log2_ty;
+    const int ty_ = r & (a_ty - 1), tx_ = r >> a_log2_ty;
     const uint32_t* c0 = tile + ((tx_ + kBall3R) * hy + (ty_ + kBall3R)) * rw + (w + 1);
     const uint32_t O = c0[0];
     // Levels in increasing d^2, cumulative; stop as soon as every voxel of the wave has been decided.
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
         const uint32_t* cbase = cls + (r0 << lg) + (zi >> 5);
         // ZINV: row r0 + j*rs splits into (tx, ty) without carries between the lane part r0 (< rs) and the
         // wave-uniform part j*rs, so the byte offset is a per-lane constant plus a scalar per pass
-        const int ty0 = r0 & (a.ty - 1), tx0 = r0 >> a.log2_ty;
+        const int ty0 = r0 & (a_ty - 1), tx0 = r0 >> a_log2_ty;
         const uint32_t lane_off = (uint32_t)(((((int)__umul24(tx0, a.ny) + ty0) << lgz) + zi) << 2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {                         // fully unrolled: 8 independent LDS->LUT->store chains
@@ -263,14 +271,14 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
                                 (__builtin_amdgcn_ubfe(pl.y, sh + 2u, 2u) << 4) | (__builtin_amdgcn_ubfe(pl.z, sh + 2u, 2u) << 6) |
                                 (__builtin_amdgcn_ubfe(pl.w, sh + 2u, 2u) << 8);
             const float2 fa = lut2[ia], fb = lut2[ib];
-            const int tyy = rr & (a.ty - 1), txx = rr >> a.log2_ty;
+            const int tyy = rr & (a_ty - 1), txx = rr >> a_log2_ty;
             if (FULL || (x0 + txx < a.out_hi && y0 + tyy < a.ny)) {
                 f4v ov;
                 ov.x = fa.x; ov.y = fa.y; ov.z = fb.x; ov.w = fb.y;
                 f4v* dst;
                 if constexpr (ZINV) {
                     const int rj = j * rs;                                                    // wave-uniform
-                    const int64_t uoff = (((int64_t)(rj >> a.log2_ty) * a.ny + (rj & (a.ty - 1))) << lgz) << 2;
+                    const int64_t uoff = (((int64_t)(rj >> a_log2_ty) * a.ny + (rj & (a_ty - 1))) << lgz) << 2;
                     dst = reinterpret_cast<f4v*>(tile_out + uoff + lane_off);
                 } else {
                     dst = reinterpret_cast<f4v*>(tile_out + (uint32_t)((((int)__umul24(txx, a.ny) + tyy) << lgz) + z) * 4u);
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(BD) void k_ball_dense3(const DenseArgs a) {
             }
         }
     };
-    if (!(a.checked & 1) && (x0 + a.tx <= a.out_hi) && (y0 + a.ty <= a.ny)) expand(std::true_type{});
+    if (!(a.checked & 1) && (x0 + a_tx <= a.out_hi) && (y0 + a_ty <= a.ny)) expand(std::true_type{});
     else expand(std::false_type{});
 
 #pragma unroll

@@ -78,6 +78,7 @@ while time.time() - t0 < budget:
         ctx.set_option("fixup_mode", 1)                 # force the fix-up kernel behind the dense ball kernel
     if rng.random() < 0.35:
         ctx.set_option("dense3_mode", 1)                # ... the wide ball kernel (KD3) in KD's place
+    ctx.set_option("dense3_fixed", int(rng.random() < 0.7))   # round 5: KD3's nz = 512 instance (compile-time row pitch) or the generic one
     ctx.set_option("dense_shell", int(rng.random() < 0.8))     # round 5: the shell pass (KD6) between KD3 and KF, or KF alone
     # tier selection: fresh decisions, forced far-field sweeps, both hand-off forms, low thresholds (far-field kernel on
     # scenes the marching kernels would normally take)
