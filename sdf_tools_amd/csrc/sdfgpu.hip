@@ -101,6 +101,7 @@ struct sdfgpu_context {
     bool envelope_dc = true;         // use the divide-and-conquer envelope kernel (sdfgpu_envelope_dc.hpp) when the shape allows
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool shell_on = true;            // KD6, the bit-parallel shell pass between KD3 and KF (option "dense_shell")
+    bool dc_fixed = true;            // far-field kernel: the 512-voxel-line instances (option "dc_fixed")
     bool dense3_fixed = true;        // KD3's nz = 512 instance (option "dense3_fixed")
     int shell_min_words = kShellMinWords;   // option "shell_min_words"
     int shell_budget_den = 8;        // ... for scenes with at most 1 / 8 of their voxels undecided behind KD3 (option "shell_budget_den"): Bernoulli
@@ -122,7 +123,7 @@ struct sdfgpu_context {
                                      // turns into), not fused K12 + K3/16 with unbounded scans (option "standby_far")
     bool standby_fold = true;        // the stand-by x sweep's launch folds the maxima and publishes the status block itself (option "standby_fold")
     int standby_grid = 1024;         // workgroups of the stand-by launches (LOOP form; option "standby_grid"): 4 per CU = all resident at once
-    bool dc_attr_set[12] = {false, false, false, false, false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
+    bool dc_attr_set[14] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
@@ -583,7 +584,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         // LOOP form: at most 2048 workgroups (a guarded exit costs 1.7 us up to there and grows with the grid), a multiple of 8
         // so that a workgroup's tiles stay on its XCD
         const int64_t nwg = loop ? std::min<int64_t>(ntiles, h->standby_grid) : ntiles;
-        const int which = (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0) + (big ? 8 : 0);
+        // 512-voxel lines, vector loads, one tile per workgroup: the instances with the line's geometry as compile-time constants (option "dc_fixed")
+        const bool fixed512 = h->dc_fixed && a.L == 512 && vec && !loop && !big && a.B == 9 && a.pitch == 514 && a.M == 64 && a.h == 256;
+        const int which = fixed512 ? 12 + (stage == 3 ? 1 : 0) : (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0) + (big ? 8 : 0);
         auto launch = [&](auto kern) -> int {
             // (the attribute is per kernel: raised once per instantiation, not on every launch -- ADVICE r3)
             if (lds > 64 * 1024 && !h->dc_attr_set[which]) {
@@ -606,7 +609,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             case 8: rc = launch(k_envelope_dc<2, false, 512, 16, false, 4>); break;
             case 9: rc = launch(k_envelope_dc<3, false, 512, 16, false, 4>); break;
             case 10: rc = launch(k_envelope_dc<2, true, 512, 16, false, 4>); break;
-            default: rc = launch(k_envelope_dc<3, true, 512, 16, false, 4>); break;
+            case 11: rc = launch(k_envelope_dc<3, true, 512, 16, false, 4>); break;
+            case 12: rc = launch(k_envelope_dc<2, true, 256, 16, false, 4, 512>); break;
+            default: rc = launch(k_envelope_dc<3, true, 256, 16, false, 4, 512>); break;
         }
         if (rc) return rc;
         HIP_TRY(h, hipGetLastError());
@@ -2160,6 +2165,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense3") { h->pol.dense3_on = value != 0; h->pol.dense3_mode = false; }
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
     else if (n == "dense_shell") h->shell_on = value != 0;
+    else if (n == "dc_fixed") h->dc_fixed = value != 0;
     else if (n == "dense3_fixed") h->dense3_fixed = value != 0;
     else if (n == "shell_min_words") h->shell_min_words = value >= 0 ? value : kShellMinWords;
     else if (n == "shell_budget_den") h->shell_budget_den = value >= 1 ? value : 8;

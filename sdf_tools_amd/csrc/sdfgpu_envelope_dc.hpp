@@ -402,7 +402,10 @@ __global__ __launch_bounds__(256) void k_probe_window(const ProbeArgs a) {
 // which a scene leaves the dense tier).
 // WPS = waves per SIMD the register budget is set for: 4 workgroups of 256 lanes per CU for lines up to 512 (LDS: 37 KB each), 2 workgroups
 // of 512 lanes for longer lines (76 KB each at 1024) -- round 4: lines above 512 used to run 2 x 256 lanes per CU, 2 waves per SIMD.
-template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines, bool LOOP = false, int WPS = (NL == 8 ? 8 : 4) * (NT / 64) / 4>
+// LC: 0 = the line's geometry (length, key bits, LDS pitch, chunk count, centre) from the arguments; otherwise the compile-time line length
+// (the launcher picks the instance that matches: 512-voxel lines): loop bounds, the level structure and the LDS addressing are then constants.
+__host__ __device__ constexpr int dc_clog2(int L) { int b = 1; while ((1 << b) < L) ++b; return b; }
+template <int STAGE, bool VEC, int NT = 256, int NL = kDcLines, bool LOOP = false, int WPS = (NL == 8 ? 8 : 4) * (NT / 64) / 4, int LC = 0>
 __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     constexpr int S = NT / NL;              // lanes per line
     constexpr int LPR = NL / 4;             // staging: lanes per row (4 lines each)
@@ -427,7 +430,8 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
     if (a.probe_stride > 0 && STAGE == 3 && a.decide_small &&
         __hip_atomic_load(a.decide_small + 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { probe_done(a); return; }   // ... settled by the y probe
-    const int L = a.L, B = a.B, pitch = a.pitch, M = a.M, h = a.h;
+    const int L = LC ? LC : a.L, B = LC ? dc_clog2(LC ? LC : 2) : a.B, pitch = LC ? ((LC + 63) / 64) * 64 + 2 : a.pitch, M = LC ? (LC + 7) / 8 : a.M,
+              h = LC ? (LC + 1) / 2 : a.h;
     const int MA = (L + 63) >> 6;
     const uint32_t mask = (1u << B) - 1u, finf = a.finf;
     // position multipliers -(2 p') << B (|.| < 2^23: 24-bit multiplies), as shifts of h - p
@@ -1115,7 +1119,8 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
 #define SDFGPU_ENVELOPE_INSTANCES(X) \
     X(2, false, 256, 16) X(3, false, 256, 16) X(2, true, 256, 16) X(3, true, 256, 16) \
     X(2, false, 256, 16, true) X(3, false, 256, 16, true) X(2, true, 256, 16, true) X(3, true, 256, 16, true) \
-    X(2, false, 512, 16, false, 4) X(3, false, 512, 16, false, 4) X(2, true, 512, 16, false, 4) X(3, true, 512, 16, false, 4)
+    X(2, false, 512, 16, false, 4) X(3, false, 512, 16, false, 4) X(2, true, 512, 16, false, 4) X(3, true, 512, 16, false, 4) \
+    X(2, true, 256, 16, false, 4, 512) X(3, true, 256, 16, false, 4, 512)
 #ifndef SDFGPU_ENVELOPE_TU
 #define SDFGPU_ENVELOPE_DECLARE(...) extern template __global__ void k_envelope_dc<__VA_ARGS__>(const EnvDcArgs);
 SDFGPU_ENVELOPE_INSTANCES(SDFGPU_ENVELOPE_DECLARE)

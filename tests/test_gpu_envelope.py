@@ -42,6 +42,9 @@ CASES = [
     ("room 160x128x96 vb", synth.room_mask_torch((160, 128, 96), "cpu").numpy(), True),
     ("tutorial boxes 128^3, solid", synth.tutorial_boxes_mask_torch((128, 128, 128), "cpu", True).numpy(), False),
     ("tutorial boxes 128^3, shells", synth.tutorial_boxes_mask_torch((128, 128, 128), "cpu", False).numpy(), False),
+    # 512-voxel lines in both swept axes: the far-field kernel's instances with the line geometry as compile-time constants (round 5)
+    ("two boxes 512x512x16", _two_boxes((512, 512, 16)), False),
+    ("room 512x512x32 vb", synth.room_mask_torch((512, 512, 32), "cpu").numpy(), True),
 ]
 
 

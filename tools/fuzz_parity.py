@@ -92,6 +92,7 @@ while time.time() - t0 < budget:
     ctx.set_option("z_wave", int(rng.random() < 0.8))
     # round 4: the handle "trusts its dense tier" (the general pipeline behind it is then the stand-by pair: far-field y sweep
     # staged from the bit field + far-field x sweep, LOOP form) with small and large stand-by grids, or the old stand-by
+    ctx.set_option("dc_fixed", int(rng.random() < 0.7))         # round 5: far-field instances with a compile-time line length (512)
     ctx.set_option("far_predict", int(rng.choice([0, 1, 2, 2])))   # round 5: the far-field pair without probes (learnt / forced)
     ctx.set_option("standby_far", int(rng.random() < 0.85))
     ctx.set_option("standby_grid", int(rng.choice([32, 64, 1024])))
