@@ -123,7 +123,7 @@ struct sdfgpu_context {
                                      // turns into), not fused K12 + K3/16 with unbounded scans (option "standby_far")
     bool standby_fold = true;        // the stand-by x sweep's launch folds the maxima and publishes the status block itself (option "standby_fold")
     int standby_grid = 1024;         // workgroups of the stand-by launches (LOOP form; option "standby_grid"): 4 per CU = all resident at once
-    bool dc_attr_set[14] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
+    bool dc_attr_set[16] = {};   // MaxDynamicSharedMemorySize raised, per far-field kernel instantiation
     int k1_resident = 0;             // workgroups of k_sweep_z_vec16 the device holds at once (persistent grid size)
     unsigned long long* d_clocks = nullptr;   // SDFGPU_PHASE_CLOCKS builds: phase clocks of the far-field kernels
     int dc_debug = 0;                // profiling aid: skips phases of k_envelope_dc (results are then wrong)
@@ -586,7 +586,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         const int64_t nwg = loop ? std::min<int64_t>(ntiles, h->standby_grid) : ntiles;
         // 512-voxel lines, vector loads, one tile per workgroup: the instances with the line's geometry as compile-time constants (option "dc_fixed")
         const bool fixed512 = h->dc_fixed && a.L == 512 && vec && !loop && !big && a.B == 9 && a.pitch == 514 && a.M == 64 && a.h == 256;
-        const int which = fixed512 ? 12 + (stage == 3 ? 1 : 0) : (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0) + (big ? 8 : 0);
+        const bool fixed1024 = h->dc_fixed && a.L == 1024 && vec && big && a.B == 10 && a.pitch == 1026 && a.M == 128 && a.h == 512;
+        const int which = fixed512 ? 12 + (stage == 3 ? 1 : 0) : fixed1024 ? 14 + (stage == 3 ? 1 : 0) :
+                          (stage == 3 ? 1 : 0) + (vec ? 2 : 0) + (loop ? 4 : 0) + (big ? 8 : 0);
         auto launch = [&](auto kern) -> int {
             // (the attribute is per kernel: raised once per instantiation, not on every launch -- ADVICE r3)
             if (lds > 64 * 1024 && !h->dc_attr_set[which]) {
@@ -611,7 +613,9 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             case 10: rc = launch(k_envelope_dc<2, true, 512, 16, false, 4>); break;
             case 11: rc = launch(k_envelope_dc<3, true, 512, 16, false, 4>); break;
             case 12: rc = launch(k_envelope_dc<2, true, 256, 16, false, 4, 512>); break;
-            default: rc = launch(k_envelope_dc<3, true, 256, 16, false, 4, 512>); break;
+            case 13: rc = launch(k_envelope_dc<3, true, 256, 16, false, 4, 512>); break;
+            case 14: rc = launch(k_envelope_dc<2, true, 512, 16, false, 4, 1024>); break;
+            default: rc = launch(k_envelope_dc<3, true, 512, 16, false, 4, 1024>); break;
         }
         if (rc) return rc;
         HIP_TRY(h, hipGetLastError());

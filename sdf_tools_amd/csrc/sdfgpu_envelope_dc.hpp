@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     X(2, false, 256, 16) X(3, false, 256, 16) X(2, true, 256, 16) X(3, true, 256, 16) \
     X(2, false, 256, 16, true) X(3, false, 256, 16, true) X(2, true, 256, 16, true) X(3, true, 256, 16, true) \
     X(2, false, 512, 16, false, 4) X(3, false, 512, 16, false, 4) X(2, true, 512, 16, false, 4) X(3, true, 512, 16, false, 4) \
-    X(2, true, 256, 16, false, 4, 512) X(3, true, 256, 16, false, 4, 512)
+    X(2, true, 256, 16, false, 4, 512) X(3, true, 256, 16, false, 4, 512) X(2, true, 512, 16, false, 4, 1024) X(3, true, 512, 16, false, 4, 1024)
 #ifndef SDFGPU_ENVELOPE_TU
 #define SDFGPU_ENVELOPE_DECLARE(...) extern template __global__ void k_envelope_dc<__VA_ARGS__>(const EnvDcArgs);
 SDFGPU_ENVELOPE_INSTANCES(SDFGPU_ENVELOPE_DECLARE)
