@@ -504,6 +504,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             if (stage == 2) { a.bits = ex->bits; a.nzw = ex->nzw; }
             if (stage == 3 && ex->loop && ex->fold_ticket && !probe_out) {
                 a.fold_status = h->d_small; a.fold_result = ex->fold_result; a.fold_report = ex->fold_report; a.fold_ticket = ex->fold_ticket;
+                a.fold_report_mask = kReportDense;
             }
         }
         const bool loop = ex && ex->loop && !probe_out;
@@ -666,8 +667,9 @@ int launch_pack_bits(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells
 }
 
 // Folds the per-slot maxima of the final-stage kernels launched so far into d_maxdsq[0..1] and clears the slots.
-int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s, uint32_t* result = nullptr, uint32_t* report = nullptr) {
-    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_maxdsq, result, report);
+int fold_slots(sdfgpu_handle h, uint32_t* d_maxdsq, hipStream_t s, uint32_t* result = nullptr, uint32_t* report = nullptr,
+               uint32_t report_mask = kReportDense) {
+    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(kSlots), 0, s, h->d_slots, d_maxdsq, result, report, report_mask);
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
@@ -1119,8 +1121,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     //  usually taken by a paused build when the probe came, its failure went unseen and the pause never grew; tests/policy_harness)
     // (a stand-by build: the x sweep's launch has done it -- one launch less behind the dense kernel)
     // (a build without the dense tier reports to the second slot: its far flags teach far_predict)
-    const bool report_far = !report && select && h->h_far_dev && !h->far_pending;
-    if (!folded) if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : report_far ? h->h_far_dev : nullptr)) return rc;
+    // (... the builds that probed: a predicted build's flags say nothing new, and a report is PCIe writes the fold waits for)
+    const bool report_far = !report && select && !predicted && h->h_far_dev && !h->far_pending;
+    if (!folded) if (int rc = fold_slots(h, h->d_small, s, h->d_result, report ? h->h_flags_dev : report_far ? h->h_far_dev : nullptr,
+                                         report ? kReportDense : kReportFar)) return rc;
     if (report_far) {
         HIP_TRY(h, hipEventRecord(h->far_ev, s));
         h->far_pending = true;

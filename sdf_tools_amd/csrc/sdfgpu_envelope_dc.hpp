@@ -119,6 +119,7 @@ struct EnvDcArgs {
     uint32_t* fold_result;
     uint32_t* fold_report;
     uint32_t* fold_ticket;
+    uint32_t fold_report_mask;
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         if ((gv != 0u) == (a.guard_invert != 0)) {
             if constexpr (LOOP && STAGE == 3) {
                 if (a.fold_status && blockIdx.x == 0)           // (block-uniform; nothing of this launch writes the slots or the status block)
-                    fold_slots_device<NT>(a.maxdsq, a.fold_status, a.fold_result, a.fold_report, (int)threadIdx.x);
+                    fold_slots_device<NT>(a.maxdsq, a.fold_status, a.fold_result, a.fold_report, a.fold_report_mask, (int)threadIdx.x);
             }
             probe_done(a);
             return;
@@ -1106,7 +1107,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 __syncthreads();
                 if (fold_last) {                                // (block-uniform) every other workgroup has finished
                     __threadfence();
-                    fold_slots_device<NT>(a.maxdsq, a.fold_status, a.fold_result, a.fold_report, t);     // (clears the ticket with the status block)
+                    fold_slots_device<NT>(a.maxdsq, a.fold_status, a.fold_result, a.fold_report, a.fold_report_mask, t);     // (clears the ticket with the status block)
                 }
             }
         }

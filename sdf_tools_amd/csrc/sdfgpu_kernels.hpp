@@ -76,6 +76,8 @@ __device__ __forceinline__ void raise_flag(uint32_t* p) {
 constexpr int kSlots = 512;
 constexpr int kStatusWords = 24;      // words of the status block that the end-of-build fold publishes and clears
 constexpr int kSlotWords = 32;
+constexpr uint32_t kReportDense = 0x1000FFu;      // status words a dense-tier report publishes to the host
+constexpr uint32_t kReportFar = 0x30u;            // ... a far-flag report (words 4, 5)
 __device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mxF, int mxQ) {
     uint32_t* p = slots + (size_t)(wave & (kSlots - 1)) * kSlotWords;
     if (mxF) atomic_max_if_larger(p + 0, (uint32_t)mxF);
@@ -90,7 +92,8 @@ __device__ __forceinline__ void slot_max2(uint32_t* slots, uint32_t wave, int mx
 //  k_envelope_dc's LOOP form; loads through the L2, because in that kernel other workgroups of the SAME launch may have written)
 template <int NT>
 __device__ __forceinline__ void fold_slots_device(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
-                                                  uint32_t* __restrict__ result, uint32_t* __restrict__ report, const int t) {
+                                                  uint32_t* __restrict__ result, uint32_t* __restrict__ report, const uint32_t report_mask,
+                                                  const int t) {
     static_assert(NT % 64 == 0 && NT >= 64 && kSlots % NT == 0, "whole waves, whole rounds over the slots");
     __shared__ uint32_t part[2 * (NT / 64)];
     uint32_t f = 0, q = 0;
@@ -122,17 +125,18 @@ __device__ __forceinline__ void fold_slots_device(uint32_t* __restrict__ slots, 
             if (t == 0) st = max(st, f);
             if (t == 1) st = max(st, q);
             result[t] = st;
-            // (host copy: words 0..7, and KD's own verdict -- word 20 -- as word 8.  Every word is a separate write across
-            //  PCIe that the kernel's end waits for: publishing all 24 made every build 0.04 ms longer)
-            if (report && (t < 8 || t == 20))
+            // (host copy: the words of report_mask -- kReportDense: words 0..7, and KD's own verdict, word 20, as word 8; kReportFar: the
+            //  two far flags.  Every word is a separate write across PCIe that the kernel's end waits for: publishing all 24 made
+            //  every build 0.04 ms longer)
+            if (report && ((report_mask >> t) & 1u))
                 __hip_atomic_store(report + (t == 20 ? 8 : t), st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             maxdsq[t] = 0;
         }
     }
 }
 SDFGPU_KERNEL __launch_bounds__(kSlots) void k_fold_slots(uint32_t* __restrict__ slots, uint32_t* __restrict__ maxdsq,
-                                                       uint32_t* __restrict__ result, uint32_t* __restrict__ report) {
-    fold_slots_device<kSlots>(slots, maxdsq, result, report, (int)threadIdx.x);
+                                                       uint32_t* __restrict__ result, uint32_t* __restrict__ report, uint32_t report_mask) {
+    fold_slots_device<kSlots>(slots, maxdsq, result, report, report_mask, (int)threadIdx.x);
 }
 
 constexpr int kInf16 = 32767;        // "no opposite voxel in this z row"
