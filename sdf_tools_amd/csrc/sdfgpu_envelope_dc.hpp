@@ -995,7 +995,12 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         for (int k = 0; k < 8; ++k) {
                             int b = byz;
                             if (a.nx > 1) b = imin(b, (int)min((int64_t)(p0 + k) + 1, a.nx - (p0 + k)));
-                            if (b < 32768) D[k] = imin(D[k], (int)__umul24((uint32_t)b, (uint32_t)b));      // (b >= 1: a voxel of the other class stays 0)
+                            // (b >= 1 inside the line: a voxel of the other class stays 0.  Positions past the end of the line -- the last
+                            //  chunk of a line whose length is not a multiple of 8 -- have b <= 0, and from the second one on b^2 as a 24-bit
+                            //  product is NEGATIVE: without the test on p0 + k such a position stopped being "not mine" (D = 0) and its
+                            //  value was stored one or more x planes past the end of the field.  Round 5's fuzz, shape 9 x 777 x 64 with a
+                            //  virtual border: the first time the field behind was the allocation's last page.)
+                            if (b < 32768 && p0 + k < L) D[k] = imin(D[k], (int)__umul24((uint32_t)b, (uint32_t)b));
                         }
                     }
                     char* const op = reinterpret_cast<char*>(reinterpret_cast<float*>(a.out) + base);     // (uniform base + 32-bit byte offset)

@@ -324,3 +324,42 @@ def test_far_field_prediction_skips_the_probes_and_stays_exact(gpu):
     finally:
         gpu.set_option("far_predict", 1)
         gpu.set_option("dense", 1)
+
+
+@pytest.mark.parametrize("nx", [9, 13, 21, 3])
+def test_virtual_border_x_sweep_writes_nothing_past_the_field(gpu, nx):
+    """Round 5 regression (found by the fuzz at 9 x 777 x 64): the far-field x sweep's finish applied the virtual border to the
+    positions of a line's last chunk that lie PAST the line's end; from the second such position on the border distance is
+    negative, its square as a 24-bit product too, the position stopped being "not mine" and its value was stored x planes
+    beyond the end of the field.  Device-resident output with a guard band of 8 x planes behind it: the field equals the exact
+    oracle and the band is untouched -- far-field pair forced (probe or not), both hand-off forms."""
+    import torch
+    shape = (nx, 40, 32)
+    m = np.zeros(shape, np.uint8)
+    m[nx // 2, 3:6, 4:9] = 1
+    m[0, 30, 20] = 1
+    res = 0.05
+    want, want_ext, _ = O.exact_sdf(m, res, True)
+    n, plane = int(np.prod(shape)), shape[1] * shape[2]
+    dm = torch.from_numpy(m).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for opts in ({"envelope_mode": 1}, {"far_predict": 2}, {"far_predict": 2, "plane16": 0}, {"envelope_mode": 1, "i32_handoff": 0}):
+            gpu.set_option("policy_reset", 1)
+            gpu.set_option("dense", 0)
+            for k, v in opts.items():
+                gpu.set_option(k, v)
+            out = torch.full((n + 8 * plane,), -12345.0, dtype=torch.float32, device="cuda")
+            gpu.build_device(dm.data_ptr(), shape, out.data_ptr(), res, True, stream)
+            torch.cuda.synchronize()
+            path = gpu.last_path()
+            assert path["far_x"], (opts, path)
+            got = out[:n].cpu().numpy().reshape(shape)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), opts
+            assert bool((out[n:] == -12345.0).all().item()), (opts, int((out[n:] != -12345.0).sum().item()))
+            assert gpu.get_extrema() == want_ext, opts
+            for k in opts:
+                gpu.set_option(k, {"envelope_mode": 0, "far_predict": 1, "plane16": 1, "i32_handoff": 1}[k])
+    finally:
+        for k, v in (("envelope_mode", 0), ("far_predict", 1), ("plane16", 1), ("i32_handoff", 1), ("dense", 1)):
+            gpu.set_option(k, v)

@@ -18,6 +18,15 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
 ctx = capi.SdfGpu(0)
+VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))           # print every scene's shape and options before its build (to find a crash)
+if VERBOSE:
+    _set = ctx.set_option
+    _opts = {}
+
+    def _recording_set(name, value):
+        _opts[name] = value
+        return _set(name, value)
+    ctx.set_option = _recording_set
 sizes = [1, 2, 3, 5, 8, 13, 16, 21, 32, 33, 40, 64, 96, 128]
 t0 = time.time()
 n = 0
@@ -98,6 +107,10 @@ while time.time() - t0 < budget:
     ctx.set_option("standby_grid", int(rng.choice([32, 64, 1024])))
     if rng.random() < 0.4:
         ctx.set_option("expect_dense", 1)
+    if VERBOSE:
+        print("scene", n, shape, "kind", int(kind), "res", res, "vb", vb, "filled", int(m.sum()), _opts, flush=True)
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.save("gpurun_out/fuzz_last_mask.npy", m)       # (the scene a crash happened in)
     got, ext = ctx.build(m, res, vb)
     want, want_ext, _ = O.exact_sdf(m, res, vb)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
