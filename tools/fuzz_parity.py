@@ -111,7 +111,26 @@ while time.time() - t0 < budget:
         print("scene", n, shape, "kind", int(kind), "res", res, "vb", vb, "filled", int(m.sum()), _opts, flush=True)
         os.makedirs("gpurun_out", exist_ok=True)
         np.save("gpurun_out/fuzz_last_mask.npy", m)       # (the scene a crash happened in)
-    got, ext = ctx.build(m, res, vb)
+    if rng.random() < 0.5:
+        # device-resident build into a field with a guard band in front of it and behind it (round 5: a store past the end of the
+        # field is silent on the host path, whose staging buffer is as large as the largest scene so far)
+        import torch
+        nvox = int(m.size)
+        g = ((max(4096, 8 * shape[1] * shape[2]) + 3) // 4) * 4
+        buf = torch.full((g + nvox + g,), -12345.0, dtype=torch.float32, device="cuda")
+        dm = torch.from_numpy(m).cuda()
+        ctx.build_device(dm.data_ptr(), shape, buf.data_ptr() + 4 * g, res, vb, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ext = ctx.get_extrema()
+        got = buf[g:g + nvox].cpu().numpy().reshape(shape)
+        if not bool((buf[:g] == -12345.0).all().item()) or not bool((buf[g + nvox:] == -12345.0).all().item()):
+            print("GUARD BAND WRITTEN shape", shape, "kind", kind, "res", res, "vb", vb,
+                  "before", int((buf[:g] != -12345.0).sum().item()), "behind", int((buf[g + nvox:] != -12345.0).sum().item()))
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.save("gpurun_out/fuzz_fail_mask.npy", m)
+            sys.exit(1)
+    else:
+        got, ext = ctx.build(m, res, vb)
     want, want_ext, _ = O.exact_sdf(m, res, vb)
     if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) or tuple(ext) != tuple(float(v) for v in want_ext):
         bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
