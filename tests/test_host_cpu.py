@@ -119,6 +119,16 @@ def test_far_field_schedule_model_is_exact():
         assert got == model.brute(F), (trial, L, kind)
         model.check_line(rng, F)                                    # again with a looser span / bound, a forced level-A form, and
                                                                     # (round 4) long ranges split over the wave's rows at scaled-down thresholds
+    # the finish under a virtual border: positions of the last chunk past the line's end must stay "not mine" (D = 0) -- the unguarded
+    # form (rounds 3 - 4) turns them negative from the second one on, for every line length that leaves two or more of them
+    for nx in range(1, 41):
+        p0 = 8 * ((nx - 1) // 8)
+        D = [25 if p0 + k < nx else 0 for k in range(8)]
+        fixed = model.vb_chunk_finish(D, p0, nx, nx, 1000, guarded=True)
+        assert all(fixed[k] == 0 for k in range(8) if p0 + k >= nx), nx
+        assert all(fixed[k] == (25 if nx == 1 else min(25, min(p0 + k + 1, nx - (p0 + k)) ** 2)) for k in range(8) if p0 + k < nx), nx    # (a single plane has no x border)
+        old = model.vb_chunk_finish(D, p0, nx, nx, 1000, guarded=False)
+        assert any(v < 0 for v in old) == (nx > 1 and nx % 8 in (1, 2, 3, 4, 5, 6)), (nx, old)
     # the wave-cooperative scans of levels B and C at the kernel's own thresholds: sites at both ends of the line only, so that
     # the argmin jumps across the whole line -- the hand-over (at a random block) must see the plain scan's candidate set
     for L in (300, 512):

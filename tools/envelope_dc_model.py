@@ -199,6 +199,29 @@ def dc_line(F, FINF, lo_t=None, hi_t=None, mt_t=None, force_clip=None, coop_rng=
     return D, evals[0]
 
 
+def i32(x):
+    x &= 0xFFFFFFFF
+    return x - (1 << 32) if x & 0x80000000 else x
+
+
+def vb_chunk_finish(D, p0, L, nx, byz, guarded=True):
+    """The x sweep's finish of one chunk of 8 positions under a virtual border (k_envelope_dc, STAGE 3): positions past the end of the
+    line were set to D = 0 ("not mine": nothing is stored for them) BEFORE this step, which lowers every D to the squared distance to
+    the padded layer -- b = min(byz, p + 1, nx - p), b^2 as the low 32 bits of a 24 x 24-bit product (v_mul_u32_u24), compared as a
+    signed int.  Past the end b <= 0, and from b = -1 on the product is 0xFE000001 = negative: without the guard the position is no
+    longer 0 and its value is stored x planes behind the field (the bug round 5's fuzz found at nx = 9).  Returns the chunk's D."""
+    out = list(D)
+    for k in range(8):
+        p = p0 + k
+        b = byz
+        if nx > 1:
+            b = min(b, min(p + 1, nx - p))
+        if b < 32768 and (p < L or not guarded):
+            sq = i32((b & 0xFFFFFF) * (b & 0xFFFFFF))
+            out[k] = min(out[k], sq)
+    return out
+
+
 def brute(F):
     L = len(F)
     out = []
