@@ -77,9 +77,7 @@ struct sdfgpu_context {
     // build skips the two probes and the three guarded marching launches (35 us of a 0.8 - 1.4 ms build) and enqueues KE2 -> KE3
     // directly (int32 hand-off); every 16th build probes again.  The far-field pair is exact on any scene: a wrong prediction costs
     // time, never a voxel.  Option "far_predict" (0 off, 1 on, 2 every build: tests and the fuzz).
-    int far_predict = 1;
-    int far_streak = 0;              // consecutive reported builds whose y AND x sweeps were the far-field kernel's
-    uint64_t build_seq = 0;
+    FarHabit far;                    // (sdfgpu_policy.hpp: plain C++, driven on the CPU by tests/policy_harness.cpp)
     uint32_t* h_far = nullptr;       // second report slot (pinned): builds that do not carry the dense tier report their far flags here
     uint32_t* h_far_dev = nullptr;
     hipEvent_t far_ev = nullptr;
@@ -858,13 +856,12 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->flags_pending = false;
         //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict, status word 20, as word 8)
         h->pol.consume_report(h->h_flags[3] != 0, h->h_flags[6] != 0, h->h_flags[8] != 0);
-        h->far_streak = (h->h_flags[4] != 0 && h->h_flags[5] != 0) ? std::min(h->far_streak + 1, 1 << 20) : 0;
+        h->far.consume_report(h->h_flags[4] != 0, h->h_flags[5] != 0);
     }
     if (h->far_pending && hipEventQuery(h->far_ev) == hipSuccess) {
         h->far_pending = false;
-        h->far_streak = (h->h_far[4] != 0 && h->h_far[5] != 0) ? std::min(h->far_streak + 1, 1 << 20) : 0;
+        h->far.consume_report(h->h_far[4] != 0, h->h_far[5] != 0);
     }
-    ++h->build_seq;
     const DensePlan plan = h->pol.plan(dense, dense_generic, nz / 32 <= 256 && h->ball_block <= 256, vb != 0);
     dense = plan.dense;
     // bounded marching scans + the far-field kernel behind them, on every shape that kernel takes; other shapes (lines beyond
@@ -892,8 +889,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
                        (h->fused_always || (dense && h->pol.expect_dense) || (!envelope && !dense));
     const bool select = dev_select && !fused;
     // (see far_predict: the handle's recent builds were far-field on both axes -- or the caller forces it)
-    const bool predicted = select && h->force_env < 0 &&
-                           (h->far_predict == 2 || (h->far_predict == 1 && h->far_streak >= 4 && (h->build_seq & 15u) != 0u));
+    const bool predicted = h->far.plan(select, h->force_env >= 0);
     if (!fused && !standby) if (int rc = ensure(h, h->zfield, (size_t)n * 2)) return rc;
     // status block [0..7]: maxima, status, uncertified, far flags, fix_needed.  Normally still zero from the previous
     // build's fold kernel; cleared here after a build that failed half-way (or before the first one)
@@ -2160,7 +2156,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "i32_handoff") h->i32_handoff = value != 0;
     else if (n == "standby_far") h->standby_far = value != 0;
     else if (n == "host_pack") h->host_pack = (value >= 0 && value <= 2) ? value : 1;
-    else if (n == "far_predict") { h->far_predict = (value >= 0 && value <= 2) ? value : 1; h->far_streak = 0; }
+    else if (n == "far_predict") h->far.set_mode(value);
     else if (n == "standby_fold") h->standby_fold = value != 0;
     else if (n == "standby_grid") h->standby_grid = value >= 32 ? value : 1024;
     else if (n == "expect_dense") h->pol.expect_dense = value != 0;      // tests: put the handle into the "dense tier trusted" state
@@ -2168,7 +2164,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
-    else if (n == "policy_reset") { h->flags_pending = false; h->pol.reset(); h->far_streak = 0; }
+    else if (n == "policy_reset") { h->flags_pending = false; h->pol.reset(); h->far.reset(); }
     else if (n == "fixup") { h->pol.fixup_on = value != 0; h->pol.fix_mode = false; h->pol.dense3_mode = false; }
     else if (n == "dense3") { h->pol.dense3_on = value != 0; h->pol.dense3_mode = false; }
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;

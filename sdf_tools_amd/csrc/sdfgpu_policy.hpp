@@ -11,8 +11,32 @@
 //  and the sequence ADVICE r3 asked to pin: staged build -> fix-up mode -> failing seed.)
 #pragma once
 #include <algorithm>
+#include <cstdint>
 
 namespace sdfgpu {
+
+// "This handle's scene is a far-field scene on both axes" (round 5).  Learnt from the far flags of the status blocks that come back
+// (status words 4 and 5: the y / x sweep was the far-field kernel's); a build in the habit enqueues KE2 -> KE3 directly, without the two
+// tier probes and the three guarded marching launches.  Like everything in this header it is exactness-neutral: the far-field pair is
+// exact on any scene, so a stale habit costs time on at most kProbeEvery - 1 builds, never a voxel.
+struct FarHabit {
+    static constexpr int kStreak = 4;                // far-field reports in a row before the probes are dropped
+    static constexpr unsigned kProbeEvery = 16;      // ... and every 16th build carries them again
+    int mode = 1;                                    // option "far_predict": 0 never, 1 learnt, 2 every build (tests, the fuzz)
+    int streak = 0;                                  // consecutive reported builds whose y AND x sweeps were far-field
+    uint64_t seq = 0;                                // builds planned so far
+
+    void reset() { streak = 0; }
+    void set_mode(int m) { mode = (m >= 0 && m <= 2) ? m : 1; streak = 0; }
+    // a report has arrived (any build's: a dense-certified build has both flags down and ends the habit at once)
+    void consume_report(bool far_y, bool far_x) { streak = (far_y && far_x) ? std::min(streak + 1, 1 << 20) : 0; }
+    // One call per build.  selectable: the build would otherwise choose its sweeps' tiers on the device (probes); forced: a tier is
+    // forced by an option (nothing to predict).  Returns whether this build takes the far-field pair without probing.
+    bool plan(bool selectable, bool forced) {
+        ++seq;
+        return selectable && !forced && (mode == 2 || (mode == 1 && streak >= kStreak && (seq % kProbeEvery) != 0u));
+    }
+};
 
 // What a build was, remembered with its report.
 struct ReportedBuild {

@@ -45,4 +45,18 @@ int pol_state(void* h, int which) {
     return -1;
 }
 
+// ---- the far-field habit (round 5) ------------------------------------------------------------------------------------------
+void* far_new(int mode) {
+    sdfgpu::FarHabit* f = new sdfgpu::FarHabit();
+    f->set_mode(mode);
+    return f;
+}
+void far_free(void* h) { delete static_cast<sdfgpu::FarHabit*>(h); }
+// one build: 1 = the far-field pair without probes
+int far_plan(void* h, int selectable, int forced) { return static_cast<sdfgpu::FarHabit*>(h)->plan(selectable != 0, forced != 0) ? 1 : 0; }
+void far_report(void* h, int far_y, int far_x) { static_cast<sdfgpu::FarHabit*>(h)->consume_report(far_y != 0, far_x != 0); }
+void far_reset(void* h) { static_cast<sdfgpu::FarHabit*>(h)->reset(); }
+void far_set_mode(void* h, int mode) { static_cast<sdfgpu::FarHabit*>(h)->set_mode(mode); }
+int far_streak(void* h) { return static_cast<sdfgpu::FarHabit*>(h)->streak; }
+
 }  // extern "C"

@@ -210,6 +210,10 @@ def _policy_lib():
     L.pol_report.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3
     L.pol_state.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.pol_remember.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4
+    L.far_new.restype = ctypes.c_void_p
+    L.far_new.argtypes = [ctypes.c_int]
+    for f, n in ((L.far_free, 0), (L.far_plan, 2), (L.far_report, 2), (L.far_reset, 0), (L.far_set_mode, 1), (L.far_streak, 0)):
+        f.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * n
     return L
 
 
@@ -284,6 +288,62 @@ def test_dense_tier_policy_sequences_on_the_cpu():
     assert sum(later) <= 8, sum(later)                             # (before: a probe in EVERY build between a pause's end and the report)
     assert L.pol_state(h, 3) >= 63                                 # the back-off doubled: 15 -> 31 -> 63 ...
     L.pol_free(h)
+
+
+def test_far_field_habit_sequences_on_the_cpu():
+    """sdfgpu_policy.hpp's FarHabit (round 5), host-only: a handle drops its tier probes after four far-field reports in a row, carries
+    them again every 16th build, loses the habit with the first report that is not far-field on both axes (a dense-certified build
+    has both flags down), never predicts for builds that do not select tiers on the device or whose tier an option forces, and
+    survives reports that arrive many builds late or not at all."""
+    L = _policy_lib()
+    # synchronous caller: every build's report is read before the next build
+    h = L.far_new(1)
+    got = []
+    for k in range(64):
+        got.append(L.far_plan(h, 1, 0))
+        L.far_report(h, 1, 1)
+    assert got[:4] == [0, 0, 0, 0] and sum(got) == 64 - 4 - 4, got      # learnt after 4 reports; builds 16, 32, 48, 64 probe again
+    assert [k + 1 for k, v in enumerate(got) if not v and k >= 4] == [16, 32, 48, 64]
+    # the scene changes: predicted builds' own flags are not reports (build_device_impl does not publish them) -- only the probing
+    # build's report ends the habit, so at most 15 builds run the far-field pair on a near-field scene
+    wrong = 0
+    for k in range(40):
+        p = L.far_plan(h, 1, 0)
+        wrong += p
+        if not p:
+            L.far_report(h, 0, 0)
+    assert wrong <= 15 and L.far_streak(h) == 0 and L.far_plan(h, 1, 0) == 0
+    # y far-field only: never a habit
+    for k in range(40):
+        assert L.far_plan(h, 1, 0) == 0
+        L.far_report(h, 1, 0)
+    # a dense-certified report in the middle of a far-field run starts the count again
+    L.far_reset(h)
+    for flags in ((1, 1), (1, 1), (1, 1), (0, 0), (1, 1), (1, 1), (1, 1)):
+        L.far_report(h, *flags)
+    assert L.far_streak(h) == 3
+    # builds that do not choose tiers on the device (stand-by behind a trusted dense tier, fused sweeps) and forced tiers never predict
+    L.far_report(h, 1, 1)
+    L.far_report(h, 1, 1)
+    assert L.far_plan(h, 0, 0) == 0 and L.far_plan(h, 1, 1) == 0
+    # reports that never come: nothing is learnt, nothing breaks; late reports teach late
+    L.far_free(h)
+    h = L.far_new(1)
+    assert sum(L.far_plan(h, 1, 0) for _ in range(100)) == 0
+    for _ in range(4):
+        L.far_report(h, 1, 1)
+    assert sum(L.far_plan(h, 1, 0) for _ in range(32)) == 30
+    # modes: 0 never, 2 every selectable build; changing the mode forgets the streak
+    L.far_set_mode(h, 0)
+    assert L.far_streak(h) == 0
+    for _ in range(8):
+        L.far_report(h, 1, 1)
+    assert sum(L.far_plan(h, 1, 0) for _ in range(20)) == 0
+    L.far_set_mode(h, 2)
+    assert sum(L.far_plan(h, 1, 0) for _ in range(20)) == 20 and L.far_plan(h, 0, 0) == 0 and L.far_plan(h, 1, 1) == 0
+    L.far_set_mode(h, 7)                                           # out of range = the default
+    assert L.far_plan(h, 1, 0) == 0
+    L.far_free(h)
 
 
 @pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "asan_ubsan"])
