@@ -93,6 +93,17 @@ static int check_policy() {
     }
     const sdfgpu::DensePlan last = pol.plan(true, false, true, false);
     CHECK(last.dense || !last.dense);                         // (any state is legal; the sanitizers watch the arithmetic)
+    // the far-field habit (round 5): a long run of far-field reports, re-probes, a scene change, every mode
+    sdfgpu::FarHabit far;
+    int predicted = 0;
+    for (int b = 0; b < 5000; ++b) {
+        const bool p = far.plan((b % 7) != 3, (b % 11) == 5);
+        predicted += p ? 1 : 0;
+        if (!p) far.consume_report(b < 3000 || (b % 2) == 0, b < 3000);
+        if (b == 4000) far.set_mode(2);
+        if (b == 4500) far.set_mode(0);
+    }
+    CHECK(predicted > 2000 && far.streak >= 0 && far.seq == 5000);
     return 0;
 }
 
