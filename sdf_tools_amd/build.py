@@ -32,7 +32,7 @@ def _hipcc():
             return c
 
 
-def build_libsdfgpu(force=False, verbose=False):
+def build_libsdfgpu(force=False, verbose=False, out=None):
     """Three translation units -> objects (compiled side by side) -> libsdfgpu.so: sdfgpu.hip (C ABI, host orchestration, most
     kernels), sdfgpu_envelope_tu.hip (the far-field kernel's instantiations) and sdfgpu_dense6_tu.hip (the shell pass).  Each object is rebuilt when its
     source or ANY header it can include is newer (a stale library after a header-only edit is the kind of bug that
@@ -54,18 +54,35 @@ def build_libsdfgpu(force=False, verbose=False):
         if force or _newer(obj, [src] + deps):
             todo.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-I", INCLUDE, "-c", src,
                          "-o", obj] + extra)
-    if not todo and not _newer(LIB, objs):
-        return LIB
+    lib = out or LIB
+    if not todo and not _newer(lib, objs):
+        return lib
     if verbose:
         for cmd in todo:
             print(" ".join(cmd))
     with ThreadPoolExecutor(max_workers=3) as pool:
         list(pool.map(subprocess.check_call, todo))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
+
+
+def build_profiling_variant(name, flags, verbose=False):
+    """A profiling build of the same library (never the shipped one): tools/probe/libsdfgpu_<name>.so compiled with extra
+    flags -- "hooks": -DSDFGPU_DEBUG_HOOKS (switches that skip work; results are then wrong), "trips":
+    -DSDFGPU_PHASE_CLOCKS -DSDFGPU_TRIP_COUNTS.  Selected with SDFGPU_LIB=<path> by the tools/ scripts."""
+    out = os.path.join(ROOT, "tools", "probe", "libsdfgpu_%s.so" % name)
+    old = os.environ.get("SDFGPU_EXTRA_FLAGS")
+    os.environ["SDFGPU_EXTRA_FLAGS"] = flags
+    try:
+        return build_libsdfgpu(False, verbose, out)
+    finally:
+        if old is None:
+            del os.environ["SDFGPU_EXTRA_FLAGS"]
+        else:
+            os.environ["SDFGPU_EXTRA_FLAGS"] = old
 
 
 def build_libsdfgpu_multi(force=False, verbose=False):

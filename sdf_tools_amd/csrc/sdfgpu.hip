@@ -10,9 +10,12 @@
 #include "sdfgpu_dense.hpp"
 #include "sdfgpu_envelope_dc.hpp"
 #include "sdfgpu_policy.hpp"
+#include "sdfgpu_hostteam.hpp"
 
 #include <sys/mman.h>
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -65,6 +68,8 @@ struct sdfgpu_context {
     DeviceBuffer query_stage;   // host-API staging of sdfgpu_query_points: points | distance | gradient | flags
     size_t tag_cached_bytes = 0;            // stage_in holds the tagged cell records of the last sdfgpu_build_tagged_cells call
     void* pin[2] = {nullptr, nullptr};      // pinned host staging of copy_to_host (two chunks in flight)
+    HostTeam* team = nullptr;               // the host threads that fill / drain the staging chunks: created with the first staged
+                                            // transfer, parked between calls, joined by sdfgpu_destroy (sdfgpu_hostteam.hpp)
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     uint32_t* d_small = nullptr;   // [0] max d^2 free, [1] max d^2 filled, [2] status, [3] uncertified, [4] far_y, [5] far_x
     hipStream_t last_stream = nullptr;
@@ -1173,50 +1178,22 @@ int copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, hi
         const uintptr_t hi = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(kHuge - 1);
         if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
     }
-    const int64_t nchunks = (int64_t)((bytes + kPinChunk - 1) / kPinChunk);
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int team = (int)std::max<size_t>(1, std::min<size_t>(16, hw / 4));
-    std::atomic<int64_t> ready{-1};                      // highest chunk whose bytes are in its staging buffer
-    std::atomic<int64_t> copied{0};                      // slices copied out so far (team slices per chunk)
-    std::atomic<bool> abort{false};
-    auto chunk_bytes = [&](int64_t i) { return std::min(kPinChunk, bytes - (size_t)i * kPinChunk); };
-    std::vector<std::thread> workers;
-    workers.reserve((size_t)team);
-    for (int w = 0; w < team; ++w) {
-        workers.emplace_back([&, w]() {
-            for (int64_t i = 0; i < nchunks; ++i) {
-                while (ready.load(std::memory_order_acquire) < i) {
-                    if (abort.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
-                }
-                const size_t len = chunk_bytes(i);
-                const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
-                const size_t b = std::min(len, (size_t)w * per), e = std::min(len, b + per);
-                if (e > b) memcpy(static_cast<char*>(dst) + (size_t)i * kPinChunk + b, static_cast<const char*>(h->pin[i & 1]) + b, e - b);
-                copied.fetch_add(1, std::memory_order_release);
-            }
-        });
-    }
-    auto issue = [&](int64_t i) -> hipError_t {
-        hipError_t e = hipMemcpyAsync(h->pin[i & 1], static_cast<const char*>(d_src) + (size_t)i * kPinChunk, chunk_bytes(i),
-                                      hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipEventRecord(h->pin_ev[i & 1], st);
-        return e;
-    };
-    hipError_t err = issue(0);
-    if (err == hipSuccess && nchunks > 1) err = issue(1);
-    for (int64_t i = 0; i < nchunks && err == hipSuccess; ++i) {
-        err = hipEventSynchronize(h->pin_ev[i & 1]);
-        if (err != hipSuccess) break;
-        ready.store(i, std::memory_order_release);
-        while (copied.load(std::memory_order_acquire) < (i + 1) * team) std::this_thread::yield();      // buffer i & 1 is free again
-        if (i + 2 < nchunks) err = issue(i + 2);
-    }
-    if (err != hipSuccess) abort.store(true);
-    for (std::thread& w : workers) w.join();
-    if (err != hipSuccess) {
+    if (!h->team) h->team = new (std::nothrow) HostTeam();
+    if (!h->team) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
+    // (the scheduler is host-only code, tests/sched_harness.cpp runs it under -fsanitize=thread: sdfgpu_hostteam.hpp)
+    hipError_t herr = hipSuccess;
+    const int rc = staged_drain(
+        *h->team, bytes, kPinChunk, host_team_size(16),
+        [&](int64_t i, int buf, size_t len) -> int {
+            herr = hipMemcpyAsync(h->pin[buf], static_cast<const char*>(d_src) + (size_t)i * kPinChunk, len, hipMemcpyDeviceToHost, st);
+            if (herr == hipSuccess) herr = hipEventRecord(h->pin_ev[buf], st);
+            return herr == hipSuccess ? 0 : 1;
+        },
+        [&](int buf) -> int { herr = hipEventSynchronize(h->pin_ev[buf]); return herr == hipSuccess ? 0 : 1; },
+        [&](int buf, size_t off, size_t goff, size_t len) { memcpy(static_cast<char*>(dst) + goff, static_cast<const char*>(h->pin[buf]) + off, len); });
+    if (rc != 0) {
         (void)hipDeviceSynchronize();
-        return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) in the device-to-host copy", (int)err, hipGetErrorString(err));
+        return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) in the device-to-host copy", (int)herr, hipGetErrorString(herr));
     }
     return SDFGPU_OK;
 }
@@ -1229,82 +1206,40 @@ int copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, hi
 // of 4096 bytes except the last): a plain memcpy for copy_from_host, the cells / mask -> bits classification for the
 // host-buffer builds (round 5), which is what makes the team worth more than a copy -- it reads 8 or 64 bytes per byte sent.
 template <class Fill>
-int staged_upload(sdfgpu_handle h, void* d_dst, size_t bytes, hipStream_t st, int team_cap, Fill fill) {
+int staged_upload_hip(sdfgpu_handle h, void* d_dst, size_t bytes, hipStream_t st, int team_cap, Fill fill) {
     if (bytes == 0) return SDFGPU_OK;
     for (int i = 0; i < 2; ++i) {
         if (!h->pin[i] && hipHostMalloc(&h->pin[i], kPinChunk, hipHostMallocDefault) != hipSuccess) h->pin[i] = nullptr;
         if (h->pin[i] && !h->pin_ev[i] && hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) h->pin_ev[i] = nullptr;
     }
-    if (!h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1])
-        return fail(h, SDFGPU_ERR_HIP, "no pinned staging memory for the host-to-device copy");
-    const int64_t nchunks = (int64_t)((bytes + kPinChunk - 1) / kPinChunk);
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int team = (int)std::max<size_t>(1, std::min<size_t>((size_t)team_cap, hw / 4));
-    std::atomic<int64_t> may_fill{1};                    // chunks 0 .. may_fill may be written to their staging buffer
-    // slices filled, PER CHUNK: chunks i and i + 1 may be filled at the same time, so one running total would let the fast
-    // threads' slices of chunk i + 1 stand in for a slow thread's slice of chunk i (round 5: seen once in ~10 runs of the
-    // 100 MiB copy test after the calling thread became a filler)
-    std::vector<std::atomic<int>> filled((size_t)nchunks);
-    for (auto& f : filled) f.store(0, std::memory_order_relaxed);
-    std::atomic<bool> abort{false};
-    auto chunk_bytes = [&](int64_t i) { return std::min(kPinChunk, bytes - (size_t)i * kPinChunk); };
-    auto work = [&](int w) {
-        for (int64_t i = 0; i < nchunks; ++i) {
-            while (may_fill.load(std::memory_order_acquire) < i) {
-                if (abort.load(std::memory_order_relaxed)) return;
-                std::this_thread::yield();
-            }
-            const size_t len = chunk_bytes(i);
-            const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
-            const size_t b = std::min(len, (size_t)w * per), e = std::min(len, b + per);
-            if (e > b) fill(static_cast<char*>(h->pin[i & 1]) + b, (size_t)i * kPinChunk + b, e - b);
-            filled[(size_t)i].fetch_add(1, std::memory_order_release);
+    if (!h->pin[0] || !h->pin[1] || !h->pin_ev[0] || !h->pin_ev[1]) {
+        // no pinned staging (a locked-memory limit): produce the bytes into a pageable temporary, one runtime-staged copy each
+        // (slower, never wrong -- ADVICE r5: rounds 1 - 4 had this fallback, round 5 had dropped it)
+        (void)hipGetLastError();
+        std::vector<char> tmp(std::min(bytes, kPinChunk));
+        for (size_t o = 0; o < bytes; o += tmp.size()) {
+            const size_t len = std::min(tmp.size(), bytes - o);
+            fill(tmp.data(), o, len);
+            HIP_TRY(h, hipMemcpyAsync(static_cast<char*>(d_dst) + o, tmp.data(), len, hipMemcpyHostToDevice, st));
+            HIP_TRY(h, hipStreamSynchronize(st));           // (tmp is refilled by the next round)
         }
-    };
-    std::vector<std::thread> workers;
-    workers.reserve((size_t)team);
-    for (int w = 1; w < team; ++w) workers.emplace_back(work, w);
-    hipError_t err = hipSuccess;
-    // (the calling thread is slice 0 of the first chunk -- a one-chunk upload, 16 MiB of bits for 512^3, would otherwise only wait)
-    {
-        const size_t len = chunk_bytes(0);
-        const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
-        const size_t e = std::min(len, per);
-        if (e > 0) fill(static_cast<char*>(h->pin[0]), 0, e);
-        filled[(size_t)0].fetch_add(1, std::memory_order_release);
+        return SDFGPU_OK;
     }
-    std::thread rest;                                    // ... and hands its slices of the later chunks to one more worker
-    if (nchunks > 1) rest = std::thread([&]() {
-        for (int64_t i = 1; i < nchunks; ++i) {
-            while (may_fill.load(std::memory_order_acquire) < i) {
-                if (abort.load(std::memory_order_relaxed)) return;
-                std::this_thread::yield();
-            }
-            const size_t len = chunk_bytes(i);
-            const size_t per = ((len / (size_t)team) + 4095) & ~(size_t)4095;
-            const size_t e = std::min(len, per);
-            if (e > 0) fill(static_cast<char*>(h->pin[i & 1]), (size_t)i * kPinChunk, e);
-            filled[(size_t)i].fetch_add(1, std::memory_order_release);
-        }
-    });
-    for (int64_t i = 0; i < nchunks && err == hipSuccess; ++i) {
-        while (filled[(size_t)i].load(std::memory_order_acquire) < team) std::this_thread::yield();
-        err = hipMemcpyAsync(static_cast<char*>(d_dst) + (size_t)i * kPinChunk, h->pin[i & 1], chunk_bytes(i), hipMemcpyHostToDevice, st);
-        if (err == hipSuccess) err = hipEventRecord(h->pin_ev[i & 1], st);
-        // chunk i + 1 was released for filling already; chunk i + 2 shares this chunk's buffer: release it once this DMA is done
-        if (err == hipSuccess && i + 2 < nchunks) {
-            err = hipEventSynchronize(h->pin_ev[i & 1]);
-            may_fill.store(i + 2, std::memory_order_release);
-        }
-    }
-    if (err != hipSuccess) abort.store(true);
-    for (std::thread& w : workers) w.join();
-    if (rest.joinable()) rest.join();
-    if (err == hipSuccess) err = hipEventSynchronize(h->pin_ev[(nchunks - 1) & 1]);
-    if (err == hipSuccess && nchunks > 1) err = hipEventSynchronize(h->pin_ev[(nchunks - 2) & 1]);
-    if (err != hipSuccess) {
+    if (!h->team) h->team = new (std::nothrow) HostTeam();
+    if (!h->team) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
+    hipError_t herr = hipSuccess;
+    const int rc = sdfgpu::staged_upload(
+        *h->team, bytes, kPinChunk, host_team_size(team_cap),
+        [&](int buf, size_t off, size_t goff, size_t len) { fill(static_cast<char*>(h->pin[buf]) + off, goff, len); },
+        [&](int64_t i, int buf, size_t len) -> int {
+            herr = hipMemcpyAsync(static_cast<char*>(d_dst) + (size_t)i * kPinChunk, h->pin[buf], len, hipMemcpyHostToDevice, st);
+            if (herr == hipSuccess) herr = hipEventRecord(h->pin_ev[buf], st);
+            return herr == hipSuccess ? 0 : 1;
+        },
+        [&](int buf) -> int { herr = hipEventSynchronize(h->pin_ev[buf]); return herr == hipSuccess ? 0 : 1; });
+    if (rc != 0) {
         (void)hipDeviceSynchronize();
-        return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) in the host-to-device copy", (int)err, hipGetErrorString(err));
+        return fail(h, SDFGPU_ERR_HIP, "HIP error %d (%s) in the host-to-device copy", (int)herr, hipGetErrorString(herr));
     }
     return SDFGPU_OK;
 }
@@ -1316,7 +1251,7 @@ int copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, 
         HIP_TRY(h, hipStreamSynchronize(st));
         return SDFGPU_OK;
     }
-    return staged_upload(h, d_dst, bytes, st, 16, [src](char* dst, size_t o, size_t len) { memcpy(dst, static_cast<const char*>(src) + o, len); });
+    return staged_upload_hip(h, d_dst, bytes, st, 16, [src](char* dst, size_t o, size_t len) { memcpy(dst, static_cast<const char*>(src) + o, len); });
 }
 
 // ---- host-side classification: cells / mask -> one bit per voxel (round 5) ----------------------------------
@@ -1328,12 +1263,21 @@ void pack_mask_bits(const uint8_t* m, int64_t n, size_t ob, size_t len, uint8_t*
     const int64_t v0 = (int64_t)ob * 8, v1 = std::min<int64_t>(n, v0 + (int64_t)len * 8);
     int64_t v = v0;
     size_t o = 0;
+#if defined(__SSE2__)
     const __m128i zero = _mm_setzero_si128();
     for (; v + 16 <= v1; v += 16, o += 2) {
         const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i*>(m + v));
         const uint32_t nz = ~(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, zero)) & 0xffffu;
         out[o] = (uint8_t)nz; out[o + 1] = (uint8_t)(nz >> 8);
     }
+#else       // (hosts without SSE2: eight bytes -> eight bits by the multiply trick)
+    for (; v + 8 <= v1; v += 8, ++o) {
+        uint64_t x;
+        memcpy(&x, m + v, 8);
+        x = (x | ((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full)) & 0x8080808080808080ull;
+        out[o] = (uint8_t)(((x >> 7) * 0x0102040810204080ull) >> 56);
+    }
+#endif
     for (; o < len; ++o) {
         uint32_t b = 0;
         for (int k = 0; k < 8; ++k, ++v) if (v < v1 && m[v]) b |= 1u << k;
@@ -1344,6 +1288,7 @@ void pack_cells_bits(const char* cells, size_t stride, size_t off, int unknown, 
     const int64_t v0 = (int64_t)ob * 8, v1 = std::min<int64_t>(n, v0 + (int64_t)len * 8);
     int64_t v = v0;
     size_t o = 0;
+#if defined(__SSE2__)
     if (stride == 8 && (off == 0 || off == 4)) {                // COLLISION_CELL {float occupancy; uint32 component}: 4 records per pair of loads
         const __m128 half = _mm_set1_ps(0.5f);
         const __m128 unk = _mm_castsi128_ps(_mm_set1_epi32(unknown ? -1 : 0));
@@ -1360,6 +1305,7 @@ void pack_cells_bits(const char* cells, size_t stride, size_t off, int unknown, 
             out[o] = (uint8_t)b;
         }
     }
+#endif
     for (; o < len; ++o) {
         uint32_t b = 0;
         for (int k = 0; k < 8; ++k, ++v) {
@@ -1387,7 +1333,7 @@ int upload_packed(sdfgpu_handle h, const uint8_t* filled, const void* cells, siz
         if (real < len) memset(dst + real, 0, len - real);
     };
     if (padded >= ((size_t)256 << 10)) {
-        if (int rc = staged_upload(h, h->stage_bits.ptr, padded, st, 32, fill)) return rc;
+        if (int rc = staged_upload_hip(h, h->stage_bits.ptr, padded, st, 32, fill)) return rc;
     } else {                                                    // small grids: one thread, one runtime-staged copy
         std::vector<char> tmp(padded);
         fill(tmp.data(), 0, padded);
@@ -1521,6 +1467,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
     for (size_t i = 0; i < h->events.size(); ++i)
         if (i % 8 == 0 || h->events[i] != h->events[i - 1]) (void)hipEventDestroy(h->events[i]);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    delete h->team;                                             // (joins the parked host threads)
     delete h;
     return SDFGPU_OK;
 }

@@ -1037,6 +1037,9 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         int D1 = (int)(ent & 0xfffu);           // (saturated at kDcLocalSat: then only a candidate found below can finish the voxel)
                         // offsets in rounds of 4 (8 loads in flight; D1 <= 1023: at most 8 rounds).  A candidate beyond the bound that
                         // rides along in a round is still a candidate: harmless.
+#ifdef SDFGPU_DEBUG_HOOKS
+                        if (a.dbg & 64) D1 = 1;                 // profiling builds: bit 6 = no local-search rounds (wrong results)
+#endif
                         for (int d0 = 1; (int)__umul24(d0, d0) < D1; d0 += 4) {
                             int v[8];
 #pragma unroll

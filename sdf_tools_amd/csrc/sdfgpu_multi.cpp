@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/sdfgpu_multi.h"
+#include "sdfgpu_hostteam.hpp"
 
 namespace {
 
@@ -60,6 +61,8 @@ struct Msg {
 struct sdfgpu_multi_context {
     std::vector<Rank> r;
     bool use_rccl = false;
+    bool rccl_dead = false;         // the communicators were aborted after a rank failed with an exchange in flight: the context is
+                                    // finished (every later build returns an error; destroy and create again)
     std::string error;
     int halo = 3;
     bool dense_on = true;
@@ -141,91 +144,12 @@ bool dense_shape_ok(int64_t nz) {
 // other on the host (message matching orders the devices); when several logical ranks share a GPU (the single-GPU test form:
 // device-to-device copies that read the SENDER's buffer behind the sender's event) a host barrier stands between the step that
 // records an event and the step that waits for it.
-struct Step {
-    std::function<int(int)> fn;     // what rank q does (returns an SDFGPU_* code; the message goes to its Rank::error)
-    bool barrier_after;             // every rank must have finished this step before any starts the next (copy mode only)
-    bool wait;                      // a step that only waits for the device: not counted as host time
-};
-
-struct Team {
-    int G = 1;
-    std::vector<std::thread> th;
-    std::mutex m;
-    std::condition_variable cv;
-    uint64_t epoch = 0;             // (guarded by m) bumped for every job
-    bool quit = false;
-    const std::vector<Step>* job = nullptr;
-    std::atomic<int> done{0};
-    std::atomic<int> bar_count{0}, bar_sense{0};
-    std::vector<int> rc;
-    std::vector<double> busy_us;    // host time of the last job per rank thread, waits and barriers excluded
-
-    static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    void barrier() {
-        if (G <= 1) return;
-        const int s = bar_sense.load(std::memory_order_acquire);
-        if (bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == G) {
-            bar_count.store(0, std::memory_order_relaxed);
-            bar_sense.store(s ^ 1, std::memory_order_release);
-        } else {
-            while (bar_sense.load(std::memory_order_acquire) == s) std::this_thread::yield();
-        }
-    }
-    void run_rank(int q, const std::vector<Step>& steps) {
-        int my = SDFGPU_OK;
-        double busy = 0.0;
-        for (const Step& st : steps) {
-            if (my == SDFGPU_OK) {              // (a failed rank still meets the others at the barriers)
-                const double t0 = now_us();
-                my = st.fn(q);
-                if (!st.wait) busy += now_us() - t0;
-            }
-            if (st.barrier_after) barrier();
-        }
-        rc[(size_t)q] = my;
-        busy_us[(size_t)q] = busy;
-    }
-    void worker(int q, int dev) {
-        (void)hipSetDevice(dev);                // (the current device is per thread: set once for the life of the thread)
-        uint64_t seen = 0;
-        for (;;) {
-            const std::vector<Step>* steps;
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return quit || epoch != seen; });
-                if (quit) return;
-                seen = epoch;
-                steps = job;
-            }
-            run_rank(q, *steps);
-            done.fetch_add(1, std::memory_order_release);
-        }
-    }
-    void start(const std::vector<int>& devs) {
-        G = (int)devs.size();
-        rc.assign((size_t)G, SDFGPU_OK);
-        busy_us.assign((size_t)G, 0.0);
-        for (int q = 1; q < G; ++q) th.emplace_back(&Team::worker, this, q, devs[(size_t)q]);
-    }
-    void stop() {
-        { std::lock_guard<std::mutex> lk(m); quit = true; }
-        cv.notify_all();
-        for (std::thread& t : th) t.join();
-        th.clear();
-    }
-    // every rank runs `steps`; returns the first failing rank (or -1)
-    int run(const std::vector<Step>& steps) {
-        done.store(0, std::memory_order_relaxed);
-        if (G > 1) {
-            { std::lock_guard<std::mutex> lk(m); job = &steps; ++epoch; }
-            cv.notify_all();
-        }
-        run_rank(0, steps);
-        while (done.load(std::memory_order_acquire) < G - 1) std::this_thread::yield();
-        for (int q = 0; q < G; ++q) if (rc[(size_t)q] != SDFGPU_OK) return q;
-        return -1;
-    }
-};
+// The dispatcher itself is host-only code (sdfgpu_hostteam.hpp: RankTeam, run under -fsanitize=thread by tests/sched_harness.cpp).
+// A rank whose step fails skips its remaining steps; the others look before every EXCHANGE step and skip it too, and when one of
+// them had posted already the failing rank's watchdog aborts the communicators (abort_comms) so that the build returns the
+// error instead of hanging in hipStreamSynchronize.
+using Step = sdfgpu::RankStep;
+using Team = sdfgpu::RankTeam;
 
 int rfail(Rank& k, int code, const char* fmt, ...) {
     char buf[640];
@@ -263,7 +187,9 @@ int run_steps(sdfgpu_multi_handle h, const std::vector<Step>& steps) {
     for (double v : t.busy_us) { mx = std::max(mx, v); sum += v; }
     h->host_us_max += mx;
     h->host_us_sum += sum;
-    if (bad >= 0) return mfail(h, t.rc[(size_t)bad], "rank %d: %s", bad, h->r[(size_t)bad].error.c_str());
+    if (t.aborted && h->use_rccl) h->rccl_dead = true;
+    if (bad >= 0) return mfail(h, t.rc[(size_t)bad], "rank %d: %s%s", bad, h->r[(size_t)bad].error.c_str(),
+                               h->rccl_dead ? " (peers had posted an exchange: the RCCL communicators were aborted, destroy this context)" : "");
     return SDFGPU_OK;
 }
 
@@ -344,6 +270,7 @@ int check_request(sdfgpu_multi_handle h, int64_t nx, int64_t ny, int64_t nz, con
 int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx, int64_t ny, int64_t nz, double res, int vb,
                  float* const* d_out, double* out_max, double* out_min) {
     const int G = (int)h->r.size();
+    if (h->rccl_dead) return mfail(h, SDFGPU_ERR_HIP, "this context's RCCL communicators were aborted after a rank failed mid-exchange; destroy it and create a new one");
     if (int rc = check_request(h, nx, ny, nz, nullptr, 0, 0)) return rc;
     const int64_t plane = ny * nz;
     int64_t min_slab = nx;
@@ -406,7 +333,7 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
             }
             if (int rc = phase(q, 1)) return rc;
             if (G > 1) R_HIP(k, hipEventRecord(k.ev_cs, k.cs));
-            return SDFGPU_OK; }, host_barriers, false});
+            return SDFGPU_OK; }, host_barriers, false, true});
         steps.push_back({[&](int q) -> int {                    // the 2 + 2 border planes, then the status block
             if (G > 1) if (int rc = s_after_cs(h, q, true)) return rc;
             if (int rc = phase(q, 2)) return rc;
@@ -471,7 +398,7 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
                 if (int rc = cs_after_s(h, q, true)) return rc;
                 if (int rc = exchange_rank(h, q, msgs)) return rc;
                 R_HIP(k, hipEventRecord(k.ev_cs, k.cs));
-                return SDFGPU_OK; }, host_barriers, false});
+                return SDFGPU_OK; }, host_barriers, false, true});
             steps.push_back({[&](int q) -> int {
                 Rank& k = h->r[(size_t)q];
                 if (int rc = s_after_cs(h, q, true)) return rc;
@@ -560,7 +487,7 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
                 if (int rc = cs_after_s(h, q)) return rc;
                 if (int rc = exchange_rank(h, q, there)) return rc;
                 R_HIP(k, hipEventRecord(k.ev_cs, k.cs));
-                return SDFGPU_OK; }, host_barriers, false});
+                return SDFGPU_OK; }, host_barriers, false, true});
             steps.push_back({[&](int q) -> int {
                 Rank& k = h->r[(size_t)q];
                 if (int rc = s_after_cs(h, q)) return rc;
@@ -580,7 +507,7 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
                 if (int rc = cs_after_s(h, q)) return rc;
                 if (int rc = exchange_rank(h, q, back)) return rc;
                 R_HIP(k, hipEventRecord(k.ev_cs, k.cs));
-                return SDFGPU_OK; }, host_barriers, false});
+                return SDFGPU_OK; }, host_barriers, false, true});
             steps.push_back({[&](int q) -> int {                // unpack what I received
                 Rank& k = h->r[(size_t)q];
                 if (int rc = s_after_cs(h, q)) return rc;
@@ -723,7 +650,13 @@ int sdfgpu_multi_create(int n_ranks, const int* devices, sdfgpu_multi_handle* ou
     }
     h->team = new (std::nothrow) sdfgpu_multi_team();
     if (!h->team) return bail(SDFGPU_ERR_INVALID_ARGUMENT, "out of host memory");
-    h->team->t.start(devs);                                 // one host thread per rank beyond the caller's (rank 0)
+    h->team->t.thread_init = [devs](int q) { (void)hipSetDevice(devs[(size_t)q]); };   // (the current device is per thread: set once)
+    if (h->use_rccl) h->team->t.on_stuck = [h]() {
+        // a rank failed while peers sat in an exchange that waits for it: end the posted operations.  The communicators are
+        // gone afterwards (rccl_dead): the build returns its error, every later build says why it cannot run.
+        for (Rank& k : h->r) if (k.comm) { (void)ncclCommAbort(k.comm); k.comm = nullptr; }
+    };
+    h->team->t.start(n_ranks);                              // one host thread per rank beyond the caller's (rank 0)
     *out_handle = h;
     return SDFGPU_OK;
 }

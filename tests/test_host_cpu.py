@@ -370,3 +370,31 @@ def test_oracle_policy_and_host_headers_under_sanitizers(sanitize):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "host headers OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("sanitize", [False, True], ids=["plain", "tsan"])
+def test_host_schedulers_under_thread_sanitizer(sanitize):
+    """VERDICT r5 "next round" 5: the library's host-side concurrency -- the thread team that outlives a call (HostTeam), the
+    chunk schedulers of the staged upload / download, libsdfgpu_multi's one-thread-per-rank step dispatcher with its
+    any-rank-failed agreement -- is host-only code in sdf_tools_amd/csrc/sdfgpu_hostteam.hpp with every device call
+    behind a callback; tests/sched_harness.cpp drives it against a fake DMA engine / fake exchanges with random delays, team
+    sizes 1 .. 32, injected DMA errors and failing ranks, built plain and with -fsanitize=thread.  The PRE-FIX arithmetic of
+    round 5's fill race (one running total of filled slices for two chunks in flight) is run too: it must be caught -- as
+    corrupted bytes by the plain build, as a data race by the sanitizer."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tests = os.path.join(root, "tests")
+    exe = os.path.join(tests, "sched_harness_tsan" if sanitize else "sched_harness")
+    san = ["-fsanitize=thread", "-g", "-O1"] if sanitize else ["-O2"]
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-pthread"] + san + [os.path.join(tests, "sched_harness.cpp"), "-o", exe])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:exitcode=66")
+    iters = 40 if sanitize else 150
+    for what in ("team", "upload", "drain", "ranks"):
+        r = subprocess.run([exe, what, "3", str(iters)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, what + "\n" + r.stdout + r.stderr[-3000:]
+    r = subprocess.run([exe, "upload_prefix", "3", str(3 * iters)], capture_output=True, text=True, timeout=600, env=env)
+    if sanitize:
+        assert "ThreadSanitizer: data race" in r.stderr, "the sanitizer did not see the pre-fix fill race\n" + r.stdout
+    else:
+        assert r.returncode == 3, "the pre-fix arithmetic did not corrupt a single upload: the harness is too tame\n" + r.stdout + r.stderr
