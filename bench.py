@@ -388,6 +388,74 @@ def parity_counts(ctx, res):
     return out
 
 
+CONTRACT_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data"]
+
+
+def summary_line(result):
+    """The ONE line the driver parses (VERDICT r5 "next round" 7): the contract fields, `roofline`, `cpu_baseline` and a short
+    summary of everything else -- round 5's single line had grown past the driver's stdout tail and lost its head."""
+    out = {k: result[k] for k in CONTRACT_KEYS if k in result}
+    cfg = result.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "grid", "voxels", "partition") if k in cfg}
+    r = result.get("roofline")
+    if r:
+        out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_voxel", "avg_ms",
+                                             "rocprof_avg_ms", "traffic_frac", "traffic_over_compulsory", "launches_timed") if k in r}
+    if "cpu_baseline" in result:
+        out["cpu_baseline"] = result["cpu_baseline"]
+    for k in ("value_without_stage_events", "extrema", "vs_1gpu_same_grid", "multi_gpu"):
+        if k in result:
+            out[k] = result[k]
+    if "value_repeats" in result:
+        out["value_repeats"] = {k: result["value_repeats"][k] for k in ("min", "median", "max")}
+    if "pipeline" in result:
+        out["pipeline_frac_of_hbm_peak"] = result["pipeline"]["frac_of_hbm_peak"]
+    b = result.get("bits_entry")
+    if b:
+        out["bits_entry"] = {k: b[k] for k in ("ms_per_step", "Mvoxels_per_s", "frac_of_hbm_peak", "bit_identical_to_the_mask_build", "error") if k in b}
+    legs = {}
+    for name, leg in (result.get("legs") or {}).items():
+        if not isinstance(leg, dict):
+            legs[name] = str(leg)[:80]
+            continue
+        ent = {"ms": leg.get("ms_per_step", leg.get("ms_per_frame"))}
+        if "frames_per_s" in leg:
+            ent["hz"] = leg["frames_per_s"]
+        lr = leg.get("roofline")
+        if lr:
+            ent["kernel"], ent["frac"] = lr["stage"], lr["frac"]
+        if "error" in leg:
+            ent = {"error": leg["error"][:80]}
+        legs[name] = ent
+    if legs:
+        out["legs"] = legs
+    p = result.get("parity", {}).get("cases")
+    if p:
+        out["parity"] = {k: [v["differ_from_reference_gt_tol"], v["of_which_reference_overestimates"], v["gpu_bit_equal_to_exact_edt"]]
+                         for k, v in p.items()}
+        out["parity_key"] = "[voxels differing from the reference algorithm by > 1e-5, of which reference over-estimates, GPU bit-equal to the exact EDT]"
+    h = result.get("host_api")
+    if h:
+        out["host_api_ms"] = {"sdfgpu_build": h.get("ms"), "to_device": (h.get("device_resident") or {}).get("build_ms"),
+                              "class_seam_cpp": (h.get("class_seam") or {}).get("cpp_ms"), "class_seam_pybind": (h.get("class_seam") or {}).get("pybind_ms")}
+    out["full_detail"] = "the line above (BENCH_FULL ...) and gpurun_out/bench_full.json"
+    return out
+
+
+def emit(result):
+    full = json.dumps(result)
+    print("BENCH_FULL " + full, flush=True)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_full.json"), "w") as f:
+            f.write(full + "\n")
+    except Exception:
+        pass
+    print(json.dumps(summary_line(result)), flush=True)
+
+
 def main():
     args = parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL between processes here
@@ -589,6 +657,34 @@ def main():
                                    "note": "five more runs of the same timed loop (events off), Mvoxels/s"}
         mx, mn = ctx.get_extrema()
         result["extrema"] = [mx, mn]
+        # the same K steps through the BITS entry point (VERDICT r5 "next round" 4): the caller holds one bit per voxel, the
+        # dense tier reads it in place, no pack kernel runs.  Reported beside `value`, never instead of it (BASELINE.json's
+        # workload is a uint8 occupancy grid).
+        if nz % 32 == 0:
+            try:
+                bits = [torch.empty(n_total // 32, dtype=torch.int32, device=dev) for _ in range(n_masks)]
+                for m_, b_ in zip(masks, bits):
+                    ctx.pack_bits_device(m_.data_ptr(), nx * ny, nz, b_.data_ptr(), stream.cuda_stream)
+                out_b = torch.empty(shape, dtype=torch.float32, device=dev)
+
+                def step_bits(i):
+                    ctx.build_bits_device(bits[i % n_masks].data_ptr(), shape, out_b.data_ptr(), res, False, stream.cuda_stream)
+
+                for i in range(max(args.warmup, 3)):
+                    step_bits(i)
+                    torch.cuda.synchronize(dev)
+                same = bool(torch.equal(out_b.view(torch.int32), out.view(torch.int32))) if (max(args.warmup, 3) - 1) % n_masks == (args.steps - 1) % n_masks else None
+                tb = sorted(timed_loop(step_bits, args.steps, fence) for _ in range(3))
+                result["bits_entry"] = {"call": "sdfgpu_build_bits_device: 1 bit per voxel in (device), fp32 SDF + extrema out",
+                                        "ms_per_step": round(tb[1] / args.steps * 1e3, 4),
+                                        "Mvoxels_per_s": round(n_total / (tb[1] / args.steps) / 1e6, 2),
+                                        "Mvoxels_per_s_min_max": [round(n_total / (tb[2] / args.steps) / 1e6, 2), round(n_total / (tb[0] / args.steps) / 1e6, 2)],
+                                        "compulsory_bytes_per_voxel": 4.125,
+                                        "frac_of_hbm_peak": round(n_total * 4.125 / (tb[1] / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "bit_identical_to_the_mask_build": same, "kernels": ctx.last_build_info()}
+                del bits, out_b
+            except Exception as e:
+                result["bits_entry"] = {"error": repr(e)}
         if builds:
             info, avg, stage_ms = stage_table(ctx, ms_sum, builds, n_total)
             result["config"]["kernels"] = info
@@ -784,7 +880,7 @@ def main():
             result["host_api"]["class_seam"] = {"error": repr(e)}
         result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.p, res)
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if world > 1:
         dist.destroy_process_group()
 

@@ -137,6 +137,23 @@ int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells,
 
 int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min);
 
+/* Bits in (round 6): the occupancy as ONE BIT per voxel in linear voxel order -- bit (v & 31) of 32-bit word (v >> 5) is set
+ * iff voxel v = x*ny*nz + y*nz + z is filled; ceil(nx*ny*nz / 32) words, bits beyond the last voxel ignored.  This is what the
+ * predicate loop of sdf_generation.hpp:219-240 produces when a caller keeps its occupancy packed (an octree leaf mask, a
+ * voxel hash), what the host-buffer entry points above upload after classifying on the host, and what
+ * sdfgpu_voxelize_points_bits_device writes.  The dense tier reads the field in place (where nz = 32 * 2^k the linear field IS
+ * its [x][y][nz/32] bit field: no pack kernel runs; 16-byte alignment avoids one device copy), the z sweep and the generic dense
+ * kernels read it through bit loaders: no byte mask exists anywhere.  Same results, extrema and errors as sdfgpu_build_device /
+ * sdfgpu_build.  d_bits / bits must be 4-byte aligned. */
+int sdfgpu_build_bits_device(sdfgpu_handle h, const uint32_t* d_bits,
+                             int64_t nx, int64_t ny, int64_t nz,
+                             double resolution, int add_virtual_border,
+                             float* d_out_sdf, void* stream);
+int sdfgpu_build_bits(sdfgpu_handle h, const uint32_t* bits,
+                      int64_t nx, int64_t ny, int64_t nz,
+                      double resolution, int add_virtual_border,
+                      float* out_sdf, double* out_max, double* out_min);
+
 /* Pageable host memory <-> device memory at the rate of the link.  These are the copies the host-buffer entry points
  * above use; wrappers that keep their own device buffers (the multi-GPU library, a caller filling a std::vector such
  * as the reference's GetImmutableRawData() storage, sdf.hpp / voxel_grid.hpp:760) can use them too.
@@ -337,6 +354,13 @@ int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_
                                   const double* origin, double resolution,
                                   int64_t nx, int64_t ny, int64_t nz,
                                   uint8_t* d_mask, int clear_first, void* stream);
+
+/* The same scatter into the bit field of sdfgpu_build_bits_device (one atomic OR per point; clear_first zeroes
+ * ceil(nx*ny*nz / 32) words): a streaming frame goes point cloud -> bits -> SDF without a byte mask in between. */
+int sdfgpu_voxelize_points_bits_device(sdfgpu_handle h, const float* d_points, int64_t n_points,
+                                       const double* origin, double resolution,
+                                       int64_t nx, int64_t ny, int64_t nz,
+                                       uint32_t* d_bits, int clear_first, void* stream);
 
 /* Debug / test hooks: copy the intermediates of the most recent
  * sdfgpu_build*_device call to host buffers (N int16 / N int32). */

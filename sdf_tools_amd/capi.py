@@ -26,6 +26,7 @@ EXPORTS = [
     "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
     "sdfgpu_copy_to_host", "sdfgpu_copy_from_host", "sdfgpu_query_points", "sdfgpu_device_malloc", "sdfgpu_device_free",
     "sdfgpu_build_to_device", "sdfgpu_build_cells_to_device", "sdfgpu_upload_classified",
+    "sdfgpu_build_bits_device", "sdfgpu_build_bits", "sdfgpu_voxelize_points_bits_device",
 ]
 
 
@@ -77,6 +78,9 @@ def load_library():
     L.sdfgpu_build_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_build_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, i64, i64, dbl, ci, vp, vp]
     L.sdfgpu_get_extrema.argtypes = [vp, vp, vp]
+    L.sdfgpu_build_bits_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp]
+    L.sdfgpu_build_bits.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, vp, vp]
+    L.sdfgpu_voxelize_points_bits_device.argtypes = [vp, vp, i64, vp, dbl, i64, i64, i64, vp, ci, vp]
     L.sdfgpu_sweep_zy_device.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     L.sdfgpu_classify_cells_device.argtypes = [vp, vp, sz, sz, ci, i64, vp, vp]
     L.sdfgpu_sweep_zy_tiered_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
@@ -105,6 +109,15 @@ def load_library():
             fn.restype = ci
     _lib = L
     return L
+
+
+def pack_bits_host(filled):
+    """uint8 / bool occupancy (any shape) -> the linear bit field of sdfgpu_build_bits*: uint32[ceil(n / 32)], bit (v & 31) of
+    word (v >> 5) = voxel v in C order."""
+    m = np.ascontiguousarray(filled).reshape(-1) != 0
+    b = np.packbits(m, bitorder="little")
+    b = np.concatenate([b, np.zeros((-b.size) % 4, np.uint8)])
+    return b.view("<u4").astype(np.uint32, copy=False)
 
 
 def device_count():
@@ -251,6 +264,31 @@ class SdfGpu:
         nx, ny, nz = (int(s) for s in shape)
         self._check(self._lib.sdfgpu_build_device(self._h, d_filled, nx, ny, nz, float(resolution),
                                                   int(bool(add_virtual_border)), d_out, stream or None))
+
+    def build_bits_device(self, d_bits, shape, d_out, resolution=1.0, add_virtual_border=False, stream=0):
+        """d_bits: device pointer of the linear bit field (bit v & 31 of word v >> 5 = voxel v), ceil(n / 32) uint32 words."""
+        nx, ny, nz = (int(s) for s in shape)
+        self._check(self._lib.sdfgpu_build_bits_device(self._h, d_bits, nx, ny, nz, float(resolution),
+                                                       int(bool(add_virtual_border)), d_out, stream or None))
+
+    def build_bits(self, bits, shape, resolution=1.0, add_virtual_border=False):
+        """bits: host uint32 array of ceil(n / 32) words (see pack_bits_host).  Returns (sdf float32 [nx,ny,nz], (max, min))."""
+        nx, ny, nz = (int(s) for s in shape)
+        b = np.ascontiguousarray(bits, dtype=np.uint32)
+        if b.size != (nx * ny * nz + 31) // 32:
+            raise ValueError("bit field must hold ceil(nx*ny*nz / 32) words")
+        out = np.empty((nx, ny, nz), dtype=np.float32)
+        ext = (ctypes.c_double * 2)()
+        self._check(self._lib.sdfgpu_build_bits(self._h, b.ctypes.data, nx, ny, nz, float(resolution),
+                                                int(bool(add_virtual_border)), out.ctypes.data,
+                                                ctypes.byref(ext, 0), ctypes.byref(ext, 8)))
+        return out, (float(ext[0]), float(ext[1]))
+
+    def voxelize_points_bits_device(self, d_points, n_points, origin, resolution, shape, d_bits, clear_first=True, stream=0):
+        nx, ny, nz = (int(s) for s in shape)
+        o = (ctypes.c_double * 3)(*[float(v) for v in origin])
+        self._check(self._lib.sdfgpu_voxelize_points_bits_device(self._h, d_points, int(n_points), o, float(resolution),
+                                                                 nx, ny, nz, d_bits, int(bool(clear_first)), stream or None))
 
     def build_cells_device(self, d_cells, shape, d_out, cell_stride=8, occupancy_offset=0,
                            unknown_is_filled=False, resolution=1.0, add_virtual_border=False, stream=0):

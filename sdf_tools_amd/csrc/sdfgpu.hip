@@ -105,6 +105,7 @@ struct sdfgpu_context {
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool shell_on = true;            // KD6, the bit-parallel shell pass between KD3 and KF (option "dense_shell")
     bool dc_fixed = true;            // far-field kernel: the 512-voxel-line instances (option "dc_fixed")
+    bool fast_finish = true;         // far-field x sweep: fp32 finish with an fp64 fallback per wave round (option "fast_finish"; sdfgpu_finish.hpp)
     bool dense3_fixed = true;        // KD3's nz = 512 instance (option "dense3_fixed")
     int shell_min_words = kShellMinWords;   // option "shell_min_words"
     int shell_budget_den = 8;        // ... for scenes with at most 1 / 8 of their voxels undecided behind KD3 (option "shell_budget_den"): Bernoulli
@@ -218,8 +219,34 @@ int rows_per_block(int nz) {
 
 // K1 launch.  cells == nullptr -> uint8 mask.
 int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, size_t stride, size_t off,
-                   int unknown, int64_t nx, int64_t ny, int64_t nz, int16_t* d_out, hipStream_t s) {
+                   int unknown, int64_t nx, int64_t ny, int64_t nz, int16_t* d_out, hipStream_t s, const uint32_t* d_bits = nullptr) {
     const int64_t nrows = nx * ny;
+    if (d_bits) {
+        // bits in (round 6): the wave-private form reads its 16 voxels as one 16-bit piece of the bit field; every other shape
+        // goes through the generic kernel with a bit loader
+        if (h->z_wave_on && (nz == 64 || nz == 128 || nz == 256 || nz == 512 || nz == 1024)) {
+            const int rw = 1024 / (int)nz;
+            const int64_t ngroups = (nrows + rw - 1) / rw;
+            dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), 8192)), block(kBlock);
+            const uint8_t* b8 = reinterpret_cast<const uint8_t*>(d_bits);
+            switch ((int)nz) {
+                case 64: hipLaunchKernelGGL((k_sweep_z_wave16<4, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
+                case 128: hipLaunchKernelGGL((k_sweep_z_wave16<8, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
+                case 256: hipLaunchKernelGGL((k_sweep_z_wave16<16, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
+                case 512: hipLaunchKernelGGL((k_sweep_z_wave16<32, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
+                default: hipLaunchKernelGGL((k_sweep_z_wave16<64, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
+            }
+        } else {
+            const int rpb = rows_per_block((int)nz);
+            const int W = ((int)nz + 63) / 64;
+            const size_t lds = (size_t)rpb * W * 8 + (size_t)rpb * 4;
+            const int64_t nblocks = (nrows + rpb - 1) / rpb;
+            BitsLoader ld{d_bits};
+            hipLaunchKernelGGL(k_sweep_z_generic<BitsLoader>, dim3((unsigned)std::min<int64_t>(nblocks, 2048)), dim3(kBlock), lds, s, ld, d_out, nrows, (int)nz, rpb, h->guard);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return SDFGPU_OK;
+    }
     const int rpb = rows_per_block((int)nz);
     const int W = ((int)nz + 63) / 64;
     const size_t lds = (size_t)rpb * W * 8 + (size_t)rpb * 4;     // bitmap + one class word per row (vec16 kernel)
@@ -499,6 +526,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         else { a.group_lines = ny * nz; a.tiles_per_outer = (ny * nz + NL - 1) / NL; ntiles = a.tiles_per_outer; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
         a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = 0; a.h = (a.L + 1) / 2;
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
+        a.fin = make_finish_fast(resolution, g.finf, h->fast_finish);       // (finf > every finite squared distance of this grid)
         a.y_off = 0; a.ny_glob = ny;
         if (ex) {
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
@@ -808,12 +836,15 @@ int launch_ball_dense(sdfgpu_handle h, const uint32_t* d_bits, float* d_out, int
 // Generic dense tier (any nz, virtual border): k_pack_bits_rows + k_ball_dense_generic
 int launch_dense_generic(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, size_t stride, size_t off, int unknown,
                          int64_t nx, int64_t ny, int64_t nz, double resolution, int vb, float* d_out, uint32_t* d_uncert,
-                         hipStream_t s) {
+                         hipStream_t s, const uint32_t* d_bits_in = nullptr) {
     const int64_t nzw = (nz + 31) / 32, nrows = nx * ny, nwords = nrows * nzw;
     if (nwords > 0x7fffffffLL * (int64_t)kBlock) return fail(h, SDFGPU_ERR_UNSUPPORTED_SIZE, "dense grid too large");
     if (int rc = ensure(h, h->bits, (size_t)nwords * 4)) return rc;
     const dim3 grid((unsigned)((nwords + kBlock - 1) / kBlock)), block(kBlock);
-    if (d_cells) {
+    if (d_bits_in) {                                            // (linear bits -> rows padded to whole words)
+        BitsLoader ld{d_bits_in};
+        hipLaunchKernelGGL(k_pack_bits_rows<BitsLoader>, grid, block, 0, s, ld, (uint32_t*)h->bits.ptr, nrows, (int)nz, (int)nzw);
+    } else if (d_cells) {
         CellLoader ld{reinterpret_cast<const char*>(d_cells), (int64_t)stride, (int64_t)off, unknown};
         hipLaunchKernelGGL(k_pack_bits_rows<CellLoader>, grid, block, 0, s, ld, (uint32_t*)h->bits.ptr, nrows, (int)nz, (int)nzw);
     } else {
@@ -833,11 +864,14 @@ int launch_dense_generic(sdfgpu_handle h, const uint8_t* d_mask, const void* d_c
     return SDFGPU_OK;
 }
 
+// d_bits_in != nullptr (round 6): the occupancy arrives as one bit per voxel, linear order (sdfgpu_build_bits*): the tuned dense
+// kernels read it in place (no K0), the z sweep and the generic dense tier read it through their bit loaders -- no byte mask exists.
 int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_cells, size_t stride, size_t off,
                       int unknown, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb,
-                      float* d_out, hipStream_t s) {
+                      float* d_out, hipStream_t s, const uint32_t* d_bits_in = nullptr) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
-    if ((!d_filled && !d_cells) || !d_out) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if ((!d_filled && !d_cells && !d_bits_in) || !d_out) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (d_bits_in && (reinterpret_cast<uintptr_t>(d_bits_in) % 4) != 0) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "the bit field must be 4-byte aligned");
     if (int rc = check_dims(h, nx, ny, nz)) return rc;
     if (d_cells && (stride < 4 || (stride % 4) || (off % 4) || off + 4 > stride))
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
@@ -939,18 +973,28 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // Dense path first: exact wherever the nearest opposite voxel is within d^2 <= 8; raises
     // d_small[3] otherwise, in which case (and only then) the general pipeline below does any work.
     bool cur_fix_mode = false, cur_dense3 = false, cur_staged = false;
+    const uint32_t* dense_bits = nullptr;                       // the bit field the tuned dense kernels (and the stand-by y sweep) read
     h->last_dense = dense;
     h->guard = nullptr;
     if (dense && dense_generic) {
         HIP_TRY(h, mark(1));
         if (int rc = launch_dense_generic(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz, resolution, vb, d_out,
-                                          h->d_small + 3, s)) return rc;
+                                          h->d_small + 3, s, d_bits_in)) return rc;
         launched_since_mark = true;
         h->guard = h->d_small + 3;
     } else if (dense) {
-        if (int rc = ensure(h, h->bits, (size_t)n / 8)) return rc;
-        if (int rc = launch_pack_bits(h, d_filled, d_cells, stride, off, unknown, n, (uint32_t*)h->bits.ptr, s)) return rc;
-        launched_since_mark = true;
+        if (d_bits_in && (reinterpret_cast<uintptr_t>(d_bits_in) % 16) == 0) {
+            dense_bits = d_bits_in;                             // (nz % 32 == 0: the caller's linear bit field IS the [x][y][nz / 32] field K0 writes)
+        } else if (d_bits_in) {                                 // (the dense kernels stage bit rows with 16-byte loads)
+            if (int rc = ensure(h, h->bits, (size_t)n / 8)) return rc;
+            HIP_TRY(h, hipMemcpyAsync(h->bits.ptr, d_bits_in, (size_t)n / 8, hipMemcpyDeviceToDevice, s));
+            dense_bits = (const uint32_t*)h->bits.ptr;
+        } else {
+            if (int rc = ensure(h, h->bits, (size_t)n / 8)) return rc;
+            if (int rc = launch_pack_bits(h, d_filled, d_cells, stride, off, unknown, n, (uint32_t*)h->bits.ptr, s)) return rc;
+            launched_since_mark = true;
+            dense_bits = (const uint32_t*)h->bits.ptr;
+        }
         HIP_TRY(h, mark(1));
         // fix-up mode (policy): undecided voxels go to the fix-up kernel, which raises `uncertified` only for what it
         // cannot decide either; otherwise the ball kernel raises it directly and nothing extra is launched
@@ -959,13 +1003,13 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         const bool fix = plan.fix;
         cur_dense3 = plan.dense3;
         cur_staged = plan.staged;
-        if (int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
+        if (int rc = launch_ball_dense(h, dense_bits, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
                                        cur_staged ? h->d_small + 20 : h->d_small + 3, s,
                                        (fix || cur_dense3) ? h->d_small + 6 : nullptr, true, vb, nx, cur_dense3 ? 3 : 2)) return rc;
         if (cur_staged) {
             h->unc_override = (!fused && h->zfield.ptr && h->zfield.bytes >= (size_t)n / 8) ? (uint32_t*)h->zfield.ptr : nullptr;
             h->unc_override_bytes = h->unc_override ? h->zfield.bytes : 0;
-            const int rc = launch_ball_dense(h, (const uint32_t*)h->bits.ptr, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
+            const int rc = launch_ball_dense(h, dense_bits, d_out, nx, 0, nx, ny, nz, resolution, h->d_small,
                                              h->d_small + 3, s, h->d_small + 6, true, 0, nx, 3, h->d_small + 20);
             h->unc_override = nullptr;
             if (rc) return rc;
@@ -987,7 +1031,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     h->scan_y = h->scan_x = kScanExpectNear;
     if (!fused && !standby) {                                   // (the stand-by pair takes its z distances from the bit field)
         if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
-                                    (int16_t*)h->zfield.ptr, s)) return rc;
+                                    (int16_t*)h->zfield.ptr, s, d_bits_in)) return rc;
         launched_since_mark = true;
     }
     HIP_TRY(h, mark(3));
@@ -1010,7 +1054,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     auto decide = [&](int stage) -> int { return launch_decide(h, stage, dense, s, handoff, window_choice); };   // probe counters -> guard words
     DcExtra sb2{}, sb3{};                                       // stand-by pair: int32 hand-off unconditionally, LOOP form, self-reporting
     sb2.out_i32 = (int32_t*)h->yzfield.ptr; sb2.loop = true; sb2.ran_flag = h->d_small + 4;
-    sb2.bits = (const uint32_t*)h->bits.ptr; sb2.nzw = (int)((nz + 31) / 32);
+    sb2.bits = dense_bits ? dense_bits : (const uint32_t*)h->bits.ptr; sb2.nzw = (int)((nz + 31) / 32);
     sb3.in_i32 = (const int32_t*)h->yzfield.ptr; sb3.loop = true; sb3.ran_flag = h->d_small + 5;
     // (moved up: the stand-by x sweep does the fold itself and needs to know where the report goes)
     const bool report = h->envelope_on && h->h_flags_dev && !h->flags_pending && dense;
@@ -1340,6 +1384,7 @@ int upload_packed(sdfgpu_handle h, const uint8_t* filled, const void* cells, siz
         HIP_TRY(h, hipMemcpyAsync(h->stage_bits.ptr, tmp.data(), padded, hipMemcpyHostToDevice, st));
         HIP_TRY(h, hipStreamSynchronize(st));                   // (tmp goes out of scope)
     }
+    if (!d_mask_dst) return SDFGPU_OK;                          // (the host-buffer builds: the bits are the build's input)
     const int64_t nch = (n + 15) / 16;
     hipLaunchKernelGGL(k_unpack_bits_mask, dim3((unsigned)((nch + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        (const uint32_t*)h->stage_bits.ptr, d_mask_dst, n);
@@ -1347,12 +1392,20 @@ int upload_packed(sdfgpu_handle h, const uint8_t* filled, const void* cells, siz
     return SDFGPU_OK;
 }
 
+// the caller's host bit field (ceil(n / 32) words) -> h->stage_bits
+int upload_bits(sdfgpu_handle h, const uint32_t* bits, int64_t n, hipStream_t st) {
+    const size_t bytes = (((size_t)n + 31) / 32) * 4;
+    if (int rc = ensure(h, h->stage_bits, bytes)) return rc;
+    return copy_from_host(h, h->stage_bits.ptr, bits, bytes, st);
+}
+
 // d_out_user != nullptr: the field stays on the device in the caller's buffer (no download; out_sdf is unused)
+// bits_in != nullptr: the caller's occupancy is already one bit per voxel (sdfgpu_build_bits)
 int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t stride, size_t off,
                     int unknown, int64_t nx, int64_t ny, int64_t nz, double resolution, int vb, float* out_sdf,
-                    double* out_max, double* out_min, float* d_out_user = nullptr) {
+                    double* out_max, double* out_min, float* d_out_user = nullptr, const uint32_t* bits_in = nullptr) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
-    if ((!filled && !cells) || (!out_sdf && !d_out_user)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
+    if ((!filled && !cells && !bits_in) || (!out_sdf && !d_out_user)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
     if (int rc = check_dims(h, nx, ny, nz)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t n = nx * ny * nz;
@@ -1362,23 +1415,20 @@ int build_host_impl(sdfgpu_handle h, const uint8_t* filled, const void* cells, s
     // chunk, and 1/8 B per voxel crosses PCIe (16 MiB at 512^3 instead of 128 MiB of mask or 1 GiB of COLLISION_CELL records);
     // k_unpack_bits_mask spreads them into the byte mask on the device.  Same predicate as the device classifier
     // (pack_cells_bits); "host_pack" = 0 keeps the upload-and-classify-on-device path (device-resident cells always take it).
-    const bool packed = h->host_pack == 2 || (h->host_pack == 1 && in_bytes >= kPinMin);
-    if (!packed) if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
+    const bool packed = !bits_in && (h->host_pack == 2 || (h->host_pack == 1 && in_bytes >= kPinMin));
+    if (!packed && !bits_in) if (int rc = ensure(h, h->stage_in, in_bytes)) return rc;
     if (!d_out_user) if (int rc = ensure(h, h->stage_out, (size_t)n * 4)) return rc;
     float* const d_out = d_out_user ? d_out_user : (float*)h->stage_out.ptr;
     const bool timing = getenv("SDFGPU_HOST_TIMING") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t1 = now();
     // (out_sdf is scratch from here on: include/sdfgpu.h documents that its contents are undefined when the call fails)
-    const uint8_t* d_mask = nullptr;
-    if (packed) {
-        if (int rc0 = ensure(h, h->stage_in, (size_t)n)) return rc0;
-        if (int rc0 = upload_packed(h, filled, cells, stride, off, unknown, n, (uint8_t*)h->stage_in.ptr, nullptr)) return rc0;
-        d_mask = (const uint8_t*)h->stage_in.ptr;
-    }
+    // (round 6: the uploaded bits ARE the build's input -- no byte mask is spread out on the device and packed again by K0)
+    if (packed) { if (int rc0 = upload_packed(h, filled, cells, stride, off, unknown, n, nullptr, nullptr)) return rc0; }
+    else if (bits_in) { if (int rc0 = upload_bits(h, bits_in, n, nullptr)) return rc0; }
     else if (int rc0 = copy_from_host(h, h->stage_in.ptr, cells ? cells : (const void*)filled, in_bytes)) return rc0;
     const double t2 = now();
-    int rc = packed ? build_device_impl(h, d_mask, nullptr, 0, 0, 0, nx, ny, nz, resolution, vb, d_out, nullptr)
+    int rc = (packed || bits_in) ? build_device_impl(h, nullptr, nullptr, 0, 0, 0, nx, ny, nz, resolution, vb, d_out, nullptr, (const uint32_t*)h->stage_bits.ptr)
                     : build_device_impl(h, cells ? nullptr : (const uint8_t*)h->stage_in.ptr,
                                         cells ? h->stage_in.ptr : nullptr, stride, off, unknown, nx, ny, nz, resolution,
                                         vb, d_out, nullptr);
@@ -1521,6 +1571,20 @@ int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_
     if (h && !d_cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_cells is null");
     return build_device_impl(h, nullptr, d_cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz,
                              resolution, add_virtual_border, d_out_sdf, (hipStream_t)stream);
+}
+
+int sdfgpu_build_bits_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t nx, int64_t ny, int64_t nz,
+                             double resolution, int add_virtual_border, float* d_out_sdf, void* stream) {
+    if (h && !d_bits) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_bits is null");
+    return build_device_impl(h, nullptr, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, d_out_sdf,
+                             (hipStream_t)stream, d_bits);
+}
+
+int sdfgpu_build_bits(sdfgpu_handle h, const uint32_t* bits, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                      int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    if (h && !bits) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bits is null");
+    return build_host_impl(h, nullptr, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, out_sdf, out_max, out_min,
+                           nullptr, bits);
 }
 
 int sdfgpu_copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, void* stream) {
@@ -1866,6 +1930,24 @@ int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_
     return SDFGPU_OK;
 }
 
+int sdfgpu_voxelize_points_bits_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
+                                       double resolution, int64_t nx, int64_t ny, int64_t nz, uint32_t* d_bits, int clear_first,
+                                       void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    if (!d_bits || !origin || (n_points > 0 && !d_points) || n_points < 0 || !(resolution > 0.0))
+        return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad voxelize arguments");
+    if (int rc = check_dims(h, nx, ny, nz)) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (clear_first) HIP_TRY(h, hipMemsetAsync(d_bits, 0, (((size_t)(nx * ny * nz) + 31) / 32) * 4, s));
+    if (n_points > 0) {
+        hipLaunchKernelGGL(k_voxelize_points_bits, dim3((unsigned)((n_points + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, d_points,
+                           n_points, origin[0], origin[1], origin[2], resolution, nx, ny, nz, d_bits);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return SDFGPU_OK;
+}
+
 int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz,
                            double resolution, int enable_edge_gradients, void* d_out_grad, int out_is_f64,
                            void* stream) {
@@ -2117,6 +2199,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
     else if (n == "dense_shell") h->shell_on = value != 0;
     else if (n == "dc_fixed") h->dc_fixed = value != 0;
+    else if (n == "fast_finish") h->fast_finish = value != 0;
     else if (n == "dense3_fixed") h->dense3_fixed = value != 0;
     else if (n == "shell_min_words") h->shell_min_words = value >= 0 ? value : kShellMinWords;
     else if (n == "shell_budget_den") h->shell_budget_den = value >= 1 ? value : 8;

@@ -51,6 +51,7 @@
 #pragma once
 #include "sdfgpu_kernels.hpp"
 #include "sdfgpu_sweep_x16.hpp"
+#include "sdfgpu_finish.hpp"
 
 namespace sdfgpu {
 
@@ -120,6 +121,7 @@ struct EnvDcArgs {
     uint32_t* fold_report;
     uint32_t* fold_ticket;
     uint32_t fold_report_mask;
+    FinishFast fin;           // STAGE 3: the fp32 form of the finish (sdfgpu_finish.hpp); fin.ok = 0: fp64 for every voxel
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -1009,12 +1011,19 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         mx = imax(mx, D[k]);
+                        // the finish: fp32 with a per-lane "too close to a rounding boundary" flag (sdfgpu_finish.hpp); a wave in
+                        // which a lane raises it -- one voxel in ~11 000 -- runs the reference's fp64 sequence for that round
+                        bool slow;
+                        float f = finish_fast(D[k], a.fin, slow);                                       // (D = 0: not stored)
+                        slow = (slow || !a.fin.ok) && D[k] != 0 && D[k] < kInf32;
 #ifdef SDFGPU_DEBUG_HOOKS
-                        float f = (a.dbg & 2) ? (float)D[k] : (float)(sqrt_exact_pos((double)D[k]) * a.resolution);
+                        if (a.dbg & 2) { f = (float)D[k]; slow = false; }
                         if ((a.dbg & 4) && (k || slotT)) { bo += 4u * ls; continue; }
-#else
-                        float f = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);                 // (D = 0: not stored)
 #endif
+                        if (__ballot(slow) != 0ull) {                                                   // (wave-uniform)
+                            const float g = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);
+                            f = slow ? g : f;
+                        }
                         f = D[k] >= kInf32 ? __builtin_inff() : f;
                         if (D[k] != 0) *reinterpret_cast<float*>(op + bo) = cls == 1 ? -f : f;
                         bo += 4u * ls;

@@ -1,0 +1,57 @@
+// sdfgpu_finish.hpp -- the reference's finishing arithmetic float(sqrt((double)D) * resolution) (sdf_generation.hpp:254-265; D = the
+// integer squared distance) WITHOUT fp64 on the fast path (round 6, VERDICT r5 "next round" 1c).
+//
+// The fp64 sequence is 12 of the ~29 instructions the far-field x sweep spends on a voxel outside its search, at half rate (the
+// rsq seed slower still).  finish_fast computes the same float in fp32:
+//     s = v_sqrt_f32(D), e = (D - s^2) / 2s            sqrt(D) = s + e up to 2^-47 relative (one Newton residual; s, 1/s: 1 ulp each)
+//     p = s * rh, pe = fma(s, rh, -p)                  resolution = rh + rl (two floats: 2^-49 relative), p + pe = s * rh exactly
+//     c = pe + s * rl + e * rh                         T = sqrt(D) * resolution = p + c up to 2^-20 ulp(p)
+//     y = RN(p + (c - thr)), yh = RN(p + (c + thr))    thr = p * 2^-38 = 2^-15 .. 2^-14 ulp(p)
+// Rounding is monotone: when y == yh every value between the two sums rounds to y -- T does, and so does the reference's
+// double-rounded T (which differs from T by 2^-52 relative) -- across binade boundaries too.  When they differ (a share of
+// ~9e-5 of all D, no small D among them for the usual resolutions) the lane raises `slow` and takes the fp64 sequence; the
+// callers branch on a wave-wide ballot, so a wave pays for it once in ~200 voxel rounds.
+// Exactness: tools/probe/finish_fast_check.c restates this with correctly rounded host arithmetic and perturbs the two
+// approximate instructions by -1 / 0 / +1 ulp: every D <= 3 * 1024^2 x 15 resolutions x 9 perturbations either raises `slow` or
+// returns the reference's float; on the device tests/test_gpu_finish.py compares the kernel's own table of every D.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cmath>
+
+namespace sdfgpu {
+
+struct FinishFast {
+    float rh, rl, hrh;      // resolution = rh + rl, hrh = rh / 2
+    int ok;                 // 0: every lane takes the fp64 sequence (resolution outside the safe range, squared distances beyond 2^24, option off)
+};
+
+// host: max_d = an upper bound of the finite squared distances of this build (beyond it only the "infinite" sentinel occurs)
+inline FinishFast make_finish_fast(double resolution, uint64_t max_d, bool enabled = true) {
+    FinishFast k{0.0f, 0.0f, 0.0f, 0};
+    // s * rh, the residuals and thr must stay normal floats: sqrt(D) in [1, 2^12], so 2^-60 <= resolution <= 2^60 is ample
+    if (!enabled || !(resolution >= 0x1p-60) || !(resolution <= 0x1p60) || max_d >= (1ull << 24)) return k;
+    k.rh = (float)resolution;
+    k.rl = (float)(resolution - (double)k.rh);
+    k.hrh = 0.5f * k.rh;
+    k.ok = 1;
+    return k;
+}
+
+// D >= 1 and exactly representable as a float (the caller masks D = 0 and the sentinel out of `slow`)
+__device__ __forceinline__ float finish_fast(int D, const FinishFast& k, bool& slow) {
+    const float x = (float)D;
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float r = __builtin_fmaf(-s, s, x);
+    const float t1 = r * __builtin_amdgcn_rcpf(s);
+    const float p = s * k.rh;
+    const float pe = __builtin_fmaf(s, k.rh, -p);
+    float c = __builtin_fmaf(s, k.rl, pe);
+    c = __builtin_fmaf(t1, k.hrh, c);
+    const float thr = p * 0x1p-38f;
+    const float y = p + (c - thr), yh = p + (c + thr);
+    slow = __builtin_bit_cast(uint32_t, y) != __builtin_bit_cast(uint32_t, yh);
+    return y;
+}
+
+}  // namespace sdfgpu

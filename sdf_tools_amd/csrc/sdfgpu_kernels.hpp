@@ -167,6 +167,13 @@ struct CellLoader {
     }
 };
 
+// one bit per voxel, linear order: bit (v & 31) of word (v >> 5) = voxel v (the layout K0 writes for nz % 32 == 0; the input of
+// the bits-in entry points, sdfgpu_build_bits*)
+struct BitsLoader {
+    const uint32_t* p;
+    __device__ __forceinline__ bool filled(int64_t idx) const { return (p[idx >> 5] >> (idx & 31)) & 1u; }
+};
+
 // 4 mask bytes -> 4 bits (byte k nonzero -> bit k)
 __device__ __forceinline__ uint32_t nonzero_bits4(uint32_t w) {
     const uint32_t m = (w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
@@ -360,7 +367,9 @@ __device__ __forceinline__ uint32_t pk_neg_i16(uint32_t a) {
 // waves of the workgroup -- no workgroup barrier between "pack" and "search", so one wave's loads and stores run under
 // another wave's bit searches (the barrier form ran at memory time PLUS compute time: 0.115 ms at 512^3 for 0.07 ms of
 // traffic and 0.045 ms of VALU work).  The row classes come from two ballots instead of LDS atomics.
-template <int CPR>
+// BITS (round 6): `mask` is the linear bit field instead of the byte mask -- a lane's 16 voxels are one aligned 16-bit piece of
+// it (2 bytes read per lane instead of 16: the z sweep of a bits-in build reads 1/8 B per voxel).
+template <int CPR, bool BITS = false>
 __global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __restrict__ mask, int16_t* __restrict__ out,
                                                           int64_t nrows, const uint32_t* __restrict__ guard) {
     if (guard && *guard == 0u) return;
@@ -377,7 +386,11 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __rest
     const int64_t gstep = (int64_t)gridDim.x * (kBlock / 64);
     auto fetch = [&](int64_t g) -> uint4 {
         const int64_t rr = g * RW + r;
-        if (g < ngroups && rr < nrows) return *reinterpret_cast<const uint4*>(mask + rr * nz + 16 * c);
+        if constexpr (BITS) {
+            if (g < ngroups && rr < nrows) return make_uint4(reinterpret_cast<const uint16_t*>(mask)[rr * CPR + c], 0u, 0u, 0u);
+        } else {
+            if (g < ngroups && rr < nrows) return *reinterpret_cast<const uint4*>(mask + rr * nz + 16 * c);
+        }
         return make_uint4(0u, 0u, 0u, 0u);
     };
     int64_t g = (int64_t)blockIdx.x * (kBlock / 64) + wave;
@@ -387,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __rest
         vnext = fetch(g + gstep);
         const int64_t rr = g * RW + r;
         const bool valid = rr < nrows;
-        const uint32_t bits = nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) | (nonzero_bits4(v.w) << 12);
+        const uint32_t bits = BITS ? v.x : (nonzero_bits4(v.x) | (nonzero_bits4(v.y) << 4) | (nonzero_bits4(v.z) << 8) | (nonzero_bits4(v.w) << 12));
         const uint64_t bF = __ballot(bits != 0u), bE = __ballot(bits != 0xFFFFu);
         const uint64_t rmask = CPR == 64 ? ~0ull : (((1ull << (CPR & 63)) - 1ull) << (r * CPR));
         const bool anyF = (bF & rmask) != 0ull, anyE = (bE & rmask) != 0ull;
@@ -840,6 +853,23 @@ SDFGPU_KERNEL __launch_bounds__(kBlock) void k_voxelize_points(const float* __re
     if (!(fx > -1.0 && fy > -1.0 && fz > -1.0 && fx < (double)nx && fy < (double)ny && fz < (double)nz)) return;  // also NaN
     const int64_t ix = (int64_t)fx, iy = (int64_t)fy, iz = (int64_t)fz;      // truncation toward zero, like astype(int64)
     mask[(ix * ny + iy) * nz + iz] = 1;                                       // benign race: every writer stores 1
+}
+
+// The same scatter into the bit field the bits-in entry points take (round 6): one atomic OR per point, 1/8 B per voxel to clear
+// and nothing to pack afterwards -- a streaming frame goes point cloud -> bits -> SDF without a byte mask in between.
+SDFGPU_KERNEL __launch_bounds__(kBlock) void k_voxelize_points_bits(const float* __restrict__ pts, int64_t n_points,
+                                                                double ox, double oy, double oz, double res,
+                                                                int64_t nx, int64_t ny, int64_t nz,
+                                                                uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_points) return;
+    const double fx = ((double)pts[3 * i + 0] - ox) / res;
+    const double fy = ((double)pts[3 * i + 1] - oy) / res;
+    const double fz = ((double)pts[3 * i + 2] - oz) / res;
+    if (!(fx > -1.0 && fy > -1.0 && fz > -1.0 && fx < (double)nx && fy < (double)ny && fz < (double)nz)) return;  // also NaN
+    const int64_t ix = (int64_t)fx, iy = (int64_t)fy, iz = (int64_t)fz;      // truncation toward zero, like astype(int64)
+    const int64_t v = (ix * ny + iy) * nz + iz;
+    atomic_or_if_new(bits + (v >> 5), 1u << (v & 31));
 }
 
 // ---------------------------------------------------------------------------

@@ -21,7 +21,8 @@ from . import capi
 
 
 class StreamingSdf:
-    def __init__(self, shape, resolution, origin=(0.0, 0.0, 0.0), device_index=0, gradient="query", grad_f64=False):
+    def __init__(self, shape, resolution, origin=(0.0, 0.0, 0.0), device_index=0, gradient="query", grad_f64=False,
+                 occupancy="bits"):
         """gradient: "query" (default) -- frame(points, query_points) answers batched distance + gradient queries on
         the fresh field; "full" / True -- frame() also writes the grid-aligned gradient of every voxel; None / False --
         the field only."""
@@ -36,7 +37,12 @@ class StreamingSdf:
         self.origin = tuple(float(v) for v in origin)
         self.device = torch.device("cuda", device_index)
         self.ctx = capi.SdfGpu(device_index)
-        self.mask = torch.zeros(self.shape, dtype=torch.uint8, device=self.device)
+        # round 6: the occupancy of a frame is ONE BIT per voxel (sdfgpu_voxelize_points_bits_device -> sdfgpu_build_bits_device):
+        # 16 MiB to clear at 512^3 instead of 128 MiB, nothing to pack, the z sweep reads 1/8 B per voxel.  occupancy="mask"
+        # keeps the byte mask of rounds 1 - 5 (sdfgpu_voxelize_points_device -> sdfgpu_build_device).
+        n = self.shape[0] * self.shape[1] * self.shape[2]
+        self.bits = torch.zeros((n + 31) // 32, dtype=torch.int32, device=self.device) if occupancy == "bits" else None
+        self._mask = torch.zeros(self.shape, dtype=torch.uint8, device=self.device) if occupancy != "bits" else None
         self.sdf = torch.empty(self.shape, dtype=torch.float32, device=self.device)
         self.gradient = None
         self.grad_f64 = bool(grad_f64)
@@ -54,9 +60,14 @@ class StreamingSdf:
         None when no query points were given.  The query buffers are re-used by the next frame."""
         assert points.is_cuda and points.dtype == torch.float32 and points.is_contiguous() and points.shape[-1] == 3
         s = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx.voxelize_points_device(points.data_ptr(), points.shape[0], self.origin, self.resolution, self.shape,
-                                        self.mask.data_ptr(), True, s)
-        self.ctx.build_device(self.mask.data_ptr(), self.shape, self.sdf.data_ptr(), self.resolution, False, s)
+        if self.bits is not None:
+            self.ctx.voxelize_points_bits_device(points.data_ptr(), points.shape[0], self.origin, self.resolution, self.shape,
+                                                 self.bits.data_ptr(), True, s)
+            self.ctx.build_bits_device(self.bits.data_ptr(), self.shape, self.sdf.data_ptr(), self.resolution, False, s)
+        else:
+            self.ctx.voxelize_points_device(points.data_ptr(), points.shape[0], self.origin, self.resolution, self.shape,
+                                            self._mask.data_ptr(), True, s)
+            self.ctx.build_device(self._mask.data_ptr(), self.shape, self.sdf.data_ptr(), self.resolution, False, s)
         if self.gradient is not None:
             self.ctx.gradient_device(self.sdf.data_ptr(), self.shape, self.gradient.data_ptr(), self.resolution, True,
                                      self.grad_f64, s)
@@ -78,6 +89,16 @@ class StreamingSdf:
             out = tuple(t[:m] for t in self._q)
             return self.sdf, self.query(query_points, enable_edge_gradients, out)
         return self.sdf, self.gradient
+
+    @property
+    def mask(self):
+        """The current frame's occupancy as a uint8 [nx, ny, nz] tensor (unpacked from the bit field on demand: tests, debugging)."""
+        if self._mask is not None:
+            return self._mask
+        n = self.shape[0] * self.shape[1] * self.shape[2]
+        k = torch.arange(32, device=self.device, dtype=torch.int32)
+        b = ((self.bits.unsqueeze(1) >> k) & 1).to(torch.uint8).reshape(-1)[:n]
+        return b.reshape(self.shape)
 
     def query(self, points, enable_edge_gradients=True, out=None):
         """Batched EstimateDistance + GetGradient (sdf.hpp:947-961, :383-430) on the current field.

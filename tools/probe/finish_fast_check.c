@@ -1,0 +1,79 @@
+/* finish_fast_check.c -- exhaustive CPU check of the fp64-free finish (VERDICT r5 "next round" 1c).
+ *
+ * The reference finishes a voxel as float(sqrt((double)D) * resolution) (sdf_generation.hpp:254-265; D = the integer squared
+ * distance).  The far-field x sweep spends 12 of its ~29 finishing instructions per voxel on that fp64 sequence, at half rate.
+ * The fast path (sdfgpu_finish.hpp: finish_fast) computes the same float in fp32 -- hardware sqrt and rcp (1 ulp each), one
+ * Newton residual, the product against resolution split into two floats, and raises `slow` when the
+ * unrounded value lies within 2^-14 ulp of a rounding boundary: only those lanes need the fp64 sequence.
+ * This program restates the fast path with the host's correctly rounded fmaf / sqrtf and PERTURBS the two approximate
+ * instructions by -1, 0, +1 ulp (all 9 combinations): for every D in [1, dmax] and every resolution given, each combination
+ * must either raise `slow` or return exactly the reference's float.  Prints the share of values that take the slow path.
+ *   gcc -O2 -o finish_fast_check finish_fast_check.c -lm && ./finish_fast_check [dmax = 3145728] [res ...]            */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t as_u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+typedef struct { float rh, rl, hrh; } fin_t;
+
+static float finish_fast(uint32_t D, fin_t k, int ds, int dr, int* slow) {
+    const float x = (float)D;
+    float s = sqrtf(x);
+    if (ds) s = nextafterf(s, ds > 0 ? INFINITY : 0.0f);
+    const float r = fmaf(-s, s, x);
+    float rc = 1.0f / s;
+    if (dr) rc = nextafterf(rc, dr > 0 ? INFINITY : 0.0f);
+    const float t1 = r * rc;
+    const float p = s * k.rh;
+    const float pe = fmaf(s, k.rh, -p);
+    float c = fmaf(s, k.rl, pe);
+    c = fmaf(t1, k.hrh, c);
+    /* T = sqrt(D) * res lies within 2^-20 ulp of p + c.  Round both ends of p + c -+ thr (thr = 2^-15 .. 2^-14 ulp): rounding is
+     * monotone, so when the two agree every value in between -- T included, and the reference's double-rounded T -- rounds to that
+     * float, binade boundaries included; when they differ the lane takes the fp64 sequence. */
+    const float thr = p * 0x1p-38f;
+    const float y = p + (c - thr), yh = p + (c + thr);
+    *slow = as_u(y) != as_u(yh);
+    return y;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t dmax = argc > 1 ? (uint32_t)strtoul(argv[1], NULL, 10) : 3u * 1024u * 1024u;
+    double res_default[] = {1.0, 0.01, 0.013, 0.25, 0.1, 1e-3, 3.0, 0.04, 0.02, 1.0 / 3.0, 0.05, 2.5e-2, 0.7071067811865476, 1e6, 1e-6};
+    int nres = (int)(sizeof res_default / sizeof res_default[0]);
+    double* resv = res_default;
+    if (argc > 2) { nres = argc - 2; resv = malloc(sizeof(double) * nres); for (int i = 0; i < nres; ++i) resv[i] = strtod(argv[2 + i], NULL); }
+    long long bad = 0, slow_n = 0, total = 0;
+    for (int ri = 0; ri < nres; ++ri) {
+        const double res = resv[ri];
+        fin_t k;
+        k.rh = (float)res;
+        k.rl = (float)(res - (double)k.rh);
+        k.hrh = 0.5f * k.rh;
+        long long slow_r = 0;
+        for (uint32_t D = 1; D <= dmax; ++D) {
+            const float ref = (float)(sqrt((double)D) * res);
+            int any_slow = 0;
+            for (int ds = -1; ds <= 1; ++ds)
+                for (int dr = -1; dr <= 1; ++dr) {
+                    int slow;
+                    const float y = finish_fast(D, k, ds, dr, &slow);
+                    any_slow |= slow && ds == 0 && dr == 0;
+                    if (!slow && as_u(y) != as_u(ref)) {
+                        if (bad < 10) fprintf(stderr, "MISMATCH D=%u res=%.17g ds=%d dr=%d fast=%.9g ref=%.9g\n", D, res, ds, dr, y, ref);
+                        ++bad;
+                    }
+                }
+            slow_r += any_slow;
+            ++total;
+        }
+        slow_n += slow_r;
+        printf("res %-22.17g slow path %lld of %u (%.2e)\n", res, slow_r, dmax, (double)slow_r / dmax);
+    }
+    printf("%s: %lld values x 9 perturbations, %lld mismatches, slow share %.3e\n", bad ? "FAILED" : "ok", total, bad, (double)slow_n / (double)total);
+    return bad ? 1 : 0;
+}
