@@ -51,7 +51,8 @@ typedef enum sdfgpu_status {
     SDFGPU_ERR_HIP = -2,              /* a HIP runtime call failed (maps to std::runtime_error)   */
     SDFGPU_ERR_UNSUPPORTED_SIZE = -3, /* a dim > 16384 or nx^2+ny^2+nz^2 >= 2^30                   */
     SDFGPU_ERR_NO_DEVICE = -4,        /* no HIP device / device index out of range                */
-    SDFGPU_ERR_UNRESOLVED = -5        /* slab x-sweep needed rows beyond the supplied halo        */
+    SDFGPU_ERR_UNRESOLVED = -5,       /* slab x-sweep needed rows beyond the supplied halo        */
+    SDFGPU_ERR_REDZONE = -6           /* red-zone mode: a kernel of this call stored outside a buffer of the library (the message names it) */
 } sdfgpu_status;
 
 /* Library version, e.g. "sdfgpu 0.1 (gfx950)". */
@@ -362,9 +363,22 @@ int sdfgpu_voxelize_points_bits_device(sdfgpu_handle h, const float* d_points, i
                                        int64_t nx, int64_t ny, int64_t nz,
                                        uint32_t* d_bits, int clear_first, void* stream);
 
+/* Red zones (round 6).  With SDFGPU_REDZONE=1 in the environment when sdfgpu_create runs -- or after
+ * sdfgpu_set_option(h, "redzone", 1) -- every device allocation of the library (scratch fields, status block, extrema slots,
+ * staging buffers, sdfgpu_device_malloc memory) carries 4 KiB of canary bytes in front and behind, and every entry point that
+ * may have launched a kernel ends with one check kernel over all of them and a synchronisation: a store outside a buffer
+ * fails THAT call with SDFGPU_ERR_REDZONE and a message that names the buffer and the offset.  Debug mode (calls become
+ * synchronous; results are unchanged).  sdfgpu_redzone_check runs the same check on demand (wrappers with device buffers from
+ * sdfgpu_device_malloc: libsdfgpu_multi); SDFGPU_OK when the mode is off. */
+int sdfgpu_redzone_check(sdfgpu_handle h, void* stream);
+
 /* Debug / test hooks: copy the intermediates of the most recent
  * sdfgpu_build*_device call to host buffers (N int16 / N int32). */
 int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n);
+/* ... and the finishing arithmetic of the far-field x sweep, float(sqrt((double)D) * resolution) (sdf_generation.hpp:254-265),
+ * for D = 0 .. n - 1 (n <= 2^24) into d_out[n] (device), computed exactly as that kernel's store loop does (fp32 fast path +
+ * fp64 for the wave rounds that need it, option "fast_finish"); *out_slow_lanes = lanes that asked for the fp64 sequence. */
+int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, uint32_t* out_slow_lanes);
 int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
 
 /* Per-stage timing with HIP events recorded on the build's own stream (bench.py's roofline leg).

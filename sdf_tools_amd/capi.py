@@ -26,7 +26,7 @@ EXPORTS = [
     "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
     "sdfgpu_copy_to_host", "sdfgpu_copy_from_host", "sdfgpu_query_points", "sdfgpu_device_malloc", "sdfgpu_device_free",
     "sdfgpu_build_to_device", "sdfgpu_build_cells_to_device", "sdfgpu_upload_classified",
-    "sdfgpu_build_bits_device", "sdfgpu_build_bits", "sdfgpu_voxelize_points_bits_device",
+    "sdfgpu_build_bits_device", "sdfgpu_build_bits", "sdfgpu_voxelize_points_bits_device", "sdfgpu_debug_finish_table",
 ]
 
 
@@ -92,6 +92,7 @@ def load_library():
     L.sdfgpu_extrema_from_dsq.argtypes = [u32, u32, dbl, vp, vp]
     L.sdfgpu_gradient_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci, vp]
     L.sdfgpu_gradient.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci]
+    L.sdfgpu_debug_finish_table.argtypes = [vp, vp, i64, dbl, vp]
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_debug_copy_yzsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_set_tuning.argtypes = [vp, ci, ci]
@@ -381,6 +382,13 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_gradient(self._h, f.ctypes.data, *f.shape, float(resolution),
                                               int(bool(enable_edge_gradients)), out.ctypes.data, int(bool(f64))))
         return out
+
+    def debug_finish_table(self, d_out, n, resolution):
+        """finish(D) for D = 0 .. n - 1 into the device buffer d_out, as the far-field x sweep computes it; returns the number of
+        lanes that took the fp64 sequence."""
+        c = ctypes.c_uint32()
+        self._check(self._lib.sdfgpu_debug_finish_table(self._h, d_out, int(n), float(resolution), ctypes.byref(c)))
+        return int(c.value)
 
     def debug_zsweep(self, shape):
         out = np.empty(shape, dtype=np.int16)

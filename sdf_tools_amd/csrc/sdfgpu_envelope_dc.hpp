@@ -142,6 +142,27 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
 }
 
 
+// Test hook (sdfgpu_debug_finish_table): the finish of squared distances 0 .. n - 1 exactly as the x sweep's store loop computes it
+// -- fp32 fast path, wave-wide ballot, fp64 sequence for the rounds that need it -- so that tests can compare EVERY D with the
+// reference's arithmetic on the device's own sqrt / rcp instructions; slow_count = lanes that raised the flag.
+SDFGPU_KERNEL __launch_bounds__(256) void k_finish_table(float* __restrict__ out, int64_t n, double resolution, FinishFast fin,
+                                                       uint32_t* __restrict__ slow_count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int D = (int)(i < n ? i : 1);
+    bool slow;
+    float f = finish_fast(D, fin, slow);
+    slow = (slow || !fin.ok) && D != 0;
+    if (__ballot(slow) != 0ull) {
+        const float g = (float)(sqrt_exact_pos((double)D) * resolution);
+        f = slow ? g : f;
+    }
+    if (D == 0) f = 0.0f;
+    if (i < n) {
+        out[i] = f;
+        if (slow && fin.ok) atomicAdd(slow_count, 1u);
+    }
+}
+
 // Signed z distance of voxel z of one bit row, as the z sweep (K1) defines it: + distance to the nearest FILLED voxel of the row
 // for a free voxel, - distance to the nearest FREE one for a filled voxel, +-kInf16 when the row holds no voxel of the other
 // class.  Word-at-a-time scans in both directions: slow next to K1 (up to 2 nzw loads per voxel on an empty row), which is fine
