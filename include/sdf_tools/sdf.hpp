@@ -42,7 +42,12 @@ namespace detail {
 // (begin, end, end of storage -- a layout that has not changed since GCC 3; checked against a normally built vector at run
 // time); anywhere else, or if the check fails, the vector is built the ordinary way and only speed is lost.
 inline std::vector<float> UninitializedFloatVector(const size_t n) {
-#if defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(SDF_TOOLS_NO_VECTOR_ADOPT)
+    // OPT-IN (round 6): the trick overwrites a std::vector's representation -- undefined behaviour by the letter of the standard, and
+    // invisible to an instrumented vector -- so it is compiled only when the client defines SDF_TOOLS_VECTOR_ADOPT (the in-tree
+    // builds of pysdf_tools and the examples do; INTEGRATION.md's drop-in recipe does not), never in debug / sanitizer builds of
+    // libstdc++.  Without it the storage is value-initialised the ordinary way: +75 ... 100 ms per 512^3 result (measured: profiles/r06_redzone_suite_and_fuzz.txt).
+#if defined(SDF_TOOLS_VECTOR_ADOPT) && defined(__GLIBCXX__) && !defined(_GLIBCXX_DEBUG) && !defined(_GLIBCXX_SANITIZE_VECTOR) && \
+    !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__) && !defined(SDF_TOOLS_NO_VECTOR_ADOPT)
     static_assert(sizeof(std::vector<float>) == 3 * sizeof(float*), "std::vector<float> is not three pointers");
     static const bool layout_ok = []() {
         std::vector<float> probe(3);

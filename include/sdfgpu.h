@@ -319,7 +319,9 @@ int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf,
  * reference's host-side SignedDistanceField::EstimateDistance* / GetGradient*, sdf.hpp:922-961, :383-430): points
  * (n x 3 doubles) and the three outputs are HOST arrays (any output may be NULL); d_sdf is a device pointer, e.g.
  * one filled by sdfgpu_build_device into memory from sdfgpu_device_malloc.  A caller that only needs answers at its
- * points never downloads the field (512 MiB at 512^3, ~10 ms of PCIe).  Synchronous. */
+ * points never downloads the field (512 MiB at 512^3, ~10 ms of PCIe).  Synchronous.  Runs on the device's null stream behind this
+ * handle's last build; a d_sdf written by ANOTHER producer on a non-blocking stream (another handle's build on a PyTorch stream, a
+ * caller's kernel) must be complete before the call: synchronise that stream first. */
 int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf,
                         int64_t nx, int64_t ny, int64_t nz, double resolution,
                         const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
@@ -394,49 +396,57 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
 int sdfgpu_set_profiling(sdfgpu_handle h, int enable);
 int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_builds);
 
-/* Named integer options (benchmarks / A-B tests): "fused_zy" (1 = let the policy use the fused z+y kernel,
- * default; 0 = never; 2 = always when the shape allows), "rows_per_chunk_y", "rows_per_chunk_x",
- * "rows_per_chunk_zy" (0 = automatic), "fused_window" (register-window radius of the fused kernel at
- * nz = 512: 2 or 3), "plane16" (1 = int16 plane field + int32 side table between the y and x sweeps
- * when the shape allows, default; 0 = int32 plane field), "x16_voxels_per_lane" (4 or 8),
- * "x16_window" (2 or 3), "dense" (1 = try the bit-parallel dense kernel first, default; 0 = general
- * pipeline only), "envelope" (1 = bound the outward scans of K2 / K3 and redo far-field sweeps with the
- * lower-envelope kernels, default; 0 = unbounded scans), "envelope_mode" (1 = the far-field kernel is the
- * only sweep of both axes, no probes; 0 = back to the choice made on the device inside each build), "policy_reset"
- * (forget what was learned from earlier builds: only whether the dense tier is worth trying is learned),
- * "dense_retry" (after an uncertified dense attempt, try the dense kernels again only every N-th build;
- * default 16, 0 = always try), "fixup" (the fix-up kernel behind the dense ball kernel for almost-dense
- * scenes, default 1), "fixup_mode" (force the policy state that launches it with the next build), "dense3" (1 = the
- * fix-up stage starts with the wide ball kernel KD3, |offset| <= 3, in the dense kernel's place where the shape allows
- * it, default; 0 = the dense kernel + the fix-up kernel), "dense3_mode" (KD3 + the fix-up kernel with every dense build), "dense3_staged" (1 = a dense build that does not expect the
- * dense kernel to decide the scene enqueues KD3 + the fix-up kernel behind it, guarded on its verdict, default),
- * "march_window" / "x16_window" = 8 (force the radius-8 register windows of the y / x marching sweeps;
- * the y window is otherwise chosen by the probe), "dense_generic" (1 = shapes the tuned dense kernels do not take -- nz not 32 * 2^k, virtual border -- use their
- * generic forms, default; 0 = such shapes skip the dense tier), "envelope_dc" (1 = the far-field kernel k_envelope_dc
- * redoes sweeps whose bounded scans did not decide every voxel, default; 0 = never: the marching scans stay unbounded), "far_threshold_y" / "far_fraction_den_y" and "..._x" (an axis counts as
- * far-field when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 5 for the
- * y sweep and 9, 24 for the x sweep), "mid_threshold_y" / "mid_fraction_den_y" (near-field y sweep: radius-8 marching
- * windows when more than 1 / den of the probed voxels have a squared distance >= threshold; defaults 16, 24; den 0 = always the radius-3 window), "i32_handoff" (1 = when the y probe finds the scene far-field, the x sweep is the
- * far-field kernel too and takes an exact int32 plane field from the y sweep, default; 0 = 16-bit plane field + side
- * table between them and a probe of its own for the x axis), "probe_window" (1 = the tier probes are window statistics
- * over ~32 k sampled voxels, default; 0 = level A of the far-field search on sampled tiles), "y16" (1 = the y sweep of
- * the 16-bit pipeline through the packed 16-bit kernel, default; 0 = the 32-bit marching kernel), "z_wave" (1 = z sweep
- * with whole rows per wave where nz is 64 ... 1024 and a power of two, default; 0 = the workgroup form), "standby_far" (1 = behind a
- * dense tier the handle trusts, the guarded general pipeline is the far-field kernel pair -- two launches, bounded on any scene --
- * default; 0 = the fused z+y sweep + the marching x sweep with unbounded scans), "standby_grid" (workgroups of those stand-by
- * launches, default 1024), "expect_dense" (tests: 1 = put the handle into the "dense tier trusted" state for the next build),
- * "host_pack" (host-buffer entry points: 1 = inputs of 4 MiB and more are classified into one bit per voxel by the host's
- * thread team and 1/8 B per voxel is uploaded, default; 0 = upload the caller's mask / cells and classify on the device;
- * 2 = classify on the host whatever the size -- sdfgpu_upload_classified), "far_predict" (1 = a handle whose recent builds were
- * far-field on both axes enqueues the far-field pair without probes and marching launches and probes again every 16th build,
- * default; 0 = every build probes; 2 = every build takes the far-field pair), "standby_fold" (1 = the last launch of a stand-by
- * build also folds the extrema and publishes the status block, default; 0 = a launch of its own), "dense_shell" (1 = the shell
- * pass KD6, 16 <= d^2 <= 36, between KD3 and the fix-up kernel, default), "shell_min_words" / "shell_budget_den" (KD6: open words
- * below which a tile group is left to the fix-up kernel, default 128 of 512; the pass is for scenes with at most 1 / den of their
- * voxels undecided behind KD3, default 8).
- * Every option leaves the results exact: switches that
- * skip work for profiling ("dc_debug", "ball_variant") exist only in libraries built with -DSDFGPU_DEBUG_HOOKS and are
- * rejected with SDFGPU_ERR_INVALID_ARGUMENT by the shipped one. */
+/* Named integer options.  EVERY option leaves the results exact: they move work between kernels, switch a measured optimisation
+ * off for an A/B, or put the handle's policy into a state a test needs.  Unknown names return SDFGPU_ERR_INVALID_ARGUMENT.
+ * Switches that SKIP work for profiling ("dc_debug", "dc_debug_stage", "ball_variant") exist only in libraries built with
+ * -DSDFGPU_DEBUG_HOOKS (tools/probe/libsdfgpu_hooks.so) and are rejected by the shipped one.
+ * [T] = test / fuzz only (forces a state the policy reaches by itself), [AB] = A/B switch of a measured optimisation (default = the
+ * faster setting; DESIGN.md / LAB_NOTES.md hold the measurement), [U] = for users.
+ *
+ *  tier selection                     default  meaning
+ *  "dense"                   [U]      1        try the bit-parallel dense tier first (0: sweeps / far-field pair only)
+ *  "dense_generic"           [AB]     1        shapes the tuned dense kernels do not take (nz not 32 * 2^k) use their generic forms
+ *  "dense_retry"             [U]      16       after an uncertified dense attempt, try again only every N-th build (0: always)
+ *  "envelope"                [AB]     1        bound the marching scans and redo far-field sweeps with k_envelope_dc (0: unbounded scans)
+ *  "envelope_dc"             [AB]     1        0: never use the far-field kernel
+ *  "envelope_mode"           [T]      0        1: the far-field kernel is the only sweep of both axes, no probes
+ *  "far_predict"             [U]      1        handles whose recent builds were far-field skip probes + marching launches (0 off, 2 always)
+ *  "far_threshold_y/_x", "far_fraction_den_y/_x"  [AB]  16, 9 / 5, 24   an axis is far-field when > 1/den of the probed voxels have d^2 >= thr
+ *  "mid_threshold_y", "mid_fraction_den_y"        [AB]  16 / 24         radius-8 y window when > 1/den of them have d^2 >= thr (den 0: never)
+ *  "probe_window"            [AB]     1        tier probes as window statistics (0: level A of the far-field search on sampled tiles)
+ *  "policy_reset"            [T]      -        forget what the handle learned from earlier builds
+ *  "expect_dense"            [T]      0        put the handle into the "dense tier trusted" state (stand-by pair behind it)
+ *  "fixup_mode", "dense3_mode" [T]    0        force the fix-up stage / KD3 in KD's place with the next build
+ *
+ *  dense tier
+ *  "fixup"                   [AB]     1        fix-up kernel KF behind the ball kernel for almost-dense scenes
+ *  "dense3"                  [AB]     1        wide ball kernel KD3 (|offset| <= 3) as the fix-up stage's first kernel
+ *  "dense3_staged"           [AB]     1        builds that cannot expect KD to decide the scene carry KD3 + KF behind it, guarded
+ *  "dense3_fixed"            [AB]     1        KD3's nz = 512 instance (compile-time row pitch)
+ *  "dense_shell"             [AB]     1        shell pass KD6 (16 <= d^2 <= 36) between KD3 and KF
+ *  "shell_min_words", "shell_budget_den"  [AB]  128 / 8   KD6: open words below which a tile group is left to KF; budget 1/den of the voxels
+ *  "standby_far"             [AB]     1        stand-by behind a trusted dense tier = far-field pair (0: fused z+y + marching x, unbounded)
+ *  "standby_fold"            [AB]     1        the stand-by x sweep's launch also folds the extrema (one launch less per build)
+ *  "standby_grid"            [AB]     1024     workgroups of the stand-by launches
+ *  "pack_variant", "ball_block", "nt_store"  [AB]  0   K0 unroll / KD workgroup size / non-temporal output stores
+ *
+ *  sweeps
+ *  "fused_zy"                [AB]     1        let the policy use the fused z+y kernel (0 never, 2 always when the shape allows)
+ *  "fused_window"            [AB]     2        its register-window radius at nz = 512 (2 or 3)
+ *  "plane16"                 [AB]     1        int16 plane field + int32 side table between the y and x sweeps (0: int32 plane field)
+ *  "y16"                     [AB]     1        y sweep of that pipeline through the packed 16-bit kernel
+ *  "z_wave"                  [AB]     1        z sweep with whole rows per wave where nz = 64 ... 1024
+ *  "x16_voxels_per_lane", "x16_window", "march_window"  [AB]  4 / 3 / 3   K3/16 variant; forced radius-8 windows (= 8)
+ *  "rows_per_chunk_y/_x/_zy" [AB]     0        rows marched per thread (0: automatic); also sdfgpu_set_tuning
+ *  "i32_handoff"             [AB]     1        far-field pair hands exact int32 plane values from the y to the x sweep
+ *  "dc_fixed"                [AB]     1        far-field kernel: instances with the 512- / 1024-voxel line geometry at compile time
+ *  "fast_finish"             [AB]     1        far-field x sweep: fp32 finish with an fp64 fallback per wave round (sdfgpu_finish.hpp)
+ *
+ *  host side / debugging
+ *  "host_pack"               [U]      1        host-buffer builds classify on the host and upload 1 bit / voxel (0: upload + classify on
+ *                                              the device; 2: whatever the size)
+ *  "defer_fold"              [U]      0        stage entry points leave their maxima in the slots until sdfgpu_fold_extrema_device
+ *  "redzone"                 [U]      0        canaries around every device allocation, checked at the end of every call (see above) */
 int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value);
 
 /* Which kernels the most recent sdfgpu_build*_device call used: bit 0 = fused z+y kernel (K12),

@@ -120,7 +120,7 @@ def build_pysdf_tools(force=False, verbose=False):
     if not force and not _newer(out, deps):
         return out
     build_libsdfgpu_multi(force=False, verbose=verbose)
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DSDF_TOOLS_MULTI_GPU",
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DSDF_TOOLS_MULTI_GPU", "-DSDF_TOOLS_VECTOR_ADOPT",
            "-I", INCLUDE, "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
            src, "-o", out, "-L", PKG, "-lsdfgpu_multi", "-lsdfgpu", "-Wl,-rpath,$ORIGIN", "-lz"]
     if verbose:
@@ -140,7 +140,7 @@ def build_example(name, force=False, verbose=False):
     build_libsdfgpu(force=False, verbose=verbose)
     if not force and not _newer(exe, deps):
         return exe
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-I", INCLUDE, src, "-o", exe, "-L", PKG, "-lsdfgpu",
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", "-DSDF_TOOLS_VECTOR_ADOPT", "-I", INCLUDE, src, "-o", exe, "-L", PKG, "-lsdfgpu",
            "-Wl,-rpath," + PKG, "-lz"]
     if verbose:
         print(" ".join(cmd))

@@ -13,7 +13,7 @@ import numpy as np
 from . import build as _build
 
 SDFGPU_DSQ_INF = 1 << 30
-_STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "HIP", -3: "UNSUPPORTED_SIZE", -4: "NO_DEVICE", -5: "UNRESOLVED"}
+_STATUS = {0: "OK", -1: "INVALID_ARGUMENT", -2: "HIP", -3: "UNSUPPORTED_SIZE", -4: "NO_DEVICE", -5: "UNRESOLVED", -6: "REDZONE"}
 
 # every symbol include/sdfgpu.h declares (tests check that the library exports them all)
 EXPORTS = [
@@ -26,7 +26,7 @@ EXPORTS = [
     "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
     "sdfgpu_copy_to_host", "sdfgpu_copy_from_host", "sdfgpu_query_points", "sdfgpu_device_malloc", "sdfgpu_device_free",
     "sdfgpu_build_to_device", "sdfgpu_build_cells_to_device", "sdfgpu_upload_classified",
-    "sdfgpu_build_bits_device", "sdfgpu_build_bits", "sdfgpu_voxelize_points_bits_device", "sdfgpu_debug_finish_table",
+    "sdfgpu_build_bits_device", "sdfgpu_build_bits", "sdfgpu_voxelize_points_bits_device", "sdfgpu_debug_finish_table", "sdfgpu_redzone_check",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library():
     L.sdfgpu_gradient_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci, vp]
     L.sdfgpu_gradient.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci]
     L.sdfgpu_debug_finish_table.argtypes = [vp, vp, i64, dbl, vp]
+    L.sdfgpu_redzone_check.argtypes = [vp, vp]
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_debug_copy_yzsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_set_tuning.argtypes = [vp, ci, ci]
@@ -382,6 +383,10 @@ class SdfGpu:
         self._check(self._lib.sdfgpu_gradient(self._h, f.ctypes.data, *f.shape, float(resolution),
                                               int(bool(enable_edge_gradients)), out.ctypes.data, int(bool(f64))))
         return out
+
+    def redzone_check(self, stream=0):
+        """Red-zone mode (SDFGPU_REDZONE=1 / option "redzone"): check every canary now; raises SdfGpuError(REDZONE) naming the buffer."""
+        self._check(self._lib.sdfgpu_redzone_check(self._h, stream or None))
 
     def debug_finish_table(self, d_out, n, resolution):
         """finish(D) for D = 0 .. n - 1 into the device buffer d_out, as the far-field x sweep computes it; returns the number of

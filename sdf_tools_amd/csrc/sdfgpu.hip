@@ -1018,7 +1018,9 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         h->flags_pending = false;
         //   (a staged build -- KD, then KD3 + KF on KD's verdict -- reports KD's own verdict, status word 20, as word 8)
         h->pol.consume_report(h->h_flags[3] != 0, h->h_flags[6] != 0, h->h_flags[8] != 0);
-        h->far.consume_report(h->h_flags[4] != 0, h->h_flags[5] != 0);
+        // (a predicted build's flags are raised by the launches themselves: they teach the habit nothing, and a near-field scene would
+        //  keep a stale "far" alive through them -- ADVICE r5)
+        if (!h->pol.prev.predicted) h->far.consume_report(h->h_flags[4] != 0, h->h_flags[5] != 0);
     }
     if (h->far_pending && hipEventQuery(h->far_ev) == hipSuccess) {
         h->far_pending = false;
@@ -1303,7 +1305,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (report) {
         HIP_TRY(h, hipEventRecord(h->flags_ev, s));
         h->flags_pending = true;
-        h->pol.prev = ReportedBuild{dense, dense_generic, cur_fix_mode, cur_staged};
+        h->pol.prev = ReportedBuild{dense, dense_generic, cur_fix_mode, cur_staged, predicted};
     }
     if (prof) {
         HIP_TRY(h, mark(7));
@@ -1652,13 +1654,17 @@ int sdfgpu_destroy(sdfgpu_handle h) {
 
 const char* sdfgpu_last_error(sdfgpu_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
-int sdfgpu_build(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+static int sdfgpu_build_body(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
                  int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
     return build_host_impl(h, filled, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, out_sdf,
                            out_max, out_min);
 }
+int sdfgpu_build(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                 int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_build_body(h, filled, nx, ny, nz, resolution, add_virtual_border, out_sdf, out_max, out_min); });
+}
 
-int sdfgpu_build_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+static int sdfgpu_build_cells_body(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
                        int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
                        int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
     if (h && !cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cells is null");
@@ -1667,15 +1673,24 @@ int sdfgpu_build_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, s
     return build_host_impl(h, nullptr, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz,
                            resolution, add_virtual_border, out_sdf, out_max, out_min);
 }
+int sdfgpu_build_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                       int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                       int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_build_cells_body(h, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz, resolution, add_virtual_border, out_sdf, out_max, out_min); });
+}
 
-int sdfgpu_build_to_device(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+static int sdfgpu_build_to_device_body(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
                            int add_virtual_border, float* d_out_sdf, double* out_max, double* out_min) {
     if (h && !d_out_sdf) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_out_sdf is null");
     return build_host_impl(h, filled, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, nullptr, out_max, out_min,
                            d_out_sdf);
 }
+int sdfgpu_build_to_device(sdfgpu_handle h, const uint8_t* filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                           int add_virtual_border, float* d_out_sdf, double* out_max, double* out_min) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_build_to_device_body(h, filled, nx, ny, nz, resolution, add_virtual_border, d_out_sdf, out_max, out_min); });
+}
 
-int sdfgpu_build_cells_to_device(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+static int sdfgpu_build_cells_to_device_body(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
                                  int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
                                  int add_virtual_border, float* d_out_sdf, double* out_max, double* out_min) {
     if (h && !cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cells is null");
@@ -1685,51 +1700,79 @@ int sdfgpu_build_cells_to_device(sdfgpu_handle h, const void* cells, size_t cell
     return build_host_impl(h, nullptr, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz, resolution,
                            add_virtual_border, nullptr, out_max, out_min, d_out_sdf);
 }
+int sdfgpu_build_cells_to_device(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                                 int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                 int add_virtual_border, float* d_out_sdf, double* out_max, double* out_min) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_build_cells_to_device_body(h, cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz, resolution, add_virtual_border, d_out_sdf, out_max, out_min); });
+}
 
-int sdfgpu_build_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nx, int64_t ny, int64_t nz,
+static int sdfgpu_build_device_body(sdfgpu_handle h, const uint8_t* d_filled, int64_t nx, int64_t ny, int64_t nz,
                         double resolution, int add_virtual_border, float* d_out_sdf, void* stream) {
     if (h && !d_filled) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_filled is null");
     return build_device_impl(h, d_filled, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, d_out_sdf,
                              (hipStream_t)stream);
 }
+int sdfgpu_build_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nx, int64_t ny, int64_t nz,
+                        double resolution, int add_virtual_border, float* d_out_sdf, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_build_device_body(h, d_filled, nx, ny, nz, resolution, add_virtual_border, d_out_sdf, stream); });
+}
 
-int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
+static int sdfgpu_build_cells_device_body(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
                               int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
                               int add_virtual_border, float* d_out_sdf, void* stream) {
     if (h && !d_cells) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_cells is null");
     return build_device_impl(h, nullptr, d_cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz,
                              resolution, add_virtual_border, d_out_sdf, (hipStream_t)stream);
 }
+int sdfgpu_build_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
+                              int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                              int add_virtual_border, float* d_out_sdf, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_build_cells_device_body(h, d_cells, cell_stride, occupancy_offset, unknown_is_filled, nx, ny, nz, resolution, add_virtual_border, d_out_sdf, stream); });
+}
 
-int sdfgpu_build_bits_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t nx, int64_t ny, int64_t nz,
+static int sdfgpu_build_bits_device_body(sdfgpu_handle h, const uint32_t* d_bits, int64_t nx, int64_t ny, int64_t nz,
                              double resolution, int add_virtual_border, float* d_out_sdf, void* stream) {
     if (h && !d_bits) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "d_bits is null");
     return build_device_impl(h, nullptr, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, d_out_sdf,
                              (hipStream_t)stream, d_bits);
 }
+int sdfgpu_build_bits_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t nx, int64_t ny, int64_t nz,
+                             double resolution, int add_virtual_border, float* d_out_sdf, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_build_bits_device_body(h, d_bits, nx, ny, nz, resolution, add_virtual_border, d_out_sdf, stream); });
+}
 
-int sdfgpu_build_bits(sdfgpu_handle h, const uint32_t* bits, int64_t nx, int64_t ny, int64_t nz, double resolution,
+static int sdfgpu_build_bits_body(sdfgpu_handle h, const uint32_t* bits, int64_t nx, int64_t ny, int64_t nz, double resolution,
                       int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
     if (h && !bits) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bits is null");
     return build_host_impl(h, nullptr, nullptr, 0, 0, 0, nx, ny, nz, resolution, add_virtual_border, out_sdf, out_max, out_min,
                            nullptr, bits);
 }
+int sdfgpu_build_bits(sdfgpu_handle h, const uint32_t* bits, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                      int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_build_bits_body(h, bits, nx, ny, nz, resolution, add_virtual_border, out_sdf, out_max, out_min); });
+}
 
-int sdfgpu_copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, void* stream) {
+static int sdfgpu_copy_to_host_body(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (bytes > 0 && (!dst || !d_src)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     return copy_to_host(h, dst, d_src, bytes, (hipStream_t)stream);
 }
+int sdfgpu_copy_to_host(sdfgpu_handle h, void* dst, const void* d_src, size_t bytes, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_copy_to_host_body(h, dst, d_src, bytes, stream); });
+}
 
-int sdfgpu_copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, void* stream) {
+static int sdfgpu_copy_from_host_body(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (bytes > 0 && (!d_dst || !src)) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     return copy_from_host(h, d_dst, src, bytes, (hipStream_t)stream);
 }
+int sdfgpu_copy_from_host(sdfgpu_handle h, void* d_dst, const void* src, size_t bytes, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_copy_from_host_body(h, d_dst, src, bytes, stream); });
+}
 
-int sdfgpu_upload_classified(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t cell_stride, size_t occupancy_offset,
+static int sdfgpu_upload_classified_body(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t cell_stride, size_t occupancy_offset,
                              int unknown_is_filled, int64_t n, uint8_t* d_mask, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if ((!filled && !cells) || !d_mask) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null pointer");
@@ -1738,6 +1781,10 @@ int sdfgpu_upload_classified(sdfgpu_handle h, const uint8_t* filled, const void*
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "cell_stride/occupancy_offset must be 4-byte aligned and in range");
     HIP_TRY(h, hipSetDevice(h->device));
     return upload_packed(h, cells ? nullptr : filled, cells, cell_stride, occupancy_offset, unknown_is_filled, n, d_mask, (hipStream_t)stream);
+}
+int sdfgpu_upload_classified(sdfgpu_handle h, const uint8_t* filled, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                             int unknown_is_filled, int64_t n, uint8_t* d_mask, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_upload_classified_body(h, filled, cells, cell_stride, occupancy_offset, unknown_is_filled, n, d_mask, stream); });
 }
 
 int sdfgpu_extrema_from_dsq(uint32_t max_dsq_free, uint32_t max_dsq_filled, double resolution, double* out_max,
@@ -1769,7 +1816,7 @@ int sdfgpu_get_extrema(sdfgpu_handle h, double* out_max, double* out_min) {
     return sdfgpu_extrema_from_dsq(v[0], v[1], h->last_resolution, out_max, out_min);
 }
 
-int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
+static int sdfgpu_sweep_zy_tiered_device_body(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
                                   int32_t* d_plane_dsq, uint32_t* d_far, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     h->guard = nullptr;
@@ -1817,13 +1864,21 @@ int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int6
     h->small_clean = true;
     return SDFGPU_OK;
 }
+int sdfgpu_sweep_zy_tiered_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
+                                  int32_t* d_plane_dsq, uint32_t* d_far, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_sweep_zy_tiered_device_body(h, d_filled, nxs, ny, nz, d_plane_dsq, d_far, stream); });
+}
 
-int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
+static int sdfgpu_sweep_zy_device_body(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
                            int32_t* d_plane_dsq, void* stream) {
     return sdfgpu_sweep_zy_tiered_device(h, d_filled, nxs, ny, nz, d_plane_dsq, nullptr, stream);
 }
+int sdfgpu_sweep_zy_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t nxs, int64_t ny, int64_t nz,
+                           int32_t* d_plane_dsq, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_sweep_zy_device_body(h, d_filled, nxs, ny, nz, d_plane_dsq, stream); });
+}
 
-int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t nx, int64_t nys, int64_t nz,
+static int sdfgpu_sweep_x_lines_device_body(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t nx, int64_t nys, int64_t nz,
                                 int64_t y_global, int64_t ny_global, double resolution, int add_virtual_border,
                                 float* d_out_sdf, uint32_t* d_maxdsq, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
@@ -1865,8 +1920,13 @@ int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int
     h->small_clean = true;
     return SDFGPU_OK;
 }
+int sdfgpu_sweep_x_lines_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t nx, int64_t nys, int64_t nz,
+                                int64_t y_global, int64_t ny_global, double resolution, int add_virtual_border,
+                                float* d_out_sdf, uint32_t* d_maxdsq, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_sweep_x_lines_device_body(h, d_plane_dsq, nx, nys, nz, y_global, ny_global, resolution, add_virtual_border, d_out_sdf, d_maxdsq, stream); });
+}
 
-int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t halo_lo, int64_t nxs,
+static int sdfgpu_sweep_x_device_body(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t halo_lo, int64_t nxs,
                           int64_t halo_hi, int64_t ny, int64_t nz, int lo_truncated, int hi_truncated,
                           int64_t x_global, int64_t nx_global, double resolution, int add_virtual_border,
                           float* d_out_sdf, uint32_t* d_maxdsq, uint32_t* d_status, void* stream) {
@@ -1885,8 +1945,14 @@ int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t h
                                 (hipStream_t)stream)) return rc;
     return h->defer_fold ? SDFGPU_OK : fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
+int sdfgpu_sweep_x_device(sdfgpu_handle h, const int32_t* d_plane_dsq, int64_t halo_lo, int64_t nxs,
+                          int64_t halo_hi, int64_t ny, int64_t nz, int lo_truncated, int hi_truncated,
+                          int64_t x_global, int64_t nx_global, double resolution, int add_virtual_border,
+                          float* d_out_sdf, uint32_t* d_maxdsq, uint32_t* d_status, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_sweep_x_device_body(h, d_plane_dsq, halo_lo, nxs, halo_hi, ny, nz, lo_truncated, hi_truncated, x_global, nx_global, resolution, add_virtual_border, d_out_sdf, d_maxdsq, d_status, stream); });
+}
 
-int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_rows, int64_t nz, uint32_t* d_bits,
+static int sdfgpu_pack_bits_device_body(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_rows, int64_t nz, uint32_t* d_bits,
                             void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!d_filled || !d_bits) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
@@ -1894,8 +1960,12 @@ int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_
     HIP_TRY(h, hipSetDevice(h->device));
     return launch_pack_bits(h, d_filled, nullptr, 0, 0, 0, n_rows * nz, d_bits, (hipStream_t)stream);
 }
+int sdfgpu_pack_bits_device(sdfgpu_handle h, const uint8_t* d_filled, int64_t n_rows, int64_t nz, uint32_t* d_bits,
+                            void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_pack_bits_device_body(h, d_filled, n_rows, nz, d_bits, stream); });
+}
 
-int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t rows_x, int64_t out_lo, int64_t out_hi,
+static int sdfgpu_dense_ball_device_body(sdfgpu_handle h, const uint32_t* d_bits, int64_t rows_x, int64_t out_lo, int64_t out_hi,
                              int64_t ny, int64_t nz, double resolution, float* d_out_sdf, uint32_t* d_maxdsq,
                              uint32_t* d_uncertified, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
@@ -1908,6 +1978,11 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
                                    d_uncertified, (hipStream_t)stream)) return rc;
     return h->defer_fold ? SDFGPU_OK : fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
+int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t rows_x, int64_t out_lo, int64_t out_hi,
+                             int64_t ny, int64_t nz, double resolution, float* d_out_sdf, uint32_t* d_maxdsq,
+                             uint32_t* d_uncertified, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_dense_ball_device_body(h, d_bits, rows_x, out_lo, out_hi, ny, nz, resolution, d_out_sdf, d_maxdsq, d_uncertified, stream); });
+}
 
 // One x slab of the dense path in three host calls instead of ten (the per-call cost of the Python binding is what
 // limits a rank at ~0.15 ms per build): phase 0 = clear the status words + pack the boundary planes (the caller then
@@ -1915,7 +1990,7 @@ int sdfgpu_dense_ball_device(sdfgpu_handle h, const uint32_t* d_bits, int64_t ro
 // (10 / 11 = only the first / second half of that), phase 2 = ball kernel on the border planes + fold of the maxima
 // (after the exchange has been waited for).  Without neighbours, or for slabs too thin to split, phase 0 packs
 // everything, phase 1 does nothing and phase 2 runs the ball kernel on the whole slab.
-int sdfgpu_slab_dense_phase(sdfgpu_handle h, int phase, const uint8_t* d_mask_slab, int64_t nxs, int64_t ny, int64_t nz,
+static int sdfgpu_slab_dense_phase_body(sdfgpu_handle h, int phase, const uint8_t* d_mask_slab, int64_t nxs, int64_t ny, int64_t nz,
                             uint32_t* d_bits_ext, int64_t halo_lo, int64_t halo_hi, double resolution, float* d_out,
                             uint32_t* d_small, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
@@ -1965,15 +2040,23 @@ int sdfgpu_slab_dense_phase(sdfgpu_handle h, int phase, const uint8_t* d_mask_sl
         return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "unknown phase %d", phase);
     }
 }
+int sdfgpu_slab_dense_phase(sdfgpu_handle h, int phase, const uint8_t* d_mask_slab, int64_t nxs, int64_t ny, int64_t nz,
+                            uint32_t* d_bits_ext, int64_t halo_lo, int64_t halo_hi, double resolution, float* d_out,
+                            uint32_t* d_small, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_slab_dense_phase_body(h, phase, d_mask_slab, nxs, ny, nz, d_bits_ext, halo_lo, halo_hi, resolution, d_out, d_small, stream); });
+}
 
-int sdfgpu_fold_extrema_device(sdfgpu_handle h, uint32_t* d_maxdsq, void* stream) {
+static int sdfgpu_fold_extrema_device_body(sdfgpu_handle h, uint32_t* d_maxdsq, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!d_maxdsq) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null device pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     return fold_slots(h, d_maxdsq, (hipStream_t)stream);
 }
+int sdfgpu_fold_extrema_device(sdfgpu_handle h, uint32_t* d_maxdsq, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_fold_extrema_device_body(h, d_maxdsq, stream); });
+}
 
-int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+static int sdfgpu_build_tagged_cells_body(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
                               size_t object_id_offset, int object_mode, const uint32_t* object_ids, int64_t n_object_ids,
                               int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
                               int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
@@ -2024,8 +2107,14 @@ int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_st
     if (out_min) *out_min = mn;
     return SDFGPU_OK;
 }
+int sdfgpu_build_tagged_cells(sdfgpu_handle h, const void* cells, size_t cell_stride, size_t occupancy_offset,
+                              size_t object_id_offset, int object_mode, const uint32_t* object_ids, int64_t n_object_ids,
+                              int unknown_is_filled, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                              int add_virtual_border, float* out_sdf, double* out_max, double* out_min) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_build_tagged_cells_body(h, cells, cell_stride, occupancy_offset, object_id_offset, object_mode, object_ids, n_object_ids, unknown_is_filled, nx, ny, nz, resolution, add_virtual_border, out_sdf, out_max, out_min); });
+}
 
-int sdfgpu_classify_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
+static int sdfgpu_classify_cells_device_body(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
                                  int unknown_is_filled, int64_t n_cells, uint8_t* d_mask, void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!d_cells || !d_mask || n_cells < 0) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "bad classify arguments");
@@ -2039,8 +2128,12 @@ int sdfgpu_classify_cells_device(sdfgpu_handle h, const void* d_cells, size_t ce
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
+int sdfgpu_classify_cells_device(sdfgpu_handle h, const void* d_cells, size_t cell_stride, size_t occupancy_offset,
+                                 int unknown_is_filled, int64_t n_cells, uint8_t* d_mask, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_classify_cells_device_body(h, d_cells, cell_stride, occupancy_offset, unknown_is_filled, n_cells, d_mask, stream); });
+}
 
-int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
+static int sdfgpu_voxelize_points_device_body(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
                                   double resolution, int64_t nx, int64_t ny, int64_t nz, uint8_t* d_mask, int clear_first,
                                   void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
@@ -2057,8 +2150,13 @@ int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_
     }
     return SDFGPU_OK;
 }
+int sdfgpu_voxelize_points_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
+                                  double resolution, int64_t nx, int64_t ny, int64_t nz, uint8_t* d_mask, int clear_first,
+                                  void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_voxelize_points_device_body(h, d_points, n_points, origin, resolution, nx, ny, nz, d_mask, clear_first, stream); });
+}
 
-int sdfgpu_voxelize_points_bits_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
+static int sdfgpu_voxelize_points_bits_device_body(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
                                        double resolution, int64_t nx, int64_t ny, int64_t nz, uint32_t* d_bits, int clear_first,
                                        void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
@@ -2075,8 +2173,13 @@ int sdfgpu_voxelize_points_bits_device(sdfgpu_handle h, const float* d_points, i
     }
     return SDFGPU_OK;
 }
+int sdfgpu_voxelize_points_bits_device(sdfgpu_handle h, const float* d_points, int64_t n_points, const double* origin,
+                                       double resolution, int64_t nx, int64_t ny, int64_t nz, uint32_t* d_bits, int clear_first,
+                                       void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_voxelize_points_bits_device_body(h, d_points, n_points, origin, resolution, nx, ny, nz, d_bits, clear_first, stream); });
+}
 
-int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz,
+static int sdfgpu_gradient_device_body(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz,
                            double resolution, int enable_edge_gradients, void* d_out_grad, int out_is_f64,
                            void* stream) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
@@ -2108,10 +2211,15 @@ int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int6
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
+int sdfgpu_gradient_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz,
+                           double resolution, int enable_edge_gradients, void* d_out_grad, int out_is_f64,
+                           void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_gradient_device_body(h, d_sdf, nx, ny, nz, resolution, enable_edge_gradients, d_out_grad, out_is_f64, stream); });
+}
 
 // Host-buffer form of the full-grid gradient (what SignedDistanceField::GetFullGradient / pysdf_tools'
 // GetFullGradientNumpy call instead of N host GetGradient calls): upload the field, one kernel, download.
-int sdfgpu_gradient(sdfgpu_handle h, const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+static int sdfgpu_gradient_body(sdfgpu_handle h, const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
                     int enable_edge_gradients, void* out_grad, int out_is_f64) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
     if (!sdf || !out_grad) return fail(h, SDFGPU_ERR_INVALID_ARGUMENT, "null host pointer");
@@ -2141,8 +2249,12 @@ int sdfgpu_gradient(sdfgpu_handle h, const float* sdf, int64_t nx, int64_t ny, i
     }
     return SDFGPU_OK;
 }
+int sdfgpu_gradient(sdfgpu_handle h, const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                    int enable_edge_gradients, void* out_grad, int out_is_f64) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_gradient_body(h, sdf, nx, ny, nz, resolution, enable_edge_gradients, out_grad, out_is_f64); });
+}
 
-int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+static int sdfgpu_query_points_device_body(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
                                const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
                                const double* d_points, int64_t n_points, int enable_edge_gradients, double* d_distance,
                                double* d_gradient, uint8_t* d_flags, void* stream) {
@@ -2166,6 +2278,12 @@ int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, 
     HIP_TRY(h, hipGetLastError());
     return SDFGPU_OK;
 }
+int sdfgpu_query_points_device(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                               const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
+                               const double* d_points, int64_t n_points, int enable_edge_gradients, double* d_distance,
+                               double* d_gradient, uint8_t* d_flags, void* stream) {
+    return rz_wrap(h, stream, [&]() -> int { return sdfgpu_query_points_device_body(h, d_sdf, nx, ny, nz, resolution, world_to_grid, grid_to_world_rotation, oob_value, d_points, n_points, enable_edge_gradients, d_distance, d_gradient, d_flags, stream); });
+}
 
 int sdfgpu_device_malloc(sdfgpu_handle h, size_t bytes, void** out_ptr) {
     if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
@@ -2183,7 +2301,7 @@ int sdfgpu_device_free(sdfgpu_handle h, void* ptr) {
     return rz_free(h, ptr);
 }
 
-int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+static int sdfgpu_query_points_body(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
                         const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
                         const double* points, int64_t n_points, int enable_edge_gradients, double* out_distance,
                         double* out_gradient, uint8_t* out_flags) {
@@ -2200,7 +2318,9 @@ int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t
     char* base = (char*)h->query_stage.ptr;
     // Round 5: the null stream of the context's device, ordered behind this handle's last build by its event --
     // not h->last_stream, which is a handle of the CALLER's (an earlier *_device build's stream may have been destroyed since).
-    // A field produced elsewhere (another handle, an upload) is ordered by the null stream's implicit synchronisation.
+    // A field produced ELSEWHERE (another handle, a caller's kernel) is ordered by the null stream's implicit synchronisation only
+    // when its stream is a blocking one: producers on hipStreamNonBlocking streams (PyTorch's are) must be synchronised by the caller
+    // before this call -- include/sdfgpu.h says so.
     hipStream_t s = nullptr;
     if (h->order_valid && h->order_stream != nullptr) HIP_TRY(h, hipStreamWaitEvent(s, h->build_done_ev, 0));
     if (int rc = copy_from_host(h, base, points, n * 24, s)) return rc;
@@ -2214,8 +2334,14 @@ int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t
     if (out_flags) if (int rc = copy_to_host(h, out_flags, base + o_f, n, s)) return rc;
     return SDFGPU_OK;
 }
+int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                        const double* world_to_grid, const double* grid_to_world_rotation, float oob_value,
+                        const double* points, int64_t n_points, int enable_edge_gradients, double* out_distance,
+                        double* out_gradient, uint8_t* out_flags) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_query_points_body(h, d_sdf, nx, ny, nz, resolution, world_to_grid, grid_to_world_rotation, oob_value, points, n_points, enable_edge_gradients, out_distance, out_gradient, out_flags); });
+}
 
-int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, uint32_t* out_slow_lanes) {
+static int sdfgpu_debug_finish_table_body(sdfgpu_handle h, float* d_out, int64_t n, double resolution, uint32_t* out_slow_lanes) {
     if (!h || !d_out || n <= 0 || n > (1ll << 24)) return SDFGPU_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = ensure(h, h->tagids, 4, "object id list")) return rc;
@@ -2228,6 +2354,14 @@ int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double r
     HIP_TRY(h, hipMemcpy(&c, h->tagids.ptr, 4, hipMemcpyDeviceToHost));
     if (out_slow_lanes) *out_slow_lanes = c;
     return SDFGPU_OK;
+}
+int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, uint32_t* out_slow_lanes) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_debug_finish_table_body(h, d_out, n, resolution, out_slow_lanes); });
+}
+
+int sdfgpu_redzone_check(sdfgpu_handle h, void* stream) {
+    if (!h) return SDFGPU_ERR_INVALID_ARGUMENT;
+    return redzone_check(h, (hipStream_t)stream);
 }
 
 int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {

@@ -3,7 +3,7 @@
 //
 // The fp64 sequence is 12 of the ~29 instructions the far-field x sweep spends on a voxel outside its search, at half rate (the
 // rsq seed slower still).  finish_fast computes the same float in fp32:
-//     s = v_sqrt_f32(D), e = (D - s^2) / 2s            sqrt(D) = s + e up to 2^-47 relative (one Newton residual; s, 1/s: 1 ulp each)
+//     rs = v_rsq_f32(D), s = D * rs, e = (D - s^2) rs / 2   sqrt(D) = s + e up to 2^-44 relative (one Newton residual; rs: 1 ulp)
 //     p = s * rh, pe = fma(s, rh, -p)                  resolution = rh + rl (two floats: 2^-49 relative), p + pe = s * rh exactly
 //     c = pe + s * rl + e * rh                         T = sqrt(D) * resolution = p + c up to 2^-20 ulp(p)
 //     y = RN(p + (c - thr)), yh = RN(p + (c + thr))    thr = p * 2^-38 = 2^-15 .. 2^-14 ulp(p)
@@ -11,8 +11,8 @@
 // double-rounded T (which differs from T by 2^-52 relative) -- across binade boundaries too.  When they differ (a share of
 // ~9e-5 of all D, no small D among them for the usual resolutions) the lane raises `slow` and takes the fp64 sequence; the
 // callers branch on a wave-wide ballot, so a wave pays for it once in ~200 voxel rounds.
-// Exactness: tools/probe/finish_fast_check.c restates this with correctly rounded host arithmetic and perturbs the two
-// approximate instructions by -1 / 0 / +1 ulp: every D <= 3 * 1024^2 x 15 resolutions x 9 perturbations either raises `slow` or
+// Exactness: tools/probe/finish_fast_check.c restates this with correctly rounded host arithmetic and perturbs the
+// approximate instruction by -2 .. +2 ulp: every D <= 3 * 1024^2 x 15 resolutions x 9 perturbations either raises `slow` or
 // returns the reference's float; on the device tests/test_gpu_finish.py compares the kernel's own table of every D.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -41,15 +41,15 @@ inline FinishFast make_finish_fast(double resolution, uint64_t max_d, bool enabl
 // D >= 1 and exactly representable as a float (the caller masks D = 0 and the sentinel out of `slow`)
 __device__ __forceinline__ float finish_fast(int D, const FinishFast& k, bool& slow) {
     const float x = (float)D;
-    const float s = __builtin_amdgcn_sqrtf(x);
+    const float rs = __builtin_amdgcn_rsqf(x);                  // the one transcendental (quarter rate); s within ~2 ulp of sqrt(x)
+    const float s = x * rs;
     const float r = __builtin_fmaf(-s, s, x);
-    const float t1 = r * __builtin_amdgcn_rcpf(s);
+    const float t1 = r * rs;                                    // e = t1 / 2 (the half sits in hrh)
     const float p = s * k.rh;
     const float pe = __builtin_fmaf(s, k.rh, -p);
     float c = __builtin_fmaf(s, k.rl, pe);
     c = __builtin_fmaf(t1, k.hrh, c);
-    const float thr = p * 0x1p-38f;
-    const float y = p + (c - thr), yh = p + (c + thr);
+    const float y = p + __builtin_fmaf(p, -0x1p-38f, c), yh = p + __builtin_fmaf(p, 0x1p-38f, c);
     slow = __builtin_bit_cast(uint32_t, y) != __builtin_bit_cast(uint32_t, yh);
     return y;
 }

@@ -116,9 +116,11 @@ int mfail(sdfgpu_multi_handle h, int code, const char* fmt, ...) {
 int ensure(sdfgpu_multi_handle h, Rank& k, Buf& b, size_t bytes) {
     if (b.p && b.bytes >= bytes) return SDFGPU_OK;
     M_HIP(h, hipSetDevice(k.dev));
-    if (b.p) { M_HIP(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
-    bytes = std::max<size_t>(bytes, 256);
-    M_HIP(h, hipMalloc(&b.p, bytes));
+    // (through the rank's libsdfgpu context: in red-zone mode -- SDFGPU_REDZONE=1 -- these buffers carry canaries like the context's
+    //  own, and every stage call of that context checks them)
+    const int q = (int)(&k - h->r.data());
+    if (b.p) { M_SDF(h, q, sdfgpu_device_free(k.ctx, b.p)); b.p = nullptr; b.bytes = 0; }
+    M_SDF(h, q, sdfgpu_device_malloc(k.ctx, bytes, &b.p));
     b.bytes = bytes;
     return SDFGPU_OK;
 }
@@ -535,6 +537,12 @@ int build_device(sdfgpu_multi_handle h, const uint8_t* const* d_mask, int64_t nx
         }
     }
     // (every rank's wait step synchronised its compute stream; the communication streams are ordered before them)
+    // red-zone mode: one more look at every rank's buffers, the exchanged ones included (a no-op otherwise)
+    for (int q = 0; q < G; ++q) {
+        M_HIP(h, hipSetDevice(h->r[(size_t)q].dev));
+        M_SDF(h, q, sdfgpu_redzone_check(h->r[(size_t)q].ctx, h->r[(size_t)q].s));
+    }
+    M_HIP(h, hipSetDevice(h->r[0].dev));
     return sdfgpu_extrema_from_dsq(max_f, max_q, res, out_max, out_min);
 }
 
@@ -670,7 +678,7 @@ int sdfgpu_multi_destroy(sdfgpu_multi_handle h) {
         if (k.cs) (void)hipStreamSynchronize(k.cs);
         if (k.comm) (void)ncclCommDestroy(k.comm);
         for (Buf* b : {&k.mask, &k.out, &k.cells, &k.bits, &k.ext, &k.lines, &k.out_y, &k.sendbuf, &k.recvtmp})
-            if (b->p) (void)hipFree(b->p);
+            if (b->p && k.ctx) (void)sdfgpu_device_free(k.ctx, b->p);
         if (k.d_small) (void)hipFree(k.d_small);
         if (k.h_small) (void)hipHostFree(k.h_small);
         if (k.ev_s) (void)hipEventDestroy(k.ev_s);

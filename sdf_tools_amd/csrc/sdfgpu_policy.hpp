@@ -44,6 +44,8 @@ struct ReportedBuild {
     bool generic = false;    // ... in their generic form (any nz / no fix-up stage behind it)
     bool fix_mode = false;   // ... as the fix-up stage (KD3 or KD with KF behind it, in fix-up mode)
     bool staged = false;     // ... as KD with the fix-up stage staged behind it, guarded on KD's verdict
+    bool predicted = false;  // the far-field pair was enqueued on the strength of earlier builds: its far flags say "the launch ran",
+                             // not "a probe found the scene far-field" -- they must not extend the habit
 };
 
 // What the next build enqueues around the dense kernels.

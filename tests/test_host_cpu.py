@@ -398,3 +398,20 @@ def test_host_schedulers_under_thread_sanitizer(sanitize):
         assert "ThreadSanitizer: data race" in r.stderr, "the sanitizer did not see the pre-fix fill race\n" + r.stdout
     else:
         assert r.returncode == 3, "the pre-fix arithmetic did not corrupt a single upload: the harness is too tame\n" + r.stdout + r.stderr
+
+
+def test_fp32_finish_is_exact_under_every_perturbation_of_the_hardware_instruction():
+    """sdf_tools_amd/csrc/sdfgpu_finish.hpp, restated with correctly rounded host arithmetic (tools/probe/finish_fast_check.c): for
+    EVERY squared distance a 1024^3 grid can hold x 15 resolutions, with the one approximate instruction (v_rsq_f32) perturbed by
+    -2 .. +2 ulp, the fp32 fast path either raises `slow` (-> the fp64 sequence) or returns exactly
+    float(sqrt((double)D) * resolution), the reference's arithmetic (sdf_generation.hpp:254-265).  The device's own instructions are
+    checked by tests/test_gpu_finish.py."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "probe", "finish_fast_check")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(root, "tools", "probe", "finish_fast_check.c"), "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    share = float(r.stdout.strip().splitlines()[-1].split("slow share")[1])
+    assert share < 2e-4, share                      # the fp64 sequence stays the exception

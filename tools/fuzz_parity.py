@@ -27,6 +27,8 @@ if VERBOSE:
         _opts[name] = value
         return _set(name, value)
     ctx.set_option = _recording_set
+MULTI = {}
+MODES = {}
 sizes = [1, 2, 3, 5, 8, 13, 16, 21, 32, 33, 40, 64, 96, 128]
 t0 = time.time()
 n = 0
@@ -109,9 +111,69 @@ while time.time() - t0 < budget:
         ctx.set_option("expect_dense", 1)
     if VERBOSE:
         print("scene", n, shape, "kind", int(kind), "res", res, "vb", vb, "filled", int(m.sum()), _opts, flush=True)
-        os.makedirs("gpurun_out", exist_ok=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    if VERBOSE:
         np.save("gpurun_out/fuzz_last_mask.npy", m)       # (the scene a crash happened in)
-    if rng.random() < (1.0 if os.environ.get("FUZZ_GUARD") else 0.5):
+    # which entry point builds this scene (round 6): the host-buffer ABI, the device-resident ABI into a guard-banded field, the
+    # bits-in ABI, libsdfgpu_multi with 1 .. 4 logical ranks on this GPU (x slabs: sdfgpu_slab_dense_phase, the tiered z / y sweep,
+    # the halo and whole-line x sweeps, the re-partition), and now and then the gradient / query kernels on the result.  With
+    # SDFGPU_REDZONE=1 every buffer the library owns -- the ranks' slabs and exchange buffers included -- and every
+    # sdfgpu_device_malloc buffer used here carries canaries that each call checks.
+    mode = str(rng.choice(["host", "guard", "guard", "bits", "multi", "rz_out"]))
+    if os.environ.get("FUZZ_GUARD") and mode == "host":
+        mode = "guard"
+    if mode == "multi" and (shape[0] < 4 or vb and rng.random() < 0.5):
+        mode = "guard"
+    if mode == "multi":
+        ranks = int(rng.choice([r for r in (1, 2, 3, 4) if r <= shape[0]]))
+        if ranks not in MULTI:
+            MULTI[ranks] = capi.MultiSdfGpu(ranks, [0] * ranks)
+        mg = MULTI[ranks]
+        mg.set_option("halo", int(rng.choice([1, 2, 3, 8])))
+        mg.set_option("dense", int(rng.integers(0, 2)))
+        mg.set_option("predict_far", int(rng.integers(0, 2)))
+        mg.set_option("dense_retry", 0)
+        got, ext = mg.build(m, res, vb)
+    elif mode == "rz_out":
+        # exact-size output and input from sdfgpu_device_malloc: in red-zone mode the first byte behind the field is canary
+        import torch
+        nvox = int(m.size)
+        d_in, d_out = ctx.device_malloc(nvox), ctx.device_malloc(nvox * 4)
+        ctx.copy_from_host(d_in, m)
+        ctx.build_device(d_in, shape, d_out, res, vb, 0)
+        ext = ctx.get_extrema()
+        got = ctx.copy_to_host(np.empty(shape, np.float32), d_out)
+        if rng.random() < 0.3:                      # the gradient and query kernels on the fresh field, exact-size outputs (values: tests/)
+            d_g = ctx.device_malloc(nvox * 12)
+            ctx.gradient_device(d_out, shape, d_g, res, True, False, 0)
+            npts = 257
+            pts = (rng.random((npts, 3)) * (np.asarray(shape) * res * 1.2) - 0.1 * res).astype(np.float64)
+            d_p, d_d, d_gr, d_f = ctx.device_malloc(npts * 24), ctx.device_malloc(npts * 8), ctx.device_malloc(npts * 24), ctx.device_malloc(npts)
+            ctx.copy_from_host(d_p, pts)
+            ctx.query_points_device(d_out, shape, res, d_p, npts, d_d, d_gr, d_f, enable_edge_gradients=bool(rng.integers(0, 2)))
+            ctx.redzone_check()
+            for ptr in (d_g, d_p, d_d, d_gr, d_f):
+                ctx.device_free(ptr)
+        ctx.device_free(d_in)
+        ctx.device_free(d_out)
+    elif mode == "bits":
+        import torch
+        nvox = int(m.size)
+        g = ((max(4096, 8 * shape[1] * shape[2]) + 3) // 4) * 4
+        buf = torch.full((g + nvox + g,), -12345.0, dtype=torch.float32, device="cuda")
+        words = capi.pack_bits_host(m).view(np.int32)
+        db = torch.zeros(words.size + 1, dtype=torch.int32, device="cuda")
+        sh = int(rng.integers(0, 2))               # (a field that is only 4-byte aligned takes the device copy)
+        db[sh:sh + words.size] = torch.from_numpy(words).cuda()
+        ctx.build_bits_device(db.data_ptr() + 4 * sh, shape, buf.data_ptr() + 4 * g, res, vb, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ext = ctx.get_extrema()
+        got = buf[g:g + nvox].cpu().numpy().reshape(shape)
+        if not bool((buf[:g] == -12345.0).all().item()) or not bool((buf[g + nvox:] == -12345.0).all().item()):
+            print("GUARD BAND WRITTEN (bits in) shape", shape, "kind", kind, "res", res, "vb", vb)
+            np.save("gpurun_out/fuzz_fail_mask.npy", m)
+            sys.exit(1)
+    elif mode == "guard":
         # device-resident build into a field with a guard band in front of it and behind it (round 5: a store past the end of the
         # field is silent on the host path, whose staging buffer is as large as the largest scene so far)
         import torch
@@ -139,4 +201,5 @@ while time.time() - t0 < budget:
         print("MISMATCH shape", shape, "kind", kind, "res", res, "vb", vb, "bad", len(bad), bad[:3].tolist(), ext, want_ext)
         sys.exit(1)
     n += 1
-print("fuzz OK: %d scenes in %.0f s (seed %d)" % (n, time.time() - t0, seed))
+    MODES[mode] = MODES.get(mode, 0) + 1
+print("fuzz OK: %d scenes in %.0f s (seed %d)%s; entry points %s" % (n, time.time() - t0, seed, ", red zones on" if os.environ.get("SDFGPU_REDZONE") else "", MODES))

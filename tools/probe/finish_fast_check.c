@@ -2,11 +2,11 @@
  *
  * The reference finishes a voxel as float(sqrt((double)D) * resolution) (sdf_generation.hpp:254-265; D = the integer squared
  * distance).  The far-field x sweep spends 12 of its ~29 finishing instructions per voxel on that fp64 sequence, at half rate.
- * The fast path (sdfgpu_finish.hpp: finish_fast) computes the same float in fp32 -- hardware sqrt and rcp (1 ulp each), one
+ * The fast path (sdfgpu_finish.hpp: finish_fast) computes the same float in fp32 -- hardware rsq (1 ulp), one
  * Newton residual, the product against resolution split into two floats, and raises `slow` when the
  * unrounded value lies within 2^-14 ulp of a rounding boundary: only those lanes need the fp64 sequence.
- * This program restates the fast path with the host's correctly rounded fmaf / sqrtf and PERTURBS the two approximate
- * instructions by -1, 0, +1 ulp (all 9 combinations): for every D in [1, dmax] and every resolution given, each combination
+ * This program restates the fast path with the host's correctly rounded fmaf / sqrtf and PERTURBS the approximate
+ * instruction by -2 .. +2 ulp (9 combinations): for every D in [1, dmax] and every resolution given, each combination
  * must either raise `slow` or return exactly the reference's float.  Prints the share of values that take the slow path.
  *   gcc -O2 -o finish_fast_check finish_fast_check.c -lm && ./finish_fast_check [dmax = 3145728] [res ...]            */
 #include <math.h>
@@ -22,12 +22,13 @@ typedef struct { float rh, rl, hrh; } fin_t;
 
 static float finish_fast(uint32_t D, fin_t k, int ds, int dr, int* slow) {
     const float x = (float)D;
-    float s = sqrtf(x);
-    if (ds) s = nextafterf(s, ds > 0 ? INFINITY : 0.0f);
+    /* v_rsq_f32 (1 ulp), perturbed; s = x * rsq is then within ~2 ulp of sqrt(x), which the residual step absorbs */
+    float rs = (float)(1.0 / sqrt((double)x));
+    if (ds) rs = nextafterf(rs, ds > 0 ? INFINITY : 0.0f);
+    if (dr) rs = nextafterf(rs, dr > 0 ? INFINITY : 0.0f);      /* (dr: a second ulp in the same direction, +-2 in all) */
+    const float s = x * rs;
     const float r = fmaf(-s, s, x);
-    float rc = 1.0f / s;
-    if (dr) rc = nextafterf(rc, dr > 0 ? INFINITY : 0.0f);
-    const float t1 = r * rc;
+    const float t1 = r * rs;                                     /* e = r / (2 s) = t1 * 0.5; the 0.5 sits in hrh */
     const float p = s * k.rh;
     const float pe = fmaf(s, k.rh, -p);
     float c = fmaf(s, k.rl, pe);
@@ -35,8 +36,7 @@ static float finish_fast(uint32_t D, fin_t k, int ds, int dr, int* slow) {
     /* T = sqrt(D) * res lies within 2^-20 ulp of p + c.  Round both ends of p + c -+ thr (thr = 2^-15 .. 2^-14 ulp): rounding is
      * monotone, so when the two agree every value in between -- T included, and the reference's double-rounded T -- rounds to that
      * float, binade boundaries included; when they differ the lane takes the fp64 sequence. */
-    const float thr = p * 0x1p-38f;
-    const float y = p + (c - thr), yh = p + (c + thr);
+    const float y = p + fmaf(p, -0x1p-38f, c), yh = p + fmaf(p, 0x1p-38f, c);
     *slow = as_u(y) != as_u(yh);
     return y;
 }
