@@ -377,10 +377,11 @@ int sdfgpu_redzone_check(sdfgpu_handle h, void* stream);
 /* Debug / test hooks: copy the intermediates of the most recent
  * sdfgpu_build*_device call to host buffers (N int16 / N int32). */
 int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n);
-/* ... and the finishing arithmetic of the far-field x sweep, float(sqrt((double)D) * resolution) (sdf_generation.hpp:254-265),
- * for D = 0 .. n - 1 (n <= 2^24) into d_out[n] (device), computed exactly as that kernel's store loop does (fp32 fast path +
- * fp64 for the wave rounds that need it, option "fast_finish"); *out_slow_lanes = lanes that asked for the fp64 sequence. */
-int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, uint32_t* out_slow_lanes);
+/* ... and float(sqrt((double)D) * resolution) (sdf_generation.hpp:254-265) for D = 0 .. n - 1 (n <= 2^24) into d_out[n] (device):
+ * fast = 0 the fp64 sequence of the far-field x sweep, fast = 1 the fp32 form of sdf_tools_amd/csrc/sdfgpu_finish.hpp (round 6: exact,
+ * measured slower than the fp64 sequence on MI355X and therefore not used by the kernels; kept with its exhaustive tests);
+ * *out_slow_lanes = lanes of the fp32 form that asked for the fp64 sequence. */
+int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, int fast, uint32_t* out_slow_lanes);
 int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
 
 /* Per-stage timing with HIP events recorded on the build's own stream (bench.py's roofline leg).
@@ -440,7 +441,6 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  *  "rows_per_chunk_y/_x/_zy" [AB]     0        rows marched per thread (0: automatic); also sdfgpu_set_tuning
  *  "i32_handoff"             [AB]     1        far-field pair hands exact int32 plane values from the y to the x sweep
  *  "dc_fixed"                [AB]     1        far-field kernel: instances with the 512- / 1024-voxel line geometry at compile time
- *  "fast_finish"             [AB]     1        far-field x sweep: fp32 finish with an fp64 fallback per wave round (sdfgpu_finish.hpp)
  *
  *  host side / debugging
  *  "host_pack"               [U]      1        host-buffer builds classify on the host and upload 1 bit / voxel (0: upload + classify on

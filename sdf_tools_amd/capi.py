@@ -92,7 +92,7 @@ def load_library():
     L.sdfgpu_extrema_from_dsq.argtypes = [u32, u32, dbl, vp, vp]
     L.sdfgpu_gradient_device.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci, vp]
     L.sdfgpu_gradient.argtypes = [vp, vp, i64, i64, i64, dbl, ci, vp, ci]
-    L.sdfgpu_debug_finish_table.argtypes = [vp, vp, i64, dbl, vp]
+    L.sdfgpu_debug_finish_table.argtypes = [vp, vp, i64, dbl, ci, vp]
     L.sdfgpu_redzone_check.argtypes = [vp, vp]
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_debug_copy_yzsweep.argtypes = [vp, vp, i64]
@@ -388,11 +388,11 @@ class SdfGpu:
         """Red-zone mode (SDFGPU_REDZONE=1 / option "redzone"): check every canary now; raises SdfGpuError(REDZONE) naming the buffer."""
         self._check(self._lib.sdfgpu_redzone_check(self._h, stream or None))
 
-    def debug_finish_table(self, d_out, n, resolution):
-        """finish(D) for D = 0 .. n - 1 into the device buffer d_out, as the far-field x sweep computes it; returns the number of
-        lanes that took the fp64 sequence."""
+    def debug_finish_table(self, d_out, n, resolution, fast=True):
+        """float(sqrt(double(D)) * resolution) for D = 0 .. n - 1 into the device buffer d_out: the fp32 form of sdfgpu_finish.hpp
+        (fast) or the x sweep's fp64 sequence; returns the number of lanes of the fp32 form that took the fp64 sequence."""
         c = ctypes.c_uint32()
-        self._check(self._lib.sdfgpu_debug_finish_table(self._h, d_out, int(n), float(resolution), ctypes.byref(c)))
+        self._check(self._lib.sdfgpu_debug_finish_table(self._h, d_out, int(n), float(resolution), int(bool(fast)), ctypes.byref(c)))
         return int(c.value)
 
     def debug_zsweep(self, shape):

@@ -118,7 +118,6 @@ struct sdfgpu_context {
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool shell_on = true;            // KD6, the bit-parallel shell pass between KD3 and KF (option "dense_shell")
     bool dc_fixed = true;            // far-field kernel: the 512-voxel-line instances (option "dc_fixed")
-    bool fast_finish = true;         // far-field x sweep: fp32 finish with an fp64 fallback per wave round (option "fast_finish"; sdfgpu_finish.hpp)
     bool dense3_fixed = true;        // KD3's nz = 512 instance (option "dense3_fixed")
     int shell_min_words = kShellMinWords;   // option "shell_min_words"
     int shell_budget_den = 8;        // ... for scenes with at most 1 / 8 of their voxels undecided behind KD3 (option "shell_budget_den"): Bernoulli
@@ -649,7 +648,6 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
         else { a.group_lines = ny * nz; a.tiles_per_outer = (ny * nz + NL - 1) / NL; ntiles = a.tiles_per_outer; a.outer_stride = 0; a.line_stride = ny * nz; a.L = (int)nx; }
         a.B = g.B; a.finf = g.finf; a.pitch = g.pitch; a.M = g.M; a.Kp = 0; a.h = (a.L + 1) / 2;
         a.resolution = resolution; a.vb = vb; a.nx = nx; a.ny = ny; a.nz = nz;
-        a.fin = make_finish_fast(resolution, g.finf, h->fast_finish);       // (finf > every finite squared distance of this grid)
         a.y_off = 0; a.ny_glob = ny;
         if (ex) {
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
@@ -2341,13 +2339,13 @@ int sdfgpu_query_points(sdfgpu_handle h, const float* d_sdf, int64_t nx, int64_t
     return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_query_points_body(h, d_sdf, nx, ny, nz, resolution, world_to_grid, grid_to_world_rotation, oob_value, points, n_points, enable_edge_gradients, out_distance, out_gradient, out_flags); });
 }
 
-static int sdfgpu_debug_finish_table_body(sdfgpu_handle h, float* d_out, int64_t n, double resolution, uint32_t* out_slow_lanes) {
+static int sdfgpu_debug_finish_table_body(sdfgpu_handle h, float* d_out, int64_t n, double resolution, int fast, uint32_t* out_slow_lanes) {
     if (!h || !d_out || n <= 0 || n > (1ll << 24)) return SDFGPU_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     if (int rc = ensure(h, h->tagids, 4, "object id list")) return rc;
     h->tag_cached_bytes = 0;
     HIP_TRY(h, hipMemset(h->tagids.ptr, 0, 4));
-    const FinishFast fin = make_finish_fast(resolution, (uint64_t)n, h->fast_finish);
+    const FinishFast fin = make_finish_fast(resolution, (uint64_t)n, fast != 0);
     hipLaunchKernelGGL(k_finish_table, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d_out, n, resolution, fin, (uint32_t*)h->tagids.ptr);
     HIP_TRY(h, hipGetLastError());
     uint32_t c = 0;
@@ -2355,8 +2353,8 @@ static int sdfgpu_debug_finish_table_body(sdfgpu_handle h, float* d_out, int64_t
     if (out_slow_lanes) *out_slow_lanes = c;
     return SDFGPU_OK;
 }
-int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, uint32_t* out_slow_lanes) {
-    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_debug_finish_table_body(h, d_out, n, resolution, out_slow_lanes); });
+int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, int fast, uint32_t* out_slow_lanes) {
+    return rz_wrap(h, nullptr, [&]() -> int { return sdfgpu_debug_finish_table_body(h, d_out, n, resolution, fast, out_slow_lanes); });
 }
 
 int sdfgpu_redzone_check(sdfgpu_handle h, void* stream) {
@@ -2475,7 +2473,6 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
     else if (n == "dense_shell") h->shell_on = value != 0;
     else if (n == "dc_fixed") h->dc_fixed = value != 0;
-    else if (n == "fast_finish") h->fast_finish = value != 0;
     else if (n == "redzone") {
         // from now on: every buffer the context holds is released (and comes back with -- or without -- zones when it is next needed);
         // the status block and the slots are replaced at once

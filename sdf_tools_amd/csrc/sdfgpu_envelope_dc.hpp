@@ -121,7 +121,6 @@ struct EnvDcArgs {
     uint32_t* fold_report;
     uint32_t* fold_ticket;
     uint32_t fold_report_mask;
-    FinishFast fin;           // STAGE 3: the fp32 form of the finish (sdfgpu_finish.hpp); fin.ok = 0: fp64 for every voxel
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -142,9 +141,10 @@ __device__ __forceinline__ double sqrt_exact_pos(double x) {
 }
 
 
-// Test hook (sdfgpu_debug_finish_table): the finish of squared distances 0 .. n - 1 exactly as the x sweep's store loop computes it
-// -- fp32 fast path, wave-wide ballot, fp64 sequence for the rounds that need it -- so that tests can compare EVERY D with the
-// reference's arithmetic on the device's own sqrt / rcp instructions; slow_count = lanes that raised the flag.
+// Test hook (sdfgpu_debug_finish_table): the finish of squared distances 0 .. n - 1 in the fp32 form of sdfgpu_finish.hpp -- fast path,
+// wave-wide ballot, the x sweep's own fp64 sequence (sqrt_exact_pos) for the rounds that ask for it -- or, fin.ok = 0, in the fp64
+// sequence alone: tests compare EVERY D with the reference's arithmetic on the device's own instructions; slow_count = lanes that
+// raised the flag.  (The fp32 form is not used by the x sweep: measured 2.4 % slower, see sdfgpu_finish.hpp.)
 SDFGPU_KERNEL __launch_bounds__(256) void k_finish_table(float* __restrict__ out, int64_t n, double resolution, FinishFast fin,
                                                        uint32_t* __restrict__ slow_count) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -485,6 +485,8 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         tile = (int64_t)blockIdx.x * a.probe_stride + (blockIdx.x * 7u) % (uint32_t)a.probe_stride;
     } else if ((nblk & 31u) == 0u) {
         const uint32_t xcd = vblk & 7u, seq = vblk >> 3;
+        // (round 6 measured the runs in a scattered -- multiplicatively permuted -- order, so that the ~1000 tiles in flight spread over
+        //  the whole plane instead of one 64 KB window: x sweep +3 % at 512^3, -1 % at 1024^3, profiles/r06_tile_order_ab.txt.  Not kept.)
         tile = ((int64_t)(seq >> 2) * 8 + xcd) * 4 + (seq & 3u);
     }
     const int64_t o = tile / a.tiles_per_outer;
@@ -1032,19 +1034,14 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         mx = imax(mx, D[k]);
-                        // the finish: fp32 with a per-lane "too close to a rounding boundary" flag (sdfgpu_finish.hpp); a wave in
-                        // which a lane raises it -- one voxel in ~11 000 -- runs the reference's fp64 sequence for that round
-                        bool slow;
-                        float f = finish_fast(D[k], a.fin, slow);                                       // (D = 0: not stored)
-                        slow = (slow || !a.fin.ok) && D[k] != 0 && D[k] < kInf32;
+                        // (round 6 built an fp64-free form of this finish -- sdfgpu_finish.hpp: exact, and 2.4 % SLOWER here: on this chip
+                        //  v_fma_f64 issues at the fp32 rate, and the fp32 form with its exactness test is the longer sequence)
 #ifdef SDFGPU_DEBUG_HOOKS
-                        if (a.dbg & 2) { f = (float)D[k]; slow = false; }
+                        float f = (a.dbg & 2) ? (float)D[k] : (float)(sqrt_exact_pos((double)D[k]) * a.resolution);
                         if ((a.dbg & 4) && (k || slotT)) { bo += 4u * ls; continue; }
+#else
+                        float f = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);                 // (D = 0: not stored)
 #endif
-                        if (__ballot(slow) != 0ull) {                                                   // (wave-uniform)
-                            const float g = (float)(sqrt_exact_pos((double)D[k]) * a.resolution);
-                            f = slow ? g : f;
-                        }
                         f = D[k] >= kInf32 ? __builtin_inff() : f;
                         if (D[k] != 0) *reinterpret_cast<float*>(op + bo) = cls == 1 ? -f : f;
                         bo += 4u * ls;

@@ -1,16 +1,21 @@
 // sdfgpu_finish.hpp -- the reference's finishing arithmetic float(sqrt((double)D) * resolution) (sdf_generation.hpp:254-265; D = the
 // integer squared distance) WITHOUT fp64 on the fast path (round 6, VERDICT r5 "next round" 1c).
 //
-// The fp64 sequence is 12 of the ~29 instructions the far-field x sweep spends on a voxel outside its search, at half rate (the
-// rsq seed slower still).  finish_fast computes the same float in fp32:
+// VERDICT r5 asked for it on the premise that fp64 issues at half rate.  Built, exact -- and NOT used by the kernels: on MI355X
+// v_fma_f64 issues at the rate of the (unpacked) fp32 FMA, the x sweep's fp64 sequence (sqrt_exact_pos: 10 instructions + convert,
+// multiply, convert) is SHORTER than this form with its exactness test, and the x sweep built on this form ran 2.4 % slower than
+// round 5's library in one process on one box (two-box scene 0.467 vs 0.456 ms, room 0.714 vs 0.698; profiles/r06_fast_finish_ab.txt
+// -- whose first, same-binary A/B had shown -7 % only because its "off" arm computed both forms).  Kept as a tested building block
+// (sdfgpu_debug_finish_table, tests/test_gpu_finish.py, tools/probe/finish_fast_check.c) for hardware where fp64 is the slow pipe.
+// finish_fast computes the same float in fp32:
 //     rs = v_rsq_f32(D), s = D * rs, e = (D - s^2) rs / 2   sqrt(D) = s + e up to 2^-44 relative (one Newton residual; rs: 1 ulp)
 //     p = s * rh, pe = fma(s, rh, -p)                  resolution = rh + rl (two floats: 2^-49 relative), p + pe = s * rh exactly
 //     c = pe + s * rl + e * rh                         T = sqrt(D) * resolution = p + c up to 2^-20 ulp(p)
 //     y = RN(p + (c - thr)), yh = RN(p + (c + thr))    thr = p * 2^-38 = 2^-15 .. 2^-14 ulp(p)
 // Rounding is monotone: when y == yh every value between the two sums rounds to y -- T does, and so does the reference's
 // double-rounded T (which differs from T by 2^-52 relative) -- across binade boundaries too.  When they differ (a share of
-// ~9e-5 of all D, no small D among them for the usual resolutions) the lane raises `slow` and takes the fp64 sequence; the
-// callers branch on a wave-wide ballot, so a wave pays for it once in ~200 voxel rounds.
+// ~9e-5 of all D, no small D among them for the usual resolutions) the lane raises `slow` and takes the fp64 sequence; a
+// caller branches on a wave-wide ballot, so a wave pays for it once in ~200 voxel rounds.
 // Exactness: tools/probe/finish_fast_check.c restates this with correctly rounded host arithmetic and perturbs the
 // approximate instruction by -2 .. +2 ulp: every D <= 3 * 1024^2 x 15 resolutions x 9 perturbations either raises `slow` or
 // returns the reference's float; on the device tests/test_gpu_finish.py compares the kernel's own table of every D.

@@ -4,9 +4,14 @@
 set -e
 tag=$1; name=$2
 G=gpurun_out/$tag; P=profiles
-cp $G/bench.json $P/${name}_bench.json
+# (round 6: bench.py prints the full detail as "BENCH_FULL {...}" and the contract line behind it)
+tail -1 $G/bench.json > $P/${name}_bench.json
+grep -a '^BENCH_FULL ' $G/bench.json | tail -1 | cut -c12- > $P/${name}_bench_full.json
+[ -f $G/bench_driver_style.json ] && tail -1 $G/bench_driver_style.json > $P/${name}_bench_driver_style.json
+[ -f $G/scene_bench.jsonl ] && cp $G/scene_bench.jsonl $P/${name}_scene_bench.jsonl
+[ -f $G/scene_bench_1024.jsonl ] && cp $G/scene_bench_1024.jsonl $P/${name}_scene_bench_1024.jsonl
 cp $G/stream_bench.json $P/${name}_stream_bench.json
-head -1 $G/bench_slab_world1.json > $P/${name}_bench_slab_world1.json      # (RCCL prints its banner on stdout behind the line)
+grep -a '^{' $G/bench_slab_world1.json | tail -1 > $P/${name}_bench_slab_world1.json      # (RCCL prints its banner on stdout behind the line)
 [ -f $G/psweep.jsonl ] && cp $G/psweep.jsonl $P/${name}_p_sweep.jsonl
 python tools/rocprof_summary.py stats $G/stats_dense $P/${name}_dense_kernel_stats.md
 python tools/rocprof_summary.py stats $G/stats_stream $P/${name}_stream_kernel_stats.md

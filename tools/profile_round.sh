@@ -3,7 +3,7 @@
 #   tools/profile_round.sh <tag>      -> gpurun_out/<tag>/...
 # bench line, kernel-trace stats of the bench and of the streaming / far-field workloads, PMC passes (HBM traffic and SQ
 # counters; counters are collected in their own runs, with --kernel-trace only).
-tag=${1:-r05}
+tag=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -12,6 +12,9 @@ python bench.py > $O/bench.json 2> $O/bench.err
 python bench_stream.py > $O/stream_bench.json 2> $O/stream_bench.err
 python bench.py --force-slab --no-cpu-baseline --no-legs --steps 100 > $O/bench_slab_world1.json 2> $O/bench_slab.err
 timeout 400 python tools/p_sweep.py > $O/psweep.jsonl 2> $O/psweep.err
+timeout 300 python tools/scene_bench.py 512 2>/dev/null | grep '^{' > $O/scene_bench.jsonl
+timeout 300 python tools/scene_bench.py 1024 2>/dev/null | grep '^{' > $O/scene_bench_1024.jsonl
+( t0=$(date +%s); python bench.py --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err; echo "bench wall $(( $(date +%s) - t0 )) s" >> $O/bench_driver_style.err )
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/stats_dense -o s --output-format csv -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-legs > $O/stats_dense.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/stats_stream -o s --output-format csv -- python $R/bench_stream.py --frames 30 > $O/stats_stream.log 2>&1

@@ -20,7 +20,9 @@ libs = {"A": kv.pop("A"), "B": kv.pop("B")}
 n = int(kv.pop("n", 512))
 reps = int(kv.pop("reps", 6))
 steps = int(kv.pop("steps", 50))
-opts = {k: int(v) for k, v in kv.items()} or {"dense": 0}
+scene_arg = kv.get("scene")
+opts = {k: int(v) for k, v in kv.items() if k != "scene"} or {"dense": 0}
+kv = {"scene": scene_arg} if scene_arg else {}
 vp, i64, dbl, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int
 STAGES = ["pack_bits", "dense_ball", "sweep_z", "sweep_y", "envelope_y", "sweep_x", "envelope_x"]
 
@@ -45,7 +47,22 @@ def bind(path):
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 shape = (n, n, n)
-masks = [synth.bernoulli_mask_torch(shape, 0.5, 1 + k, device=dev) for k in range(3)]
+scene = kv.pop("scene", "bernoulli") if "scene" in kv else "bernoulli"
+if scene == "twobox":                       # the streaming scene: 200 k points in two boxes (far-field on both axes)
+    import numpy as np
+    res0 = 0.01
+    masks = []
+    for f in range(3):
+        pc = synth.two_box_points(200000 * n * n // (512 * 512), seed=f, scale=n * res0)
+        idx = (pc.astype(np.float64) / res0).astype(np.int64)
+        ok = np.all((idx >= 0) & (idx < n), axis=1)
+        m = np.zeros(shape, np.uint8)
+        m[idx[ok, 0], idx[ok, 1], idx[ok, 2]] = 1
+        masks.append(torch.from_numpy(m).to(dev))
+elif scene == "room":
+    masks = [synth.room_mask_torch(shape, dev)] * 3
+else:
+    masks = [synth.bernoulli_mask_torch(shape, 0.5, 1 + k, device=dev) for k in range(3)]
 out = {k: torch.empty(shape, dtype=torch.float32, device=dev) for k in libs}
 stream = torch.cuda.current_stream(dev).cuda_stream
 ctx = {k: bind(p) for k, p in libs.items()}
@@ -84,7 +101,7 @@ for rep in range(reps):
         acc[key]["ms"].append(ms)
         acc[key]["stages"].append(st)
         print(json.dumps({"rep": rep, "lib": key, "path": libs[key], "ms_per_build": round(ms, 4), "stages_ms": st}), flush=True)
-summary = {"n": n, "options": opts, "steps": steps}
+summary = {"n": n, "scene": scene, "options": opts, "steps": steps}
 for key in libs:
     v = sorted(acc[key]["ms"])
     summary[key] = {"path": libs[key], "ms_min": round(v[0], 4), "ms_median": round(v[len(v) // 2], 4), "ms_max": round(v[-1], 4),
