@@ -441,6 +441,7 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  *  "rows_per_chunk_y/_x/_zy" [AB]     0        rows marched per thread (0: automatic); also sdfgpu_set_tuning
  *  "i32_handoff"             [AB]     1        far-field pair hands exact int32 plane values from the y to the x sweep
  *  "dc_fixed"                [AB]     1        far-field kernel: instances with the 512- / 1024-voxel line geometry at compile time
+ *  "plane_skip"              [AB]     1        builds that go straight to the far-field pair skip the x-planes without a filled voxel
  *
  *  host side / debugging
  *  "host_pack"               [U]      1        host-buffer builds classify on the host and upload 1 bit / voxel (0: upload + classify on

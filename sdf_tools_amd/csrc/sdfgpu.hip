@@ -118,6 +118,11 @@ struct sdfgpu_context {
     bool dense_generic_on = true;    // generic dense kernels for shapes / modes the tuned ones do not take
     bool shell_on = true;            // KD6, the bit-parallel shell pass between KD3 and KF (option "dense_shell")
     bool dc_fixed = true;            // far-field kernel: the 512-voxel-line instances (option "dc_fixed")
+    bool plane_skip = true;          // builds that go straight to the far-field pair: the z sweep marks the x-planes that hold a filled voxel,
+                                     // the y sweep skips the tiles of the others, the x sweep their row loads (option "plane_skip")
+    DeviceBuffer planebits;          // row_any [nx * ny] bytes, then plane_any [nx] bytes (see k_sweep_z_wave16 / EnvDcArgs)
+    bool last_plane_skip = false;    // the last build used it (sdfgpu_debug_copy_yzsweep fills the skipped planes in)
+    int64_t last_dims[3] = {0, 0, 0};
     bool dense3_fixed = true;        // KD3's nz = 512 instance (option "dense3_fixed")
     int shell_min_words = kShellMinWords;   // option "shell_min_words"
     int shell_budget_den = 8;        // ... for scenes with at most 1 / 8 of their voxels undecided behind KD3 (option "shell_budget_den"): Bernoulli
@@ -340,8 +345,14 @@ int rows_per_block(int nz) {
 }
 
 // K1 launch.  cells == nullptr -> uint8 mask.
+bool z_wave16_shape(const sdfgpu_context* h, int64_t nz) {
+    return h->z_wave_on && (nz == 64 || nz == 128 || nz == 256 || nz == 512 || nz == 1024);
+}
+
+// d_row_any != nullptr (callers check z_wave16_shape and, for masks, the alignment first): the kernel also writes one "holds a filled voxel" byte per z row
 int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, size_t stride, size_t off,
-                   int unknown, int64_t nx, int64_t ny, int64_t nz, int16_t* d_out, hipStream_t s, const uint32_t* d_bits = nullptr) {
+                   int unknown, int64_t nx, int64_t ny, int64_t nz, int16_t* d_out, hipStream_t s, const uint32_t* d_bits = nullptr,
+                   uint8_t* d_row_any = nullptr) {
     const int64_t nrows = nx * ny;
     if (d_bits) {
         // bits in (round 6): the wave-private form reads its 16 voxels as one 16-bit piece of the bit field; every other shape
@@ -352,11 +363,11 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
             dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), 8192)), block(kBlock);
             const uint8_t* b8 = reinterpret_cast<const uint8_t*>(d_bits);
             switch ((int)nz) {
-                case 64: hipLaunchKernelGGL((k_sweep_z_wave16<4, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
-                case 128: hipLaunchKernelGGL((k_sweep_z_wave16<8, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
-                case 256: hipLaunchKernelGGL((k_sweep_z_wave16<16, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
-                case 512: hipLaunchKernelGGL((k_sweep_z_wave16<32, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
-                default: hipLaunchKernelGGL((k_sweep_z_wave16<64, true>), gw, block, 0, s, b8, d_out, nrows, h->guard); break;
+                case 64: hipLaunchKernelGGL((k_sweep_z_wave16<4, true>), gw, block, 0, s, b8, d_out, nrows, h->guard, d_row_any); break;
+                case 128: hipLaunchKernelGGL((k_sweep_z_wave16<8, true>), gw, block, 0, s, b8, d_out, nrows, h->guard, d_row_any); break;
+                case 256: hipLaunchKernelGGL((k_sweep_z_wave16<16, true>), gw, block, 0, s, b8, d_out, nrows, h->guard, d_row_any); break;
+                case 512: hipLaunchKernelGGL((k_sweep_z_wave16<32, true>), gw, block, 0, s, b8, d_out, nrows, h->guard, d_row_any); break;
+                default: hipLaunchKernelGGL((k_sweep_z_wave16<64, true>), gw, block, 0, s, b8, d_out, nrows, h->guard, d_row_any); break;
             }
         } else {
             const int rpb = rows_per_block((int)nz);
@@ -398,11 +409,11 @@ int launch_sweep_z(sdfgpu_handle h, const uint8_t* d_mask, const void* d_cells, 
         const int64_t ngroups = (nrows + rw - 1) / rw;
         dim3 gw((unsigned)std::min<int64_t>((ngroups + kBlock / 64 - 1) / (kBlock / 64), 8192));
         switch ((int)nz) {
-            case 64: hipLaunchKernelGGL(k_sweep_z_wave16<4>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
-            case 128: hipLaunchKernelGGL(k_sweep_z_wave16<8>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
-            case 256: hipLaunchKernelGGL(k_sweep_z_wave16<16>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
-            case 512: hipLaunchKernelGGL(k_sweep_z_wave16<32>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
-            default: hipLaunchKernelGGL(k_sweep_z_wave16<64>, gw, block, 0, s, d_mask, d_out, nrows, h->guard); break;
+            case 64: hipLaunchKernelGGL((k_sweep_z_wave16<4, false>), gw, block, 0, s, d_mask, d_out, nrows, h->guard, d_row_any); break;
+            case 128: hipLaunchKernelGGL((k_sweep_z_wave16<8, false>), gw, block, 0, s, d_mask, d_out, nrows, h->guard, d_row_any); break;
+            case 256: hipLaunchKernelGGL((k_sweep_z_wave16<16, false>), gw, block, 0, s, d_mask, d_out, nrows, h->guard, d_row_any); break;
+            case 512: hipLaunchKernelGGL((k_sweep_z_wave16<32, false>), gw, block, 0, s, d_mask, d_out, nrows, h->guard, d_row_any); break;
+            default: hipLaunchKernelGGL((k_sweep_z_wave16<64, false>), gw, block, 0, s, d_mask, d_out, nrows, h->guard, d_row_any); break;
         }
     } else if ((nz % 16) == 0 && (reinterpret_cast<uintptr_t>(d_mask) % 16) == 0) {
         hipLaunchKernelGGL(k_sweep_z_vec16, grid, block, lds, s, d_mask, d_out, nrows, (int)nz, rpb, h->guard);
@@ -599,6 +610,8 @@ struct DcExtra {                 // int32 plane fields instead of p16 + side tab
     const uint32_t* bits = nullptr;         // stage 2: z distances from the dense tier's bit field instead of the z field (forces the scalar form)
     int nzw = 0;
     uint32_t* ran_flag = nullptr;           // status word raised by a launch that does work
+    const uint8_t* row_any = nullptr;       // plane sparsity (see EnvDcArgs); nullptr: every plane is processed
+    uint8_t* plane_any = nullptr;
     uint32_t* fold_result = nullptr;        // stage 3, LOOP form: the launch also does the end-of-build fold (fold_ticket = a free status word)
     uint32_t* fold_report = nullptr;
     uint32_t* fold_ticket = nullptr;
@@ -653,6 +666,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
             a.ran_flag = ex->ran_flag;
+            if (!probe_out) { a.row_any = ex->row_any; a.plane_any = ex->plane_any; a.some_empty = h->d_small + 22; }
             if (stage == 2) { a.bits = ex->bits; a.nzw = ex->nzw; }
             if (stage == 3 && ex->loop && ex->fold_ticket && !probe_out) {
                 a.fold_status = h->d_small; a.fold_result = ex->fold_result; a.fold_report = ex->fold_report; a.fold_ticket = ex->fold_ticket;
@@ -1097,6 +1111,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     // d_small[3] otherwise, in which case (and only then) the general pipeline below does any work.
     bool cur_fix_mode = false, cur_dense3 = false, cur_staged = false;
     const uint32_t* dense_bits = nullptr;                       // the bit field the tuned dense kernels (and the stand-by y sweep) read
+    uint8_t* row_any = nullptr;                                 // plane sparsity: one byte per z row, one per x-plane behind them (predicted far-field builds)
     h->last_dense = dense;
     h->guard = nullptr;
     if (dense && dense_generic) {
@@ -1153,10 +1168,19 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     h->far_y = (envelope && !fused) ? h->d_small + 4 : nullptr;
     h->scan_y = h->scan_x = kScanExpectNear;
     if (!fused && !standby) {                                   // (the stand-by pair takes its z distances from the bit field)
+        // a build that goes straight to the far-field pair lets the z sweep mark the x-planes that hold a filled voxel at all: a sensed
+        // scene leaves most planes without one, and the pair skips them (y sweep: the planes' tiles; x sweep: their row loads)
+        if (predicted && h->plane_skip && nx >= 8 && z_wave16_shape(h, nz) && !d_cells &&
+            (d_bits_in || (reinterpret_cast<uintptr_t>(d_filled) % 16) == 0)) {
+            if (int rc = ensure(h, h->planebits, (size_t)(nx * ny + nx), "row / x-plane occupancy flags")) return rc;
+            row_any = (uint8_t*)h->planebits.ptr;
+        }
         if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
-                                    (int16_t*)h->zfield.ptr, s, d_bits_in)) return rc;
+                                    (int16_t*)h->zfield.ptr, s, d_bits_in, row_any)) return rc;
         launched_since_mark = true;
     }
+    h->last_plane_skip = row_any != nullptr;
+    h->last_dims[0] = nx; h->last_dims[1] = ny; h->last_dims[2] = nz;
     HIP_TRY(h, mark(3));
     // y sweep: marching (bounded scan, may raise far_y) + guarded envelope, or the envelope kernel alone
     const uint32_t* const general_guard = h->guard;           // nullptr, or "the dense tier left voxels undecided"
@@ -1201,6 +1225,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         DcExtra pr2 = plain2, pr3 = plain3;
         pr2.ran_flag = h->d_small + 4;
         pr3.ran_flag = h->d_small + 5;
+        pr2.row_any = row_any; pr2.plane_any = pr3.plane_any = row_any ? row_any + nx * ny : nullptr;
         HIP_TRY(h, mark(4));                                    // (stage slot 3, the marching y sweep: nothing launched)
         if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nx, ny, nz, resolution, vb,
                                      h->d_small, general_guard, s, 0, nullptr, &pr2)) return rc;
@@ -1633,7 +1658,7 @@ int sdfgpu_destroy(sdfgpu_handle h) {
     if (!h) return SDFGPU_OK;
     (void)hipSetDevice(h->device);
     for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->unc, &h->tileflag, &h->fix_order, &h->tagmask, &h->tagids, &h->stage_in,
-                            &h->stage_bits, &h->stage_out, &h->query_stage})
+                            &h->stage_bits, &h->stage_out, &h->query_stage, &h->planebits})
         if (b->ptr) (void)rz_free(h, b->ptr);
     if (h->d_small) (void)rz_free(h, h->d_small);
     if (h->d_slots) (void)rz_free(h, h->d_slots);
@@ -2379,6 +2404,14 @@ int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->order_valid) HIP_TRY(h, hipEventSynchronize(h->build_done_ev));
     HIP_TRY(h, hipMemcpy(out_host, h->yzfield.ptr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (h->last_plane_skip && h->planebits.ptr && n == h->last_dims[0] * h->last_dims[1] * h->last_dims[2]) {
+        // the y sweep skipped the x-planes without a filled voxel: every voxel of such a plane is "free, no filled voxel in the plane"
+        std::vector<uint8_t> pa((size_t)h->last_dims[0]);
+        HIP_TRY(h, hipMemcpy(pa.data(), (const uint8_t*)h->planebits.ptr + h->last_dims[0] * h->last_dims[1], pa.size(), hipMemcpyDeviceToHost));
+        const int64_t plane = h->last_dims[1] * h->last_dims[2];
+        for (int64_t x = 0; x < h->last_dims[0]; ++x)
+            if (!pa[(size_t)x]) std::fill(out_host + x * plane, out_host + (x + 1) * plane, (int32_t)kInf32);
+    }
     uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // status block of the last build ([7]: int32 hand-off used)
     HIP_TRY(h, hipMemcpy(st, h->d_result, sizeof st, hipMemcpyDeviceToHost));
     if (h->last_plane16 && st[7] == 0u && !h->last_predicted) {
@@ -2473,13 +2506,14 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
     else if (n == "dense_shell") h->shell_on = value != 0;
     else if (n == "dc_fixed") h->dc_fixed = value != 0;
+    else if (n == "plane_skip") h->plane_skip = value != 0;
     else if (n == "redzone") {
         // from now on: every buffer the context holds is released (and comes back with -- or without -- zones when it is next needed);
         // the status block and the slots are replaced at once
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipDeviceSynchronize());
         for (DeviceBuffer* b : {&h->zfield, &h->yzfield, &h->plane16, &h->bits, &h->unc, &h->tileflag, &h->fix_order, &h->tagmask, &h->tagids, &h->stage_in,
-                                &h->stage_bits, &h->stage_out, &h->query_stage})
+                                &h->stage_bits, &h->stage_out, &h->query_stage, &h->planebits})
             if (b->ptr) { (void)rz_free(h, b->ptr); b->ptr = nullptr; b->bytes = 0; }
         h->tag_cached_bytes = 0;
         (void)rz_free(h, h->d_small);

@@ -121,6 +121,13 @@ struct EnvDcArgs {
     uint32_t* fold_report;
     uint32_t* fold_ticket;
     uint32_t fold_report_mask;
+    // round 6, plane sparsity (builds that go straight to the far-field pair; nullptr = no such knowledge): row_any[x * ny + y] = z row
+    // (x, y) holds a filled voxel (written by the z sweep in front).  STAGE 2 ORs the ny bytes of its tile's x-plane: a plane without a
+    // filled voxel is skipped -- its result, "free, no filled voxel in this plane" everywhere, is not written -- and the plane's first
+    // tile records the verdict in plane_any[x]; STAGE 3 takes exactly that value for the rows of such planes instead of loading them.
+    const uint8_t* row_any;
+    uint8_t* plane_any;
+    uint32_t* some_empty;     // status word STAGE 2 raises when it skips a plane: a scene without one (walls) costs STAGE 3 no look-ups at all
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -451,6 +458,8 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         }
     }
     const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
+    // plane sparsity: the y sweep in front skipped at least one x-plane (launch-uniform; its launch is complete)
+    const bool planes = STAGE == 3 && a.plane_any && __hip_atomic_load(a.some_empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
     if (a.probe_stride > 0 && STAGE == 3 && a.decide_small &&
         __hip_atomic_load(a.decide_small + 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { probe_done(a); return; }   // ... settled by the y probe
@@ -491,6 +500,16 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     }
     const int64_t o = tile / a.tiles_per_outer;
     const int64_t c0 = (tile - o * a.tiles_per_outer) * NL;
+    if constexpr (STAGE == 2) {
+        // an x-plane without a single filled voxel: every voxel of it is free with no site in its plane, and the x sweep will know
+        if (a.row_any) {
+            int any = 0;
+            for (int y = threadIdx.x; y < a.L; y += NT) any |= a.row_any[o * a.L + y];
+            any = __syncthreads_or(any);                        // (block-uniform from here)
+            if (c0 == 0 && threadIdx.x == 0) { a.plane_any[o] = any ? 1 : 0; if (!any) raise_flag(a.some_empty); }
+            if (!any) { if constexpr (LOOP) continue; else return; }
+        }
+    }
     const int nvalid = (int)min((int64_t)NL, a.group_lines - c0);     // lines of this tile that exist
     const int64_t base = o * a.outer_stride + c0;               // element index of (line 0, position 0)
     const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
@@ -519,6 +538,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     // exact signed value of voxel q of `line`, re-read from global memory (rare paths only)
     auto raw_signed = [&](int line, int q) -> int {
         const uint32_t idx = (uint32_t)line + (uint32_t)q * ls;
+        if (STAGE == 3 && planes && a.plane_any[q] == 0) return kInf32;     // (a plane the y sweep skipped)
         if (STAGE == 3 && in32) return in32[idx];
         int v;
         if (STAGE == 2 && !VEC && a.bits) v = zdist_from_bits(a.bits + (o * a.ny + q) * a.nzw, a.nzw, (int)a.nz, (int)c0 + line);
@@ -655,13 +675,25 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         uint32_t mt = 0xFFFFFFFFu;                              // smallest site value seen by this lane
         for (int pb = 0; pb < L; pb += PP * NB) {
             int sv[NB][4];
+            // STAGE 3 behind a y sweep that skipped the planes without a filled voxel: the verdicts of this lane's rows, requested before
+            // the row loads (all "present" without that knowledge)
+            uint32_t pw[NB];
+#pragma unroll
+            for (int it = 0; it < NB; ++it) {
+                pw[it] = 1u;
+                if constexpr (STAGE == 3) {
+                    const int prow = imin(pb + PP * it + r, L - 1);
+                    if (planes) pw[it] = a.plane_any[prow];
+                }
+            }
 #pragma unroll
             for (int it = 0; it < NB; ++it) {
                 // (rows past the end of the line re-read the last row; their keys are not written)
                 const uint32_t off = (pb + PP * it + r < L) ? off_r + (uint32_t)(pb + PP * it) * ls : off_last;
                 if constexpr (VEC) {
                     if (STAGE == 3 && in32) {
-                        const int4 e = *reinterpret_cast<const int4*>(in32 + off);
+                        int4 e = make_int4(kInf32, kInf32, kInf32, kInf32);
+                        if (pw[it] & 1u) e = *reinterpret_cast<const int4*>(in32 + off);
                         sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
                     } else {
                         const uint2 raw = *reinterpret_cast<const uint2*>(in16 + off);
@@ -685,7 +717,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t idx = off - 4u * sub + (uint32_t)lsel[k];
                         int v;
-                        if (STAGE == 3 && in32) v = in32[idx];
+                        if (STAGE == 3 && in32) v = (pw[it] & 1u) ? in32[idx] : kInf32;
                         else {
                             v = in16[idx];
                             if constexpr (STAGE == 3) if (abs(v) >= kSat16) v = side_in[idx];
