@@ -120,7 +120,7 @@ struct sdfgpu_context {
     bool dc_fixed = true;            // far-field kernel: the 512-voxel-line instances (option "dc_fixed")
     bool plane_skip = true;          // builds that go straight to the far-field pair: the z sweep marks the x-planes that hold a filled voxel,
                                      // the y sweep skips the tiles of the others, the x sweep their row loads (option "plane_skip")
-    DeviceBuffer planebits;          // row_any [nx * ny] bytes, then plane_any [nx] bytes (see k_sweep_z_wave16 / EnvDcArgs)
+    DeviceBuffer planebits;          // row_any [nx * ny] bytes | plane_any [nx] bytes | row_bits [nx][ceil(ny / 32)] words (k_sweep_z_wave16, k_pack_row_flags, EnvDcArgs)
     bool last_plane_skip = false;    // the last build used it (sdfgpu_debug_copy_yzsweep fills the skipped planes in)
     int64_t last_dims[3] = {0, 0, 0};
     bool dense3_fixed = true;        // KD3's nz = 512 instance (option "dense3_fixed")
@@ -610,8 +610,9 @@ struct DcExtra {                 // int32 plane fields instead of p16 + side tab
     const uint32_t* bits = nullptr;         // stage 2: z distances from the dense tier's bit field instead of the z field (forces the scalar form)
     int nzw = 0;
     uint32_t* ran_flag = nullptr;           // status word raised by a launch that does work
-    const uint8_t* row_any = nullptr;       // plane sparsity (see EnvDcArgs); nullptr: every plane is processed
-    uint8_t* plane_any = nullptr;
+    const uint32_t* row_bits = nullptr;     // plane sparsity (see EnvDcArgs); nullptr: every plane is processed
+    int row_words = 0;
+    const uint8_t* plane_any = nullptr;
     uint32_t* fold_result = nullptr;        // stage 3, LOOP form: the launch also does the end-of-build fold (fold_ticket = a free status word)
     uint32_t* fold_report = nullptr;
     uint32_t* fold_ticket = nullptr;
@@ -666,7 +667,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
             a.ran_flag = ex->ran_flag;
-            if (!probe_out) { a.row_any = ex->row_any; a.plane_any = ex->plane_any; a.some_empty = h->d_small + 22; }
+            if (!probe_out) { a.row_bits = ex->row_bits; a.row_words = ex->row_words; a.plane_any = ex->plane_any; a.some_empty = h->d_small + 22; }
             if (stage == 2) { a.bits = ex->bits; a.nzw = ex->nzw; }
             if (stage == 3 && ex->loop && ex->fold_ticket && !probe_out) {
                 a.fold_status = h->d_small; a.fold_result = ex->fold_result; a.fold_report = ex->fold_report; a.fold_ticket = ex->fold_ticket;
@@ -1170,9 +1171,10 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
     if (!fused && !standby) {                                   // (the stand-by pair takes its z distances from the bit field)
         // a build that goes straight to the far-field pair lets the z sweep mark the x-planes that hold a filled voxel at all: a sensed
         // scene leaves most planes without one, and the pair skips them (y sweep: the planes' tiles; x sweep: their row loads)
-        if (predicted && h->plane_skip && nx >= 8 && z_wave16_shape(h, nz) && !d_cells &&
+        if (predicted && h->plane_skip && nx >= 8 && ny <= 1024 && z_wave16_shape(h, nz) && !d_cells &&
             (d_bits_in || (reinterpret_cast<uintptr_t>(d_filled) % 16) == 0)) {
-            if (int rc = ensure(h, h->planebits, (size_t)(nx * ny + nx), "row / x-plane occupancy flags")) return rc;
+            const size_t o_bits = ((size_t)(nx * ny + nx) + 255) & ~(size_t)255;
+            if (int rc = ensure(h, h->planebits, o_bits + (size_t)nx * ((ny + 31) / 32) * 4, "row / x-plane occupancy flags")) return rc;
             row_any = (uint8_t*)h->planebits.ptr;
         }
         if (int rc = launch_sweep_z(h, d_filled, d_cells, stride, off, unknown, nx, ny, nz,
@@ -1225,7 +1227,15 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
         DcExtra pr2 = plain2, pr3 = plain3;
         pr2.ran_flag = h->d_small + 4;
         pr3.ran_flag = h->d_small + 5;
-        pr2.row_any = row_any; pr2.plane_any = pr3.plane_any = row_any ? row_any + nx * ny : nullptr;
+        if (row_any) {
+            // row bytes -> one bit per row, one byte per x-plane, "some plane is empty" (status word 22)
+            uint8_t* plane_any = row_any + nx * ny;
+            uint32_t* row_bits = (uint32_t*)(row_any + (((size_t)(nx * ny + nx) + 255) & ~(size_t)255));
+            const int row_words = (int)((ny + 31) / 32);
+            hipLaunchKernelGGL(k_pack_row_flags, dim3((unsigned)nx), dim3(256), 0, s, row_any, (int)ny, row_words, row_bits, plane_any, h->d_small + 22);
+            HIP_TRY(h, hipGetLastError());
+            pr2.row_bits = row_bits; pr2.row_words = row_words; pr2.plane_any = pr3.plane_any = plane_any;
+        }
         HIP_TRY(h, mark(4));                                    // (stage slot 3, the marching y sweep: nothing launched)
         if (int rc = launch_envelope(h, 2, (const int16_t*)h->zfield.ptr, nullptr, nullptr, nullptr, nx, ny, nz, resolution, vb,
                                      h->d_small, general_guard, s, 0, nullptr, &pr2)) return rc;
@@ -2395,6 +2405,14 @@ int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->order_valid) HIP_TRY(h, hipEventSynchronize(h->build_done_ev));
     HIP_TRY(h, hipMemcpy(out_host, h->zfield.ptr, (size_t)n * 2, hipMemcpyDeviceToHost));
+    if (h->last_plane_skip && h->planebits.ptr && n == h->last_dims[0] * h->last_dims[1] * h->last_dims[2]) {
+        // the z sweep of a build that went straight to the far-field pair does not write rows without a filled voxel
+        const int64_t nrows = h->last_dims[0] * h->last_dims[1], nz = h->last_dims[2];
+        std::vector<uint8_t> ra((size_t)nrows);
+        HIP_TRY(h, hipMemcpy(ra.data(), h->planebits.ptr, ra.size(), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < nrows; ++r)
+            if (!ra[(size_t)r]) std::fill(out_host + r * nz, out_host + (r + 1) * nz, (int16_t)kInf16);
+    }
     return SDFGPU_OK;
 }
 

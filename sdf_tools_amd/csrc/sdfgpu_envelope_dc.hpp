@@ -121,12 +121,16 @@ struct EnvDcArgs {
     uint32_t* fold_report;
     uint32_t* fold_ticket;
     uint32_t fold_report_mask;
-    // round 6, plane sparsity (builds that go straight to the far-field pair; nullptr = no such knowledge): row_any[x * ny + y] = z row
-    // (x, y) holds a filled voxel (written by the z sweep in front).  STAGE 2 ORs the ny bytes of its tile's x-plane: a plane without a
-    // filled voxel is skipped -- its result, "free, no filled voxel in this plane" everywhere, is not written -- and the plane's first
-    // tile records the verdict in plane_any[x]; STAGE 3 takes exactly that value for the rows of such planes instead of loading them.
-    const uint8_t* row_any;
-    uint8_t* plane_any;
+    // round 6, plane sparsity (builds that go straight to the far-field pair; nullptr = no such knowledge).  The z sweep in front writes
+    // one byte per z row -- "holds a filled voxel" -- and does NOT write the z field of rows without one; k_pack_row_flags packs the bytes
+    // to one bit per row, one byte per x-plane and a "some plane is empty" status word.  STAGE 2 skips the tiles of planes without a filled
+    // voxel (their result, "free, no filled voxel in this plane" everywhere, is not written) and takes "+32767" for rows without one
+    // instead of loading them -- the plane's mask comes through SCALAR loads (16 words at ny = 512): a first form with per-lane byte
+    // loads put a vector-memory round trip in front of every tile's row loads (+6 % on a scene that has no such row).  STAGE 3 takes
+    // "no site" for the rows of skipped planes instead of loading them, and looks nothing up when no plane was skipped.
+    const uint32_t* row_bits; // (packed by k_pack_row_flags: [x][row_words] words, bit y & 31 of word y >> 5 = z row (x, y) holds a filled voxel)
+    int row_words;
+    const uint8_t* plane_any; // [x]: 0 = x-plane x holds no filled voxel, 1 = some of its z rows do, 2 = every z row does
     uint32_t* some_empty;     // status word STAGE 2 raises when it skips a plane: a scene without one (walls) costs STAGE 3 no look-ups at all
 };
 
@@ -247,6 +251,32 @@ __device__ __forceinline__ int zdist_from_row(const ZRowBits& r, int w0, int nz,
     if (zu < nz) best = zu - z;
     if (zd >= 0 && z - zd < best) best = z - zd;
     return own ? -best : best;
+}
+
+// Plane sparsity, between the z sweep and the far-field y sweep: one workgroup per x-plane packs the plane's row bytes (row_any[x * ny + y])
+// into ceil(ny / 32) words, sums them up in plane_any[x] (0 / 1 / 2, below) and raises *some_empty for a plane without a filled voxel.
+SDFGPU_KERNEL __launch_bounds__(256) void k_pack_row_flags(const uint8_t* __restrict__ row_any, int ny, int row_words, uint32_t* __restrict__ row_bits,
+                                                         uint8_t* __restrict__ plane_any, uint32_t* __restrict__ some_empty) {
+    const int x = blockIdx.x, t = threadIdx.x;
+    int any = 0, hole = 0;
+    for (int y0 = 0; y0 < 32 * row_words; y0 += 256) {
+        const int y = y0 + t;
+        const int f = (y < ny) ? (row_any[(int64_t)x * ny + y] != 0) : 0;
+        const uint64_t b = __ballot(f);
+        any |= f;
+        hole |= (y < ny && !f) ? 1 : 0;
+        if ((t & 63) == 0) {
+            const int w = y >> 5;
+            if (w < row_words) row_bits[(int64_t)x * row_words + w] = (uint32_t)b;
+            if (w + 1 < row_words) row_bits[(int64_t)x * row_words + w + 1] = (uint32_t)(b >> 32);
+        }
+    }
+    any = __syncthreads_or(any);
+    hole = __syncthreads_or(hole);
+    // 0: no filled voxel in the plane; 1: some of its rows hold one; 2: every row does (a floor, a wall: the row mask has nothing to say)
+    // some_empty[0]: a plane without a filled voxel exists (the x sweep then looks planes up); some_empty[-3] (status word 19): a row
+    // without one exists (the y sweep then looks at plane_any / the row masks at all: a scene of floors and walls never does)
+    if (t == 0) { plane_any[x] = !any ? 0 : hole ? 1 : 2; if (!any) raise_flag(some_empty); if (hole) raise_flag(some_empty - 3); }
 }
 
 constexpr int kDcLines = 16;          // lines per tile (the kernel is a template over 8 / 16 lines and 128 / 256 / 512 lanes: 16 x 256 is the measured optimum)
@@ -460,6 +490,8 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     const bool i32 = !a.i32_flag || *a.i32_flag != 0u;        // (block-uniform)
     // plane sparsity: the y sweep in front skipped at least one x-plane (launch-uniform; its launch is complete)
     const bool planes = STAGE == 3 && a.plane_any && __hip_atomic_load(a.some_empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    // ... STAGE 2: the z sweep in front left at least one z row unwritten (k_pack_row_flags raises status word 19)
+    const bool rows_known = STAGE == 2 && a.row_bits && __hip_atomic_load(a.some_empty - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
     if (a.probe_stride > 0 && STAGE == 3 && a.decide_small &&
         __hip_atomic_load(a.decide_small + 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { probe_done(a); return; }   // ... settled by the y probe
@@ -500,14 +532,37 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     }
     const int64_t o = tile / a.tiles_per_outer;
     const int64_t c0 = (tile - o * a.tiles_per_outer) * NL;
+    uint32_t rwm = 0xFFFFFFFFu;             // STAGE 2, plane sparsity: bit j = the j-th row this lane stages holds a filled voxel
+    bool masked = false;                    // ... and some bit of the tile is clear (block-uniform); STAGE 3: some x-plane was skipped
     if constexpr (STAGE == 2) {
         // an x-plane without a single filled voxel: every voxel of it is free with no site in its plane, and the x sweep will know
-        if (a.row_any) {
-            int any = 0;
-            for (int y = threadIdx.x; y < a.L; y += NT) any |= a.row_any[o * a.L + y];
-            any = __syncthreads_or(any);                        // (block-uniform from here)
-            if (c0 == 0 && threadIdx.x == 0) { a.plane_any[o] = any ? 1 : 0; if (!any) raise_flag(a.some_empty); }
-            if (!any) { if constexpr (LOOP) continue; else return; }
+        if (rows_known) {
+            const int pstate = a.plane_any[o];                  // (block-uniform, a scalar load)
+            if (pstate == 0) { if constexpr (LOOP) continue; else return; }
+            masked = pstate == 1;                               // (2: every row holds a filled voxel -- nothing to look up, nothing to replace)
+            // the plane's row mask through scalar loads (uniform address), then one bit per row this lane will stage: row PP * j + t / LPR
+            constexpr int kLPR = NL / 4, kPP = NT / kLPR, kWPJ = kPP / 32;       // words of the mask per staging step (2 at 256 lanes, 4 at 512)
+            static_assert(kPP % 32 == 0, "a staging step covers whole mask words");
+            const uint32_t* __restrict__ pm = a.row_bits + o * a.row_words;
+            const int r0 = (int)threadIdx.x / kLPR, q0 = r0 >> 5, b0 = r0 & 31;
+            if (masked) rwm = 0u;
+#pragma unroll
+            for (int j = 0; j < 32 / kWPJ; ++j) {                              // (up to 32 mask words = lines of up to 1024 voxels)
+                if (masked && j * kPP < a.L) {
+                    uint32_t word = 0u;
+#pragma unroll
+                    for (int q = 0; q < kWPJ; ++q) {
+                        const int wi = kWPJ * j + q;                            // (a compile-time index: the word sits in a scalar register)
+                        const uint32_t m = wi < a.row_words ? pm[wi] : 0u;
+                        word = q0 == q ? m : word;
+                    }
+                    // (rows past the end of the line re-read the last row when they are staged: give them its bit)
+                    const int last = a.L - 1;
+                    const uint32_t lastbit = (pm[last >> 5] >> (last & 31)) & 1u;
+                    const uint32_t bit = (kPP * j + r0 < a.L) ? ((word >> b0) & 1u) : lastbit;
+                    rwm |= bit << j;
+                }
+            }
         }
     }
     const int nvalid = (int)min((int64_t)NL, a.group_lines - c0);     // lines of this tile that exist
@@ -542,6 +597,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         if (STAGE == 3 && in32) return in32[idx];
         int v;
         if (STAGE == 2 && !VEC && a.bits) v = zdist_from_bits(a.bits + (o * a.ny + q) * a.nzw, a.nzw, (int)a.nz, (int)c0 + line);
+        else if (STAGE == 2 && rows_known && ((a.row_bits[o * a.row_words + (q >> 5)] >> (q & 31)) & 1u) == 0u) v = kInf16;   // (a row the z sweep did not write: all free)
         else v = in16[idx];
         if constexpr (STAGE == 2) {
             const int g = abs(v);
@@ -666,6 +722,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         // A lane reads 4 lines x 1 position per load (VEC: one 8 / 16-byte load), NB loads in flight, and writes the
         // four keys.
         const int sub = t & (LPR - 1), r = t / LPR;
+        const bool sparse = STAGE == 3 ? planes : masked;       // plane sparsity has something to say about this tile's rows (block-uniform)
         uint32_t* const kb = keys + (4 * sub) * pitch + r;
         int lsel[4];
 #pragma unroll
@@ -675,15 +732,19 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         uint32_t mt = 0xFFFFFFFFu;                              // smallest site value seen by this lane
         for (int pb = 0; pb < L; pb += PP * NB) {
             int sv[NB][4];
-            // STAGE 3 behind a y sweep that skipped the planes without a filled voxel: the verdicts of this lane's rows, requested before
-            // the row loads (all "present" without that knowledge)
+            // plane sparsity: the verdicts of this lane's rows -- STAGE 3: the row's x-plane holds a filled voxel (the y sweep skipped the
+            // others), STAGE 2: the z row does (the z sweep did not write the others) -- requested before the row loads (all "present"
+            // without that knowledge)
             uint32_t pw[NB];
 #pragma unroll
             for (int it = 0; it < NB; ++it) {
                 pw[it] = 1u;
+                const int prow = imin(pb + PP * it + r, L - 1);
                 if constexpr (STAGE == 3) {
-                    const int prow = imin(pb + PP * it + r, L - 1);
-                    if (planes) pw[it] = a.plane_any[prow];
+                    if (planes) pw[it] = a.plane_any[prow] != 0;
+                } else {
+                    pw[it] = rwm >> ((pb / PP) + it);                       // STAGE 2: z rows without a filled voxel were not written
+                    (void)prow;
                 }
             }
 #pragma unroll
@@ -691,12 +752,15 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 // (rows past the end of the line re-read the last row; their keys are not written)
                 const uint32_t off = (pb + PP * it + r < L) ? off_r + (uint32_t)(pb + PP * it) * ls : off_last;
                 if constexpr (VEC) {
+                    // (plane sparsity: a lane whose row is known -- an x-plane / z row without a filled voxel -- does not branch around its
+                    //  load, which would put a wait behind every one of the NB loads: it loads the tile's first row instead, one cached
+                    //  line for all such lanes, and the value is replaced below)
+                    const uint32_t offl = (!sparse || (pw[it] & 1u)) ? off : 4u * (uint32_t)sub;
                     if (STAGE == 3 && in32) {
-                        int4 e = make_int4(kInf32, kInf32, kInf32, kInf32);
-                        if (pw[it] & 1u) e = *reinterpret_cast<const int4*>(in32 + off);
+                        const int4 e = *reinterpret_cast<const int4*>(in32 + offl);
                         sv[it][0] = e.x; sv[it][1] = e.y; sv[it][2] = e.z; sv[it][3] = e.w;
                     } else {
-                        const uint2 raw = *reinterpret_cast<const uint2*>(in16 + off);
+                        const uint2 raw = *reinterpret_cast<const uint2*>(in16 + offl);
                         sv[it][0] = (int)raw.x; sv[it][1] = (int)raw.y;         // (unpacked below, once every row is requested)
                     }
                 } else if (STAGE == 2 && a.bits) {
@@ -718,6 +782,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         const uint32_t idx = off - 4u * sub + (uint32_t)lsel[k];
                         int v;
                         if (STAGE == 3 && in32) v = (pw[it] & 1u) ? in32[idx] : kInf32;
+                        else if (STAGE == 2 && !(pw[it] & 1u)) v = kInf16;
                         else {
                             v = in16[idx];
                             if constexpr (STAGE == 3) if (abs(v) >= kSat16) v = side_in[idx];
@@ -728,7 +793,18 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             }
             if (pb == 0) __syncthreads();                       // args / misc initialised (the loads above are in flight meanwhile)
             if constexpr (VEC) {
-                if (!(STAGE == 3 && in32)) {
+                if (STAGE == 3 && in32) {
+                    if (sparse) {                               // (block-uniform)
+#pragma unroll
+                        for (int it = 0; it < NB; ++it)
+                            if (!(pw[it] & 1u)) { sv[it][0] = kInf32; sv[it][1] = kInf32; sv[it][2] = kInf32; sv[it][3] = kInf32; }
+                    }
+                } else {
+                    if (STAGE == 2 && sparse) {                 // (block-uniform)
+#pragma unroll
+                        for (int it = 0; it < NB; ++it)
+                            if (!(pw[it] & 1u)) { sv[it][0] = (int)0x7fff7fffu; sv[it][1] = (int)0x7fff7fffu; }     // +32767 x 4
+                    }
 #pragma unroll
                     for (int it = 0; it < NB; ++it) {
                         const uint32_t rx = (uint32_t)sv[it][0], ry = (uint32_t)sv[it][1];

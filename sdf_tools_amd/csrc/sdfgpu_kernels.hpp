@@ -372,7 +372,8 @@ __device__ __forceinline__ uint32_t pk_neg_i16(uint32_t a) {
 // row_any != nullptr (round 6, builds that go straight to the far-field pair): row_any[row] = the row holds a filled voxel, one byte per
 // z row, written for EVERY row (nothing to clear, no atomics: a first form that raised one bit per x-plane with an atomic OR put
 // 262 144 same-address accesses into the room scene's z sweep -- 0.09 -> 2.1 ms).  The far-field y sweep ORs the bytes of its
-// x-plane and skips planes without a filled voxel; the x sweep then skips their row loads.
+// x-plane and skips planes without a filled voxel; the x sweep then skips their row loads.  Rows without a filled voxel are NOT
+// written to the z field then (the y sweep takes "+32767 everywhere" from the byte).
 template <int CPR, bool BITS = false>
 __global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __restrict__ mask, int16_t* __restrict__ out,
                                                           int64_t nrows, const uint32_t* __restrict__ guard,
@@ -414,7 +415,9 @@ __global__ __launch_bounds__(kBlock) void k_sweep_z_wave16(const uint8_t* __rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (valid) {
+        // (with row_any the consumer is the far-field y sweep, which takes "+32767 everywhere" from the row's byte: an all-free row --
+        //  nearly every row of a sensed scene -- is not written at all)
+        if (valid && !(row_any && !anyF)) {
             uint4* dst = reinterpret_cast<uint4*>(out + rr * nz + 16 * c);
             if (!(anyF && anyE)) {
                 const uint32_t u = anyE ? 0x7fff7fffu : 0x80018001u;       // +32767 (all free) / -32767 (all filled)
