@@ -802,6 +802,13 @@ def main():
                 torch, capi, dev, shape, res, room, {}, leg_steps, 10,
                 "%dx%dx%d room scene (floor + two walls 2 %% of the grid thick, table on legs, shelf; 6.9 %% filled), default policy" % shape)
             del room
+            # ... and obstacles in OPEN space (the reference's tutorial boxes, src/sdf_tools_tutorial.cpp:45-59, scaled to the grid): most
+            # x-planes and z rows hold no filled voxel, which the far-field pair skips (round 6, option plane_skip)
+            boxes = [synth.tutorial_boxes_mask_torch(shape, dev, True)]
+            legs["structured_boxes"] = run_leg(
+                torch, capi, dev, shape, res, boxes, {}, leg_steps, 10,
+                "%dx%dx%d solid boxes in open space (the tutorial scene scaled to the grid), default policy" % shape)
+            del boxes
             if shape == (512, 512, 512):
                 legs["streaming_two_box"] = streaming_leg(torch, dev, 512, 0.01, 30)
             # BASELINE.json configs[1] / BASELINE.md section 3: 256^3, fp32 distances, single MI355X -- "throughput reported"

@@ -1232,7 +1232,7 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
             uint8_t* plane_any = row_any + nx * ny;
             uint32_t* row_bits = (uint32_t*)(row_any + (((size_t)(nx * ny + nx) + 255) & ~(size_t)255));
             const int row_words = (int)((ny + 31) / 32);
-            hipLaunchKernelGGL(k_pack_row_flags, dim3((unsigned)nx), dim3(256), 0, s, row_any, (int)ny, row_words, row_bits, plane_any, h->d_small + 22);
+            hipLaunchKernelGGL(k_pack_row_flags, dim3((unsigned)std::min<int64_t>((nx + 15) / 16, 16)), dim3(1024), 0, s, row_any, (int)nx, (int)ny, row_words, row_bits, plane_any, h->d_small + 22);
             HIP_TRY(h, hipGetLastError());
             pr2.row_bits = row_bits; pr2.row_words = row_words; pr2.plane_any = pr3.plane_any = plane_any;
         }

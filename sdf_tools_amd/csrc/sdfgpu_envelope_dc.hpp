@@ -253,30 +253,50 @@ __device__ __forceinline__ int zdist_from_row(const ZRowBits& r, int w0, int nz,
     return own ? -best : best;
 }
 
-// Plane sparsity, between the z sweep and the far-field y sweep: one workgroup per x-plane packs the plane's row bytes (row_any[x * ny + y])
+// Plane sparsity, between the z sweep and the far-field y sweep: packs every x-plane's row bytes (row_any[x * ny + y])
 // into ceil(ny / 32) words, sums them up in plane_any[x] (0 / 1 / 2, below) and raises *some_empty for a plane without a filled voxel.
-SDFGPU_KERNEL __launch_bounds__(256) void k_pack_row_flags(const uint8_t* __restrict__ row_any, int ny, int row_words, uint32_t* __restrict__ row_bits,
+SDFGPU_KERNEL __launch_bounds__(1024) void k_pack_row_flags(const uint8_t* __restrict__ row_any, int nx, int ny, int row_words, uint32_t* __restrict__ row_bits,
                                                          uint8_t* __restrict__ plane_any, uint32_t* __restrict__ some_empty) {
-    const int x = blockIdx.x, t = threadIdx.x;
-    int any = 0, hole = 0;
-    for (int y0 = 0; y0 < 32 * row_words; y0 += 256) {
-        const int y = y0 + t;
-        const int f = (y < ny) ? (row_any[(int64_t)x * ny + y] != 0) : 0;
-        const uint64_t b = __ballot(f);
-        any |= f;
-        hole |= (y < ny && !f) ? 1 : 0;
-        if ((t & 63) == 0) {
-            const int w = y >> 5;
-            if (w < row_words) row_bits[(int64_t)x * row_words + w] = (uint32_t)b;
-            if (w + 1 < row_words) row_bits[(int64_t)x * row_words + w + 1] = (uint32_t)(b >> 32);
+    // a WAVE per x-plane at a time, 16 waves per workgroup, at most 16 workgroups: the two status words see one store per WORKGROUP.
+    // (Device-scope stores to one address cost ~28 ns each: forms with a store per plane or per wave -- 512 to 1024 of them -- took
+    //  20 - 29 us at 512^3, whatever else the kernel did.)
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 16 + (threadIdx.x >> 6), nwaves = gridDim.x * 16;
+    bool saw_empty = false, saw_hole = false;
+    for (int x = wave; x < nx; x += nwaves) {
+        bool any = false, hole = false;
+        // (every byte of the plane requested before the first ballot: one load at a time made this kernel 20 us of load latency)
+        int fv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int y = 64 * k + lane;
+            fv[k] = (y < ny) ? (int)row_any[(int64_t)x * ny + y] : 0;
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int y0 = 64 * k;
+            if (y0 >= 32 * row_words) break;
+            const int y = y0 + lane;
+            const int f = fv[k] != 0;
+            const uint64_t b = __ballot(f);
+            const uint64_t valid = __ballot(y < ny);
+            any |= b != 0ull;
+            hole |= (valid & ~b) != 0ull;
+            if (lane == 0) {
+                const int w = y0 >> 5;
+                row_bits[(int64_t)x * row_words + w] = (uint32_t)b;
+                if (w + 1 < row_words) row_bits[(int64_t)x * row_words + w + 1] = (uint32_t)(b >> 32);
+            }
+        }
+        // 0: no filled voxel in the plane; 1: some of its rows hold one; 2: every row does (a floor, a wall: the row mask has nothing to say)
+        if (lane == 0) plane_any[x] = !any ? 0 : hole ? 1 : 2;
+        saw_empty |= !any;
+        saw_hole |= hole;
     }
-    any = __syncthreads_or(any);
-    hole = __syncthreads_or(hole);
-    // 0: no filled voxel in the plane; 1: some of its rows hold one; 2: every row does (a floor, a wall: the row mask has nothing to say)
     // some_empty[0]: a plane without a filled voxel exists (the x sweep then looks planes up); some_empty[-3] (status word 19): a row
     // without one exists (the y sweep then looks at plane_any / the row masks at all: a scene of floors and walls never does)
-    if (t == 0) { plane_any[x] = !any ? 0 : hole ? 1 : 2; if (!any) raise_flag(some_empty); if (hole) raise_flag(some_empty - 3); }
+    const int wg_empty = __syncthreads_or(saw_empty ? 1 : 0), wg_hole = __syncthreads_or(saw_hole ? 1 : 0);
+    if (threadIdx.x == 0 && wg_empty) __hip_atomic_store(some_empty, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && wg_hole) __hip_atomic_store(some_empty - 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int kDcLines = 16;          // lines per tile (the kernel is a template over 8 / 16 lines and 128 / 256 / 512 lanes: 16 x 256 is the measured optimum)
