@@ -43,8 +43,12 @@ def main():
     st.ctx.set_profiling(True)
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record()
-    st.ctx.voxelize_points_device(clouds[0].data_ptr(), clouds[0].shape[0], st.origin, st.resolution, st.shape,
-                                  st.mask.data_ptr(), True, torch.cuda.current_stream().cuda_stream)
+    if st.bits is not None:                     # (the frame's own voxelisation: points -> bit field)
+        st.ctx.voxelize_points_bits_device(clouds[0].data_ptr(), clouds[0].shape[0], st.origin, st.resolution, st.shape,
+                                           st.bits.data_ptr(), True, torch.cuda.current_stream().cuda_stream)
+    else:
+        st.ctx.voxelize_points_device(clouds[0].data_ptr(), clouds[0].shape[0], st.origin, st.resolution, st.shape,
+                                      st.mask.data_ptr(), True, torch.cuda.current_stream().cuda_stream)
     e1.record()
     st.frame(clouds[0], qf)
     e2.record()

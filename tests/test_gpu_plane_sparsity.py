@@ -56,6 +56,13 @@ def test_far_field_pair_with_and_without_plane_sparsity(gpu, shape):
                 assert gpu.last_build_info()["far_predicted"]
                 assert np.array_equal(got, ex) and ext == ex_ext, (name, vb, skip)
                 fields[skip] = (gpu.debug_zsweep(shape).copy(), gpu.debug_yzsweep(shape).copy())
+            # ... and through the bits entry point (the z sweep reads the bit field and writes the same row bytes)
+            from sdf_tools_amd import capi
+            bt = torch.from_numpy(capi.pack_bits_host(m).view(np.int32)).cuda()
+            gpu.set_option("policy_reset", 1)
+            gpu.set_option("plane_skip", 1)
+            gpu.build_bits_device(bt.data_ptr(), shape, out.data_ptr(), res, vb, s)
+            assert gpu.last_build_info()["far_predicted"] and np.array_equal(out.cpu().numpy(), ex) and gpu.get_extrema() == ex_ext, (name, vb, "bits")
             gpu.set_option("dense", 1)
             gpu.set_option("far_predict", 1)
             gpu.set_option("plane_skip", 1)
