@@ -120,6 +120,7 @@ struct sdfgpu_context {
     bool dc_fixed = true;            // far-field kernel: the 512-voxel-line instances (option "dc_fixed")
     bool plane_skip = true;          // builds that go straight to the far-field pair: the z sweep marks the x-planes that hold a filled voxel,
                                      // the y sweep skips the tiles of the others, the x sweep their row loads (option "plane_skip")
+    bool flat_tiles = true;          // ... and y tiles whose 16 lines are all flat-positive (a floor under open space) skip the search (option "flat_tiles")
     DeviceBuffer planebits;          // row_any [nx * ny] bytes | plane_any [nx] bytes | row_bits [nx][ceil(ny / 32)] words (k_sweep_z_wave16, k_pack_row_flags, EnvDcArgs)
     bool last_plane_skip = false;    // the last build used it (sdfgpu_debug_copy_yzsweep fills the skipped planes in)
     int64_t last_dims[3] = {0, 0, 0};
@@ -667,7 +668,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
             a.ran_flag = ex->ran_flag;
-            if (!probe_out) { a.row_bits = ex->row_bits; a.row_words = ex->row_words; a.plane_any = ex->plane_any; a.some_empty = h->d_small + 22; }
+            if (!probe_out) { a.row_bits = ex->row_bits; a.row_words = ex->row_words; a.plane_any = ex->plane_any; a.some_empty = h->d_small + 22; a.flat_on = h->flat_tiles ? 1 : 0; }
             if (stage == 2) { a.bits = ex->bits; a.nzw = ex->nzw; }
             if (stage == 3 && ex->loop && ex->fold_ticket && !probe_out) {
                 a.fold_status = h->d_small; a.fold_result = ex->fold_result; a.fold_report = ex->fold_report; a.fold_ticket = ex->fold_ticket;
@@ -2525,6 +2526,7 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "dense_shell") h->shell_on = value != 0;
     else if (n == "dc_fixed") h->dc_fixed = value != 0;
     else if (n == "plane_skip") h->plane_skip = value != 0;
+    else if (n == "flat_tiles") h->flat_tiles = value != 0;
     else if (n == "redzone") {
         // from now on: every buffer the context holds is released (and comes back with -- or without -- zones when it is next needed);
         // the status block and the slots are replaced at once

@@ -132,6 +132,14 @@ struct EnvDcArgs {
     int row_words;
     const uint8_t* plane_any; // [x]: 0 = x-plane x holds no filled voxel, 1 = some of its z rows do, 2 = every z row does
     uint32_t* some_empty;     // status word STAGE 2 raises when it skips a plane: a scene without one (walls) costs STAGE 3 no look-ups at all
+    // round 6, flat-positive tiles (STAGE 2, pass 0, planes whose every z row holds a filled voxel -- a floor).  When every entry of a line
+    // that is not a zero site (F = 0: a filled voxel) carries the SAME value c -- the height above the floor, for every y line of the open
+    // volume -- then min_q F(q) + (p - q)^2 = min(c, d0(p)^2), d0 = distance along the line to the nearest zero site: a candidate is a zero
+    // site (cost (p - q)^2) or a c site (cost >= c, = c at q = p).  A tile whose 16 lines are all of that kind skips the three search
+    // levels and computes d0 from the zero sites of its chunks (tools/flat_tile_model.py: 51 % of the room's y tiles).  With TWO values
+    // mn < mx outside the zero sites -- a line that passes over or under a table top -- the answer is min(mx, d0^2, mn + d1^2), d1 = distance
+    // to the nearest mn site: that covers every y tile of the room.  0 = never.
+    int flat_on;
 };
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
@@ -302,10 +310,11 @@ SDFGPU_KERNEL __launch_bounds__(1024) void k_pack_row_flags(const uint8_t* __res
 constexpr int kDcLines = 16;          // lines per tile (the kernel is a template over 8 / 16 lines and 128 / 256 / 512 lanes: 16 x 256 is the measured optimum)
 constexpr int NB = 8;          // staging: row loads in flight per lane (a 512-line is staged from ONE round of loads)
 
+constexpr int kDcMisc = 80;           // words of per-tile bookkeeping in LDS (k_envelope_dc: misc)
 inline int envelope_dc_pitch(int L) { return ((L + 63) / 64) * 64 + 2; }        // >= L + 2, == 2 mod 64, even (8-byte pairs)
 inline size_t envelope_dc_lds_bytes(int L, int lines = kDcLines) {
     const int M = (L + 7) / 8;
-    return ((size_t)lines * envelope_dc_pitch(L) + (size_t)(M + 2) * lines + 48 + kDcLocalFilled) * 4;
+    return ((size_t)lines * envelope_dc_pitch(L) + (size_t)(M + 2) * lines + kDcMisc + kDcLocalFilled) * 4;
 }
 
 // a * b + c on the low 24 bits of a and b (signed), low 32 bits of the result: one full-rate instruction.  (Written as
@@ -524,7 +533,9 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     uint32_t* const keys = dc_smem;                             // [16][pitch]
     uint32_t* const args = keys + NL * pitch;                   // [M + 2][16]  best value (distance << B | argmin) of coarse position 8 i
     uint32_t* const misc = args + (M + 2) * NL;                 // per wave: [0..7] span lo, [8..15] span hi, [16..23] smallest site value; [24] filled voxels listed, [25] second pass wanted, [26..28] probe
-    uint32_t* const flist = misc + 48;                          // [kDcLocalFilled] filled voxels of pass 0: line << 28 | p << 12 | min(S, kDcLocalSat)
+    uint32_t* const fl_mn = misc + 48;                          // [16] per line: smallest non-zero entry (flat-positive test), ...
+    uint32_t* const fl_mx = misc + 64;                          // [16] ... largest entry
+    uint32_t* const flist = misc + kDcMisc;                         // [kDcLocalFilled] filled voxels of pass 0: line << 28 | p << 12 | min(S, kDcLocalSat)
     const int t = threadIdx.x;
 #ifdef SDFGPU_PHASE_CLOCKS
     unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -585,6 +596,13 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             }
         }
     }
+    // flat-positive tiles (see EnvDcArgs::flat_on): tried in planes whose every z row holds a filled voxel (block-uniform, one scalar load)
+    bool flat_try = false;
+    if constexpr (STAGE == 2 && NL == 16 && VEC && !LOOP) {
+        if (a.flat_on && a.row_bits) flat_try = M <= 4 * S && L <= 2040 && a.plane_any[o] == 2;
+    }
+    // (STAGE 3 was tried too -- enabled when no z row of the grid is all free -- with one value per line: 27 % of the room's x tiles
+    //  qualify, and the x sweep got 2 % SLOWER: its search is the smaller part of its time and the test is paid by every tile.  Not kept.)
     const int nvalid = (int)min((int64_t)NL, a.group_lines - c0);     // lines of this tile that exist
     const int64_t base = o * a.outer_stride + c0;               // element index of (line 0, position 0)
     const uint32_t ls = (uint32_t)a.line_stride;                // (the launcher guarantees nx*ny*nz < 2^31: 32-bit element offsets)
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     auto run_pass = [&](auto cls_tag) {
         constexpr int cls = decltype(cls_tag)::value;
         for (int i = t; i < (M + 2) * NL; i += NT) args[i] = 0xFFFFFFFFu;
-        if (cls == 0 && t < 48) misc[t] = 0u;
+        if (cls == 0 && t < kDcMisc) misc[t] = (t >= 48 && t < 64) ? 0xFFFFFFFFu : 0u;
 
         // ---- stage the tile: rows -> keys ------------------------------------------------------------------------------------
         // A lane reads 4 lines x 1 position per load (VEC: one 8 / 16-byte load), NB loads in flight, and writes the
@@ -750,6 +768,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         const uint32_t off_r = (uint32_t)r * ls + 4u * sub, off_last = (uint32_t)(L - 1) * ls + 4u * sub;
         int lo_w = 0x7fffffff, hi_w = -1;                       // span seen by this wave (uniform)
         uint32_t mt = 0xFFFFFFFFu;                              // smallest site value seen by this lane
+        uint32_t fmn[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, fmx[4] = {0u, 0u, 0u, 0u};   // flat-positive test: per line of this lane
         for (int pb = 0; pb < L; pb += PP * NB) {
             int sv[NB][4];
             // plane sparsity: the verdicts of this lane's rows -- STAGE 3: the row's x-plane holds a filled voxel (the y sweep skipped the
@@ -867,6 +886,14 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) kb[k * pitch + (pb + PP * it)] = (F[k] << B) + cpos;
                 }
+                if (cls == 0 && flat_try) {                     // (block-uniform) smallest non-zero and largest entry of each line
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t f = inl ? F[k] : 0u;
+                        fmx[k] = umax(fmx[k], f);
+                        fmn[k] = umin(fmn[k], f ? f : 0xFFFFFFFFu);
+                    }
+                }
                 const uint32_t fmin4 = inl ? umin(umin(F[0], F[1]), umin(F[2], F[3])) : finf;
                 mt = umin(mt, fmin4);
                 const uint64_t bal = __ballot(fmin4 < finf);
@@ -889,6 +916,20 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 }
             }
         }
+        if (cls == 0 && flat_try) {                             // lanes sub, sub + LPR, ... of a wave hold the same 4 lines
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    fmn[k] = umin(fmn[k], (uint32_t)__shfl_xor((int)fmn[k], off));
+                    fmx[k] = umax(fmx[k], (uint32_t)__shfl_xor((int)fmx[k], off));
+                }
+            }
+            if ((t & 63) < LPR) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { atomicMin(&fl_mn[4 * sub + k], fmn[k]); atomicMax(&fl_mx[4 * sub + k], fmx[k]); }
+            }
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mt = umin(mt, (uint32_t)__shfl_xor((int)mt, off));
         if ((t & 63) == 0) { misc[t >> 6] = (uint32_t)lo_w; misc[8 + (t >> 6)] = (uint32_t)hi_w; misc[16 + (t >> 6)] = mt; }
@@ -907,8 +948,127 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
 #else
         const bool act = lo_t <= hi_t;                          // the tile holds a site (block-uniform)
 #endif
+        // Two-valued tiles.  Every lane classifies the positions of its chunks against its line's smallest non-zero entry mn and
+        // largest entry mx: zero site, mn site, mx site -- or something else, and then the tile is searched as usual (the keys
+        // are untouched until the verdict; the classification costs ~2 % of a searched tile).
+        bool flat = false, two = false;
+        uint32_t zm = 0u, lm = 0u;                              // zero sites / mn sites of this lane's chunks, 8 bits per round of level C
+        if (cls == 0 && flat_try && act) {
+            const uint32_t* kl = keys + lineT * pitch;
+            const uint32_t mn = fl_mn[lineT], mx = fl_mx[lineT];
+            // does any line hold two values at all?  (block-uniform: every lane reads the same 32 words.)  A tile of one-valued lines --
+            // half of the room's -- does without the mn sites: mn = mx, and min(mx, d0^2) is the whole answer
+#pragma unroll
+            for (int l = 0; l < NL; ++l) { const uint32_t a1 = fl_mn[l], b1 = fl_mx[l]; two = two || (b1 != 0u && a1 != b1); }
+            bool other = false;
+            int n = 0;
+            if (!two) {
+                for (int i0 = 0; i0 < M; i0 += S, ++n) {
+                    const int i = i0 + slotT;
+                    if (i >= M) continue;
+                    const int p0 = 8 * i, pc0 = p0 - h;
+                    uint32_t cz = mad_i24(pc0, pc0, (uint32_t)(h * h));
+                    int inc = 2 * pc0 + 1;
+                    uint32_t z8 = 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const uint2 kk = *reinterpret_cast<const uint2*>(kl + p0 + k);
+                        const uint32_t f0 = (kk.x >> B) - cz;
+                        cz += (uint32_t)inc; inc += 2;
+                        const uint32_t f1 = (kk.y >> B) - cz;
+                        cz += (uint32_t)inc; inc += 2;
+                        const bool in0 = p0 + k < L, in1 = p0 + k + 1 < L;
+                        z8 |= ((f0 == 0u && in0) ? 1u : 0u) << k;
+                        z8 |= ((f1 == 0u && in1) ? 1u : 0u) << (k + 1);
+                        other = other || (in0 && f0 != 0u && f0 != mx) || (in1 && f1 != 0u && f1 != mx);
+                    }
+                    zm |= z8 << (8 * n);
+                }
+            } else
+            for (int i0 = 0; i0 < M; i0 += S, ++n) {
+                const int i = i0 + slotT;
+                if (i >= M) continue;
+                const int p0 = 8 * i, pc0 = p0 - h;
+                uint32_t cz = mad_i24(pc0, pc0, (uint32_t)(h * h));        // the position's own term (p - h)^2 + h^2: F = (key >> B) - cz
+                int inc = 2 * pc0 + 1;
+                uint32_t z8 = 0u, l8 = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const uint2 kk = *reinterpret_cast<const uint2*>(kl + p0 + k);
+                    const uint32_t f0 = (kk.x >> B) - cz;
+                    cz += (uint32_t)inc; inc += 2;
+                    const uint32_t f1 = (kk.y >> B) - cz;
+                    cz += (uint32_t)inc; inc += 2;
+                    const bool in0 = p0 + k < L, in1 = p0 + k + 1 < L;
+                    z8 |= ((f0 == 0u && in0) ? 1u : 0u) << k;
+                    z8 |= ((f1 == 0u && in1) ? 1u : 0u) << (k + 1);
+                    l8 |= ((f0 == mn && in0) ? 1u : 0u) << k;
+                    l8 |= ((f1 == mn && in1) ? 1u : 0u) << (k + 1);
+                    other = other || (in0 && f0 != 0u && f0 != mn && f0 != mx) || (in1 && f1 != 0u && f1 != mn && f1 != mx);
+                }
+                zm |= z8 << (8 * n);
+                lm |= l8 << (8 * n);
+            }
+            flat = __syncthreads_and(other ? 0 : 1) != 0;      // (block-uniform; everybody has read its keys)
+#ifdef SDFGPU_DEBUG_HOOKS
+            if (a.dbg & 128) flat = false;
+#endif
+        }
 
-        if (act) {
+        if (flat) {
+            constexpr int kFar = 1 << 20;
+            // the key area is free now: six arrays [16][M + 2] -- first / last zero site and mn site of every chunk, then the nearest
+            // ones before / behind every chunk
+            const int MP = M + 2;
+            uint32_t* const cz0 = keys, * const cl0 = keys + NL * MP;
+            uint32_t* const nzl = keys + 2 * NL * MP, * const nzr = keys + 3 * NL * MP, * const nll = keys + 4 * NL * MP, * const nlr = keys + 5 * NL * MP;
+            {
+                int n = 0;
+                for (int i0 = 0; i0 < M; i0 += S, ++n) {
+                    const int i = i0 + slotT;
+                    if (i >= M) continue;
+                    const int p0 = 8 * i;
+                    const uint32_t z8 = (zm >> (8 * n)) & 0xFFu, l8 = (lm >> (8 * n)) & 0xFFu;
+                    cz0[lineT * MP + i] = z8 ? ((uint32_t)(p0 + 31 - __clz((int)z8)) << 16) | (uint32_t)(p0 + __ffs((int)z8) - 1) : 0xFFFFFFFFu;
+                    if (two) cl0[lineT * MP + i] = l8 ? ((uint32_t)(p0 + 31 - __clz((int)l8)) << 16) | (uint32_t)(p0 + __ffs((int)l8) - 1) : 0xFFFFFFFFu;
+                }
+            }
+            __syncthreads();
+            // per line, 16 lanes, each with a run of chunks: exclusive prefix maximum of "last" / suffix minimum of "first" over the chunks
+            if (t < 16 * NL) {
+                const int line2 = t >> 4, j = t & 15;
+                const int CP = (M + 15) >> 4, cb = j * CP, ce = imin(cb + CP, M);
+                auto nearest = [&](const uint32_t* info, uint32_t* before, uint32_t* behind) {
+                    int pre = -kFar, suf = kFar;
+                    for (int c = cb; c < ce; ++c) {
+                        const uint32_t w = info[line2 * MP + c];
+                        if (w != 0xFFFFFFFFu) { pre = imax(pre, (int)(w >> 16)); suf = imin(suf, (int)(w & 0xFFFFu)); }
+                    }
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) {
+                        const int v = __shfl_up(pre, d, 16), u = __shfl_down(suf, d, 16);
+                        if (j >= d) pre = imax(pre, v);
+                        if (j + d < 16) suf = imin(suf, u);
+                    }
+                    int run = __shfl_up(pre, 1, 16), nxt = __shfl_down(suf, 1, 16);
+                    if (j == 0) run = -kFar;
+                    if (j == 15) nxt = kFar;
+                    for (int c = cb; c < ce; ++c) {
+                        before[line2 * MP + c] = (uint32_t)run;
+                        const uint32_t w = info[line2 * MP + c];
+                        if (w != 0xFFFFFFFFu) run = (int)(w >> 16);
+                    }
+                    for (int c = ce - 1; c >= cb; --c) {
+                        behind[line2 * MP + c] = (uint32_t)nxt;
+                        const uint32_t w = info[line2 * MP + c];
+                        if (w != 0xFFFFFFFFu) nxt = (int)(w & 0xFFFFu);
+                    }
+                };
+                nearest(cz0, nzl, nzr);
+                if (two) nearest(cl0, nll, nlr);
+            }
+            __syncthreads();
+        } else if (act) {
             // ---- level A: positions 64 i ---------------------------------------------------------------------------------------
             // Two forms, chosen per wave (= 64 / S whole lines): (a) one position per lane group over a range clipped by the
             // distance bound -- a few candidates per position wherever the line runs near sites or far from ALL of them;
@@ -1042,13 +1202,57 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         // ---- level C: lane = (line, chunk of 8 positions); finish and store ---------------------------------------------------
         {
             const uint32_t* kl = keys + lineT * pitch;
-            for (int i0 = 0; i0 < M; i0 += S) {
+            for (int i0 = 0, n = 0; i0 < M; i0 += S, ++n) {
                 const int i = i0 + slotT;
                 const bool mine = i < M && lineT_ok;
                 if (NL != 16 && !mine) continue;                // (16-line tiles: the lane stays in its wave with an empty range)
                 const int p0 = 8 * i;
                 int D[8];
-                if (act) {
+                if (flat) {
+                    // D = min(mx, d0^2, mn + d1^2): d0 / d1 = distance along the line to the nearest zero site / mn site (a zero site
+                    // costs (p - q)^2, an mn site mn + (p - q)^2, an mx site at least mx -- which the position itself attains unless it
+                    // is a zero or mn site, and then one of the other two terms is already smaller)
+                    const int ic = imin(i, M - 1), MP = M + 2;
+                    const uint32_t z8 = (zm >> (8 * n)) & 0xFFu, l8 = (lm >> (8 * n)) & 0xFFu;
+                    const uint32_t mn = fl_mn[lineT], mx = fl_mx[lineT];
+                    int lz = (int)keys[(2 * NL + lineT) * MP + ic], rz = (int)keys[(3 * NL + lineT) * MP + ic];
+                    if (!two) {                                 // (block-uniform) one value per line
+                        int dz[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            if ((z8 >> k) & 1u) lz = p0 + k;
+                            dz[k] = p0 + k - lz;
+                        }
+#pragma unroll
+                        for (int k = 7; k >= 0; --k) {
+                            if ((z8 >> k) & 1u) rz = p0 + k;
+                            const int d0 = imin(dz[k], rz - (p0 + k));
+                            const uint32_t t0 = d0 > 2047 ? 0xFFFFFFFFu : __umul24((uint32_t)d0, (uint32_t)d0);
+                            const uint32_t d = umin(mx, t0);
+                            D[k] = d >= finf ? kInf32 : (int)d;
+                        }
+                    } else {
+                    int ll = (int)keys[(4 * NL + lineT) * MP + ic], rl = (int)keys[(5 * NL + lineT) * MP + ic];
+                    int dz[8], dl[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if ((z8 >> k) & 1u) lz = p0 + k;
+                        if ((l8 >> k) & 1u) ll = p0 + k;
+                        dz[k] = p0 + k - lz;
+                        dl[k] = p0 + k - ll;
+                    }
+#pragma unroll
+                    for (int k = 7; k >= 0; --k) {
+                        if ((z8 >> k) & 1u) rz = p0 + k;
+                        if ((l8 >> k) & 1u) rl = p0 + k;
+                        const int d0 = imin(dz[k], rz - (p0 + k)), d1 = imin(dl[k], rl - (p0 + k));
+                        const uint32_t t0 = d0 > 2047 ? 0xFFFFFFFFu : __umul24((uint32_t)d0, (uint32_t)d0);
+                        const uint32_t t1 = d1 > 2047 ? 0xFFFFFFFFu : mn + __umul24((uint32_t)d1, (uint32_t)d1);
+                        const uint32_t d = umin(mx, umin(t0, t1));
+                        D[k] = d >= finf ? kInf32 : (int)d;
+                    }
+                    }
+                } else if (act) {
                     const int ic = imin(i, M - 1);
                     const int a0 = (int)(args[ic * NL + lineT] & mask);
                     const int a8 = !mine ? -1 : (i + 1 < M) ? (int)(args[(i + 1) * NL + lineT] & mask) : hi_t;
