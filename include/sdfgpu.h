@@ -383,6 +383,11 @@ int sdfgpu_debug_copy_zsweep(sdfgpu_handle h, int16_t* out_host, int64_t n);
  * *out_slow_lanes = lanes of the fp32 form that asked for the fp64 sequence. */
 int sdfgpu_debug_finish_table(sdfgpu_handle h, float* d_out, int64_t n, double resolution, int fast, uint32_t* out_slow_lanes);
 int sdfgpu_debug_copy_yzsweep(sdfgpu_handle h, int32_t* out_host, int64_t n);
+/* The device-side habit of the far-field y sweep's two-valued tiles (option "flat_tiles" = 1; synchronises with the last build):
+ * out_score = the votes so far -- clamped to [0, 256] in front of every y sweep that consults it, tiles that tried and did not qualify
+ * add 1, tiles that qualified subtract 3 -- and out_gate = what the last such sweep was told (1: every candidate tile tries, 0: every
+ * 64th).  Results never depend on either. */
+int sdfgpu_debug_flat_habit(sdfgpu_handle h, int* out_score, int* out_gate);
 
 /* Per-stage timing with HIP events recorded on the build's own stream (bench.py's roofline leg).
  * While enabled, every sdfgpu_build*_device call brackets its seven stages with events:
@@ -442,6 +447,9 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  *  "i32_handoff"             [AB]     1        far-field pair hands exact int32 plane values from the y to the x sweep
  *  "dc_fixed"                [AB]     1        far-field kernel: instances with the 512- / 1024-voxel line geometry at compile time
  *  "plane_skip"              [AB]     1        builds that go straight to the far-field pair skip the x-planes without a filled voxel
+ *  "flat_tiles"              [AB]     1        ... and their y sweep skips its search in tiles whose lines hold at most two values outside
+ *                                              their zero sites (a floor under open space, table tops); 1: while it pays (a device-side
+ *                                              habit, sdfgpu_debug_flat_habit), 2: every candidate tile tries, 0: never
  *
  *  host side / debugging
  *  "host_pack"               [U]      1        host-buffer builds classify on the host and upload 1 bit / voxel (0: upload + classify on

@@ -20,7 +20,7 @@ EXPORTS = [
     "sdfgpu_version", "sdfgpu_device_count", "sdfgpu_create", "sdfgpu_destroy", "sdfgpu_last_error",
     "sdfgpu_build", "sdfgpu_build_cells", "sdfgpu_build_device", "sdfgpu_build_cells_device",
     "sdfgpu_get_extrema", "sdfgpu_sweep_zy_device", "sdfgpu_sweep_x_device", "sdfgpu_extrema_from_dsq",
-    "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_set_tuning",
+    "sdfgpu_gradient_device", "sdfgpu_debug_copy_zsweep", "sdfgpu_debug_copy_yzsweep", "sdfgpu_debug_flat_habit", "sdfgpu_set_tuning",
     "sdfgpu_set_profiling", "sdfgpu_get_stage_times", "sdfgpu_set_option", "sdfgpu_last_build_info", "sdfgpu_last_dense_certified",
     "sdfgpu_pack_bits_device", "sdfgpu_dense_ball_device", "sdfgpu_voxelize_points_device", "sdfgpu_build_tagged_cells", "sdfgpu_query_points_device", "sdfgpu_fold_extrema_device", "sdfgpu_slab_dense_phase",
     "sdfgpu_gradient", "sdfgpu_sweep_zy_tiered_device", "sdfgpu_sweep_x_lines_device", "sdfgpu_classify_cells_device",
@@ -96,6 +96,7 @@ def load_library():
     L.sdfgpu_redzone_check.argtypes = [vp, vp]
     L.sdfgpu_debug_copy_zsweep.argtypes = [vp, vp, i64]
     L.sdfgpu_debug_copy_yzsweep.argtypes = [vp, vp, i64]
+    L.sdfgpu_debug_flat_habit.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.sdfgpu_set_tuning.argtypes = [vp, ci, ci]
     L.sdfgpu_set_option.argtypes = [vp, ctypes.c_char_p, ci]
     L.sdfgpu_last_build_info.argtypes = [vp, vp]
@@ -404,6 +405,12 @@ class SdfGpu:
         out = np.empty(shape, dtype=np.int32)
         self._check(self._lib.sdfgpu_debug_copy_yzsweep(self._h, out.ctypes.data, out.size))
         return out
+
+    def debug_flat_habit(self):
+        """(score, gate) of the two-valued tiles' device-side habit (include/sdfgpu.h); synchronises."""
+        sc, g = ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.sdfgpu_debug_flat_habit(self._h, ctypes.byref(sc), ctypes.byref(g)))
+        return sc.value, g.value
 
     def set_option(self, name, value):
         self._check(self._lib.sdfgpu_set_option(self._h, name.encode(), int(value)))

@@ -120,7 +120,9 @@ struct sdfgpu_context {
     bool dc_fixed = true;            // far-field kernel: the 512-voxel-line instances (option "dc_fixed")
     bool plane_skip = true;          // builds that go straight to the far-field pair: the z sweep marks the x-planes that hold a filled voxel,
                                      // the y sweep skips the tiles of the others, the x sweep their row loads (option "plane_skip")
-    bool flat_tiles = true;          // ... and y tiles whose 16 lines are all flat-positive (a floor under open space) skip the search (option "flat_tiles")
+    bool flat_score_reset = false;   // "policy_reset": the next build clears the device-side habit of the two-valued tiles (status word 40)
+    int flat_tiles = 1;              // (2: every such tile tries, whatever the habit says -- tests)
+    // ... and y tiles whose 16 lines are all flat-positive (a floor under open space) skip the search (option "flat_tiles")
     DeviceBuffer planebits;          // row_any [nx * ny] bytes | plane_any [nx] bytes | row_bits [nx][ceil(ny / 32)] words (k_sweep_z_wave16, k_pack_row_flags, EnvDcArgs)
     bool last_plane_skip = false;    // the last build used it (sdfgpu_debug_copy_yzsweep fills the skipped planes in)
     int64_t last_dims[3] = {0, 0, 0};
@@ -668,7 +670,7 @@ int launch_envelope(sdfgpu_handle h, int stage, const int16_t* d_in16, const int
             a.in_i32 = ex->in_i32; a.out_i32 = ex->out_i32; a.y_off = ex->y_off; a.i32_flag = ex->i32_flag;
             if (ex->ny_glob >= 0) a.ny_glob = ex->ny_glob;
             a.ran_flag = ex->ran_flag;
-            if (!probe_out) { a.row_bits = ex->row_bits; a.row_words = ex->row_words; a.plane_any = ex->plane_any; a.some_empty = h->d_small + 22; a.flat_on = h->flat_tiles ? 1 : 0; }
+            if (!probe_out) { a.row_bits = ex->row_bits; a.row_words = ex->row_words; a.plane_any = ex->plane_any; a.some_empty = h->d_small + 22; a.flat_on = h->flat_tiles; a.flat_score = h->d_small + 40; }
             if (stage == 2) { a.bits = ex->bits; a.nzw = ex->nzw; }
             if (stage == 3 && ex->loop && ex->fold_ticket && !probe_out) {
                 a.fold_status = h->d_small; a.fold_result = ex->fold_result; a.fold_report = ex->fold_report; a.fold_ticket = ex->fold_ticket;
@@ -1233,7 +1235,8 @@ int build_device_impl(sdfgpu_handle h, const uint8_t* d_filled, const void* d_ce
             uint8_t* plane_any = row_any + nx * ny;
             uint32_t* row_bits = (uint32_t*)(row_any + (((size_t)(nx * ny + nx) + 255) & ~(size_t)255));
             const int row_words = (int)((ny + 31) / 32);
-            hipLaunchKernelGGL(k_pack_row_flags, dim3((unsigned)std::min<int64_t>((nx + 15) / 16, 16)), dim3(1024), 0, s, row_any, (int)nx, (int)ny, row_words, row_bits, plane_any, h->d_small + 22);
+            if (h->flat_score_reset) { h->flat_score_reset = false; HIP_TRY(h, hipMemsetAsync(h->d_small + 40, 0, 8, s)); }
+            hipLaunchKernelGGL(k_pack_row_flags, dim3((unsigned)std::min<int64_t>((nx + 15) / 16, 16)), dim3(1024), 0, s, row_any, (int)nx, (int)ny, row_words, row_bits, plane_any, h->d_small + 22, h->d_small + 40);
             HIP_TRY(h, hipGetLastError());
             pr2.row_bits = row_bits; pr2.row_words = row_words; pr2.plane_any = pr3.plane_any = plane_any;
         }
@@ -2519,14 +2522,14 @@ int sdfgpu_set_option(sdfgpu_handle h, const char* name, int value) {
     else if (n == "nt_store") h->nt_store = value;
     else if (n == "ball_block") h->ball_block = value;
     else if (n == "defer_fold") h->defer_fold = value != 0;
-    else if (n == "policy_reset") { h->flags_pending = false; h->pol.reset(); h->far.reset(); }
+    else if (n == "policy_reset") { h->flags_pending = false; h->pol.reset(); h->far.reset(); h->flat_score_reset = true; }
     else if (n == "fixup") { h->pol.fixup_on = value != 0; h->pol.fix_mode = false; h->pol.dense3_mode = false; }
     else if (n == "dense3") { h->pol.dense3_on = value != 0; h->pol.dense3_mode = false; }
     else if (n == "dense3_mode") h->pol.dense3_mode = value != 0;
     else if (n == "dense_shell") h->shell_on = value != 0;
     else if (n == "dc_fixed") h->dc_fixed = value != 0;
     else if (n == "plane_skip") h->plane_skip = value != 0;
-    else if (n == "flat_tiles") h->flat_tiles = value != 0;
+    else if (n == "flat_tiles") h->flat_tiles = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (n == "redzone") {
         // from now on: every buffer the context holds is released (and comes back with -- or without -- zones when it is next needed);
         // the status block and the slots are replaced at once
@@ -2588,6 +2591,17 @@ int sdfgpu_last_dense_certified(sdfgpu_handle h, int* out_certified) {
     uint32_t why = 0;
     HIP_TRY(h, hipMemcpy(&why, h->d_result + 21, sizeof why, hipMemcpyDeviceToHost));
     *out_certified = ((h->last_dense && v[3] == 0) ? 1 : 0) | (v[4] ? 2 : 0) | (v[5] ? 4 : 0) | (int)((why & 0xffu) << 8);
+    return SDFGPU_OK;
+}
+
+int sdfgpu_debug_flat_habit(sdfgpu_handle h, int* out_score, int* out_gate) {
+    if (!h || !out_score || !out_gate) return SDFGPU_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->order_valid) HIP_TRY(h, hipEventSynchronize(h->build_done_ev));
+    int v[2] = {0, 0};
+    HIP_TRY(h, hipMemcpy(v, h->d_small + 40, sizeof v, hipMemcpyDeviceToHost));
+    *out_score = v[0];
+    *out_gate = v[1];
     return SDFGPU_OK;
 }
 

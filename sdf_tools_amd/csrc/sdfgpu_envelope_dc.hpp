@@ -139,8 +139,16 @@ struct EnvDcArgs {
     // levels and computes d0 from the zero sites of its chunks (tools/flat_tile_model.py: 51 % of the room's y tiles).  With TWO values
     // mn < mx outside the zero sites -- a line that passes over or under a table top -- the answer is min(mx, d0^2, mn + d1^2), d1 = distance
     // to the nearest mn site: that covers every y tile of the room.  0 = never.
-    int flat_on;
+    int flat_on;              // 1: as long as it pays (flat_score); 2: in every such tile
+    // The habit lives on the device: flat_score[0] is a (signed) word of the handle that no build clears.  A tile that tries and does not
+    // qualify has paid ~15 % for nothing (a floor under noise: every tile would), one that qualifies saves ~40 %: every 16th tile that
+    // tried votes +1 / -3 (atomic adds, nobody waits for them); k_pack_row_flags, in front of every such y sweep, clamps the sum to
+    // [0, kDcFlatCap] and publishes the gate flat_score[1] = "below kDcFlatOff", which the y sweep reads with its other status words --
+    // a fresh load of the score itself sat on every tile's critical path: +4 %.  With the gate down every 64th tile still tries, and
+    // votes: the habit is back one build after the scene changes.  Results never depend on it.
+    uint32_t* flat_score;
 };
+
 
 // Correctly rounded fp64 square root of a positive normal number: exactly the Goldschmidt / Newton sequence the compiler
 // emits for sqrt(double) (rsq seed, one coupled iteration, two residual corrections), without its input scaling for
@@ -263,8 +271,15 @@ __device__ __forceinline__ int zdist_from_row(const ZRowBits& r, int w0, int nz,
 
 // Plane sparsity, between the z sweep and the far-field y sweep: packs every x-plane's row bytes (row_any[x * ny + y])
 // into ceil(ny / 32) words, sums them up in plane_any[x] (0 / 1 / 2, below) and raises *some_empty for a plane without a filled voxel.
+constexpr uint32_t kDcFlatOff = 16u, kDcFlatCap = 256u;        // (EnvDcArgs::flat_score)
 SDFGPU_KERNEL __launch_bounds__(1024) void k_pack_row_flags(const uint8_t* __restrict__ row_any, int nx, int ny, int row_words, uint32_t* __restrict__ row_bits,
-                                                         uint8_t* __restrict__ plane_any, uint32_t* __restrict__ some_empty) {
+                                                         uint8_t* __restrict__ plane_any, uint32_t* __restrict__ some_empty, uint32_t* __restrict__ flat_score) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flat_score) {      // the habit of the two-valued tiles: last build's votes -> this build's gate
+        int v = (int)flat_score[0];
+        v = v < 0 ? 0 : v > (int)kDcFlatCap ? (int)kDcFlatCap : v;
+        flat_score[0] = (uint32_t)v;
+        flat_score[1] = v < (int)kDcFlatOff ? 1u : 0u;
+    }
     // a WAVE per x-plane at a time, 16 waves per workgroup, at most 16 workgroups: the two status words see one store per WORKGROUP.
     // (Device-scope stores to one address cost ~28 ns each: forms with a store per plane or per wave -- 512 to 1024 of them -- took
     //  20 - 29 us at 512^3, whatever else the kernel did.)
@@ -520,7 +535,16 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     // plane sparsity: the y sweep in front skipped at least one x-plane (launch-uniform; its launch is complete)
     const bool planes = STAGE == 3 && a.plane_any && __hip_atomic_load(a.some_empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     // ... STAGE 2: the z sweep in front left at least one z row unwritten (k_pack_row_flags raises status word 19)
-    const bool rows_known = STAGE == 2 && a.row_bits && __hip_atomic_load(a.some_empty - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    // ... none: every z row of the grid holds a filled voxel; flat_gate: the habit of the two-valued tiles says "try" (EnvDcArgs::flat_score).
+    // (The two words are requested TOGETHER: with the gate's load behind the test of word 19 every tile waited a second round trip, +3.6 %.)
+    uint32_t w19 = 0u, wgate = 0u;
+    if (STAGE == 2 && a.row_bits) {
+        w19 = __hip_atomic_load(a.some_empty - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wgate = __hip_atomic_load(a.flat_score + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool rows_known = STAGE == 2 && a.row_bits && w19 != 0u;
+    const bool floorlike = STAGE == 2 && a.row_bits && a.flat_on && w19 == 0u;
+    const bool flat_gate = floorlike && (a.flat_on == 2 || wgate != 0u);
     if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
     if (a.probe_stride > 0 && STAGE == 3 && a.decide_small &&
         __hip_atomic_load(a.decide_small + 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { probe_done(a); return; }   // ... settled by the y probe
@@ -596,10 +620,13 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             }
         }
     }
-    // flat-positive tiles (see EnvDcArgs::flat_on): tried in planes whose every z row holds a filled voxel (block-uniform, one scalar load)
+    // two-valued tiles (see EnvDcArgs::flat_on): tried when every z row of the grid holds a filled voxel -- a floor (block-uniform)
     bool flat_try = false;
+    uint32_t flat_hash = 0u;
     if constexpr (STAGE == 2 && NL == 16 && VEC && !LOOP) {
-        if (a.flat_on && a.row_bits) flat_try = M <= 4 * S && L <= 2040 && a.plane_any[o] == 2;
+        // (samples by a hash of the tile index: tile & 63 == 0 is the same 16 lines of z in every second plane -- the floor's own tiles)
+        flat_hash = (uint32_t)tile * 2654435761u;
+        flat_try = floorlike && M <= 4 * S && L <= 2040 && (flat_gate || (flat_hash >> 26) == 0u);
     }
     // (STAGE 3 was tried too -- enabled when no z row of the grid is all free -- with one value per line: 27 % of the room's x tiles
     //  qualify, and the x sweep got 2 % SLOWER: its search is the smaller part of its time and the test is paid by every tile.  Not kept.)
@@ -952,6 +979,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         // largest entry mx: zero site, mn site, mx site -- or something else, and then the tile is searched as usual (the keys
         // are untouched until the verdict; the classification costs ~2 % of a searched tile).
         bool flat = false, two = false;
+        constexpr bool kAllIn = LC != 0 && LC % 8 == 0;          // (every position of every chunk lies inside the line)
         uint32_t zm = 0u, lm = 0u;                              // zero sites / mn sites of this lane's chunks, 8 bits per round of level C
         if (cls == 0 && flat_try && act) {
             const uint32_t* kl = keys + lineT * pitch;
@@ -962,6 +990,9 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             for (int l = 0; l < NL; ++l) { const uint32_t a1 = fl_mn[l], b1 = fl_mx[l]; two = two || (b1 != 0u && a1 != b1); }
             bool other = false;
             int n = 0;
+#ifdef SDFGPU_DEBUG_HOOKS
+            if (a.dbg & 1024) {} else                   // profiling builds: bit 10 = no classification (wrong results)
+#endif
             if (!two) {
                 for (int i0 = 0; i0 < M; i0 += S, ++n) {
                     const int i = i0 + slotT;
@@ -977,7 +1008,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         cz += (uint32_t)inc; inc += 2;
                         const uint32_t f1 = (kk.y >> B) - cz;
                         cz += (uint32_t)inc; inc += 2;
-                        const bool in0 = p0 + k < L, in1 = p0 + k + 1 < L;
+                        const bool in0 = kAllIn || p0 + k < L, in1 = kAllIn || p0 + k + 1 < L;
                         z8 |= ((f0 == 0u && in0) ? 1u : 0u) << k;
                         z8 |= ((f1 == 0u && in1) ? 1u : 0u) << (k + 1);
                         other = other || (in0 && f0 != 0u && f0 != mx) || (in1 && f1 != 0u && f1 != mx);
@@ -999,7 +1030,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                     cz += (uint32_t)inc; inc += 2;
                     const uint32_t f1 = (kk.y >> B) - cz;
                     cz += (uint32_t)inc; inc += 2;
-                    const bool in0 = p0 + k < L, in1 = p0 + k + 1 < L;
+                    const bool in0 = kAllIn || p0 + k < L, in1 = kAllIn || p0 + k + 1 < L;
                     z8 |= ((f0 == 0u && in0) ? 1u : 0u) << k;
                     z8 |= ((f1 == 0u && in1) ? 1u : 0u) << (k + 1);
                     l8 |= ((f0 == mn && in0) ? 1u : 0u) << k;
@@ -1010,6 +1041,9 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 lm |= l8 << (8 * n);
             }
             flat = __syncthreads_and(other ? 0 : 1) != 0;      // (block-uniform; everybody has read its keys)
+            if (a.flat_on == 1 && (flat_hash >> 28) == 0u && t == 0)     // this tile's vote (every 16th, and every one of the 64th that try with the gate down)
+                (void)__hip_atomic_fetch_add(reinterpret_cast<int*>(a.flat_score), flat ? -3 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DC_STAMP(1);
 #ifdef SDFGPU_DEBUG_HOOKS
             if (a.dbg & 128) flat = false;
 #endif
@@ -1035,6 +1069,9 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             }
             __syncthreads();
             // per line, 16 lanes, each with a run of chunks: exclusive prefix maximum of "last" / suffix minimum of "first" over the chunks
+#ifdef SDFGPU_DEBUG_HOOKS
+            if (a.dbg & 512) {} else                    // profiling builds: bit 9 = no nearest-site scans (wrong results)
+#endif
             if (t < 16 * NL) {
                 const int line2 = t >> 4, j = t & 15;
                 const int CP = (M + 15) >> 4, cb = j * CP, ce = imin(cb + CP, M);
@@ -1068,6 +1105,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 if (two) nearest(cl0, nll, nlr);
             }
             __syncthreads();
+            DC_STAMP(2);
         } else if (act) {
             // ---- level A: positions 64 i ---------------------------------------------------------------------------------------
             // Two forms, chosen per wave (= 64 / S whole lines): (a) one position per lane group over a range clipped by the
@@ -1216,6 +1254,16 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                     const uint32_t z8 = (zm >> (8 * n)) & 0xFFu, l8 = (lm >> (8 * n)) & 0xFFu;
                     const uint32_t mn = fl_mn[lineT], mx = fl_mx[lineT];
                     int lz = (int)keys[(2 * NL + lineT) * MP + ic], rz = (int)keys[(3 * NL + lineT) * MP + ic];
+                    int ll = 0, rl = 0;
+                    if (two) { ll = (int)keys[(4 * NL + lineT) * MP + ic]; rl = (int)keys[(5 * NL + lineT) * MP + ic]; }
+                    // (a chunk-level shortcut -- no site inside, the nearest ones too far to matter: one value for all eight positions,
+                    //  decided per wave -- was measured: y sweep +2 ... 3 %; the wall at low y reaches half of the room's chunks)
+#ifdef SDFGPU_DEBUG_HOOKS
+                    if (a.dbg & 256) {                          // profiling builds: bit 8 = no distance chains (wrong results)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) D[k] = mx >= finf ? kInf32 : (int)mx;
+                    } else
+#endif
                     if (!two) {                                 // (block-uniform) one value per line
                         int dz[8];
 #pragma unroll
@@ -1232,7 +1280,6 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                             D[k] = d >= finf ? kInf32 : (int)d;
                         }
                     } else {
-                    int ll = (int)keys[(4 * NL + lineT) * MP + ic], rl = (int)keys[(5 * NL + lineT) * MP + ic];
                     int dz[8], dl[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -1252,6 +1299,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         D[k] = d >= finf ? kInf32 : (int)d;
                     }
                     }
+                    DC_STAMP(3);
                 } else if (act) {
                     const int ic = imin(i, M - 1);
                     const int a0 = (int)(args[ic * NL + lineT] & mask);

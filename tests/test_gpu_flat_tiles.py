@@ -79,7 +79,7 @@ def test_far_field_pair_with_and_without_flat_tiles(gpu, shape):
                 ex, ex_ext, _ = O.exact_sdf(m, res, vb)
                 mt = torch.from_numpy(m).cuda()
                 fields = {}
-                for flat in (1, 0):
+                for flat in (2, 1, 0):            # 2: every candidate tile tries; 1: as long as the device-side habit says it pays
                     gpu.set_option("policy_reset", 1)
                     gpu.set_option("dense", 0)
                     gpu.set_option("far_predict", 2)
@@ -90,8 +90,38 @@ def test_far_field_pair_with_and_without_flat_tiles(gpu, shape):
                     assert gpu.last_build_info()["far_predicted"]
                     assert np.array_equal(got, ex) and ext == ex_ext, (name, vb, flat, int((got != ex).sum()))
                     fields[flat] = gpu.debug_yzsweep(shape).copy()
-                assert np.array_equal(fields[1], fields[0]), (name, vb, "plane field")
+                assert np.array_equal(fields[2], fields[0]) and np.array_equal(fields[1], fields[0]), (name, vb, "plane field")
     finally:
         gpu.set_option("dense", 1)
         gpu.set_option("far_predict", 1)
         gpu.set_option("flat_tiles", 1)
+
+
+def test_device_side_habit_follows_the_scene(gpu):
+    """A floor under noise: no tile qualifies, the votes close the gate within a build or two (every 64th tile keeps trying); the room
+    after it: every tile qualifies and the gate is open again a build or two later.  Every build along the way is exact."""
+    import torch
+    shape, res = (64, 256, 128), 0.01
+    s = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(shape, dtype=torch.float32, device="cuda")
+    noisy = synth.bernoulli_mask(shape, 0.002, 4)
+    noisy[:, :, 0] = 1
+    room = synth.room_mask_torch(shape, "cpu").numpy()
+    try:
+        gpu.set_option("policy_reset", 1)
+        gpu.set_option("dense", 0)
+        gpu.set_option("far_predict", 2)
+        gpu.set_option("flat_tiles", 1)
+        seen = []
+        for m in (noisy, room, noisy):
+            ex, ex_ext, _ = O.exact_sdf(m, res, False)
+            mt = torch.from_numpy(m).cuda()
+            for _ in range(4):
+                gpu.build_device(mt.data_ptr(), shape, out.data_ptr(), res, False, s)
+                assert np.array_equal(out.cpu().numpy(), ex) and gpu.get_extrema() == ex_ext
+            gpu.build_device(mt.data_ptr(), shape, out.data_ptr(), res, False, s)
+            seen.append(gpu.debug_flat_habit())
+        assert seen[0][1] == 0 and seen[1][1] == 1 and seen[2][1] == 0, seen
+    finally:
+        gpu.set_option("dense", 1)
+        gpu.set_option("far_predict", 1)

@@ -3,7 +3,8 @@
 (option dense=0: K1 -> probe -> K2/16 -> K3/16) on the headline grids, alternating the libraries repetition by repetition,
 so that a box's own drift shows up in both columns.  Only entry points that every round's library has are bound.
 
-usage: sweep_tier_ab.py A=<path> B=<path> [n=512] [reps=6] [steps=50] [opt=value ...]
+usage: sweep_tier_ab.py A=<path> B=<path> [n=512] [reps=6] [steps=50] [scene=...] [opt=value ...] [A:opt=value | B:opt=value ...]
+(the same path twice with an A: / B: option = an A/B of that option inside one library)
 prints one JSON line per (rep, library) and a summary line."""
 import ctypes
 import json
@@ -21,13 +22,14 @@ n = int(kv.pop("n", 512))
 reps = int(kv.pop("reps", 6))
 steps = int(kv.pop("steps", 50))
 scene_arg = kv.get("scene")
-opts = {k: int(v) for k, v in kv.items() if k != "scene"} or {"dense": 0}
+only = {"A": {k[2:]: int(v) for k, v in kv.items() if k.startswith("A:")}, "B": {k[2:]: int(v) for k, v in kv.items() if k.startswith("B:")}}
+opts = {k: int(v) for k, v in kv.items() if k != "scene" and k[1:2] != ":"} or {"dense": 0}
 kv = {"scene": scene_arg} if scene_arg else {}
 vp, i64, dbl, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int
 STAGES = ["pack_bits", "dense_ball", "sweep_z", "sweep_y", "envelope_y", "sweep_x", "envelope_x"]
 
 
-def bind(path):
+def bind(path, extra):
     L = ctypes.CDLL(os.path.abspath(path))
     L.sdfgpu_create.argtypes = [ci, ctypes.POINTER(vp)]
     L.sdfgpu_destroy.argtypes = [vp]
@@ -39,7 +41,7 @@ def bind(path):
     L.sdfgpu_last_error.restype = ctypes.c_char_p
     h = vp()
     assert L.sdfgpu_create(0, ctypes.byref(h)) == 0
-    for k, v in opts.items():
+    for k, v in list(opts.items()) + list(extra.items()):
         assert L.sdfgpu_set_option(h, k.encode(), v) == 0, (path, k, L.sdfgpu_last_error(h))
     return L, h
 
@@ -61,11 +63,17 @@ if scene == "twobox":                       # the streaming scene: 200 k points 
         masks.append(torch.from_numpy(m).to(dev))
 elif scene == "room":
     masks = [synth.room_mask_torch(shape, dev)] * 3
+elif scene == "noisyfloor":                 # a floor under 0.05 % noise: every x-plane "has a filled voxel in every row", no tile is two-valued
+    masks = []
+    for k in range(3):
+        m = synth.bernoulli_mask_torch(shape, 0.0005, 1 + k, device=dev)
+        m[:, :, :2] = 1
+        masks.append(m)
 else:
     masks = [synth.bernoulli_mask_torch(shape, 0.5, 1 + k, device=dev) for k in range(3)]
 out = {k: torch.empty(shape, dtype=torch.float32, device=dev) for k in libs}
 stream = torch.cuda.current_stream(dev).cuda_stream
-ctx = {k: bind(p) for k, p in libs.items()}
+ctx = {k: bind(p, only[k]) for k, p in libs.items()}
 
 
 def run(key, count):
@@ -101,7 +109,7 @@ for rep in range(reps):
         acc[key]["ms"].append(ms)
         acc[key]["stages"].append(st)
         print(json.dumps({"rep": rep, "lib": key, "path": libs[key], "ms_per_build": round(ms, 4), "stages_ms": st}), flush=True)
-summary = {"n": n, "scene": scene, "options": opts, "steps": steps}
+summary = {"n": n, "scene": scene, "options": opts, "only": only, "steps": steps}
 for key in libs:
     v = sorted(acc[key]["ms"])
     summary[key] = {"path": libs[key], "ms_min": round(v[0], 4), "ms_median": round(v[len(v) // 2], 4), "ms_max": round(v[-1], 4),

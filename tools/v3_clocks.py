@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Phase clocks of the far-field kernels (needs a library built with SDFGPU_EXTRA_FLAGS=-DSDFGPU_PHASE_CLOCKS):
-share of the waves' shader-clock time per phase.  usage: v3_clocks.py [stream|<bernoulli p>] [name=value ...]"""
+share of the waves' shader-clock time per phase.  usage: v3_clocks.py [stream|room[n]|<bernoulli p>] [name=value ...]
+(two-valued tiles: levelA = classification, levelB = nearest-site scans, scanC = distance chains)"""
 import ctypes
 import json
 import os
@@ -20,6 +21,9 @@ if kind == "stream":
     pts = torch.from_numpy(synth.two_box_points(200000, seed=0, scale=n * res)).to(dev)
     mask = torch.zeros((n, n, n), dtype=torch.uint8, device=dev)
     ctx.voxelize_points_device(pts.data_ptr(), pts.shape[0], (0.0, 0.0, 0.0), res, (n, n, n), mask.data_ptr(), True, s)
+elif kind.startswith("room"):
+    n = int(kind[4:] or 512)
+    mask = synth.room_mask_torch((n, n, n), dev)
 else:
     mask = synth.bernoulli_mask_torch((n, n, n), float(kind), 1, device=dev)
 out = torch.empty((n, n, n), dtype=torch.float32, device=dev)
@@ -27,7 +31,8 @@ ctx.set_option("policy_reset", 1)
 ctx.set_option("dense", 0)
 for kv in sys.argv[2:]:
     ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-ctx.set_option("envelope_mode", 1)
+if not any(a.startswith("far_predict=") for a in sys.argv[2:]):
+    ctx.set_option("envelope_mode", 1)
 lib = ctx._lib
 lib.sdfgpu_debug_read_clocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 buf = (ctypes.c_ulonglong * 16)()
