@@ -41,9 +41,12 @@ while time.time() - t0 < budget:
     if rng.random() < 0.08:                                              # long x / y lines: the far-field kernel's levels with one interval
         a, b = int(rng.choice([300, 512, 520, 777, 1024])), int(rng.choice([1, 2, 5, 9]))     # per lane (> 512) / two lanes per interval, wave-cooperative scans
         shape = ((a, b) if rng.random() < 0.5 else (b, a)) + (int(rng.choice([16, 32, 64])),)
+    floor_scene = rng.random() < 0.12                                    # round 6: floors (see kind 5)
+    if floor_scene:
+        shape = (int(rng.choice([8, 9, 16, 33, 64])), int(rng.choice([8, 21, 64, 100, 130, 256, 512, 515, 777, 1024])), int(rng.choice([64, 64, 128])))
     if np.prod(shape) > 1 << 21:
         continue
-    kind = rng.integers(0, 5)
+    kind = 5 if floor_scene else rng.integers(0, 5)
     if kind == 4:
         # round 5: axis-aligned slabs (floors / walls, whole extent in two axes), solid boxes and box shells, optionally a few noise
         # voxels -- the far-field kernel's flat-stretch shortcut (plateaus of the sweep's input with jumps and holes, unit steps
@@ -66,6 +69,29 @@ while time.time() - t0 < budget:
             m |= (rng.random(shape) < 0.002).astype(np.uint8)
         if rng.random() < 0.2:
             m = 1 - m
+    elif kind == 5:
+        # round 6: a floor (every z row holds a filled voxel: the far-field pair's row flags say "floor-like") under walls, plates,
+        # steps and pillars -- y lines with one, two and more values outside their zero sites, zero sites at chunk edges -- and now
+        # and then noise or a hole in the floor: the two-valued tiles of the far-field y sweep, with their habit open, closed and forced
+        m = np.zeros(shape, np.uint8)
+        m[:, :, :int(rng.integers(1, 4))] = 1
+        for _ in range(int(rng.integers(0, 5))):
+            what = int(rng.integers(0, 4))
+            x0, x1 = sorted(int(v) for v in rng.integers(0, shape[0] + 1, 2))
+            y0, y1 = sorted(int(v) for v in rng.integers(0, shape[1] + 1, 2))
+            z0 = int(rng.integers(0, shape[2]))
+            if what == 0:
+                m[:, y0:y0 + int(rng.integers(1, 12)), :] = 1                     # a wall across y lines
+            elif what == 1:
+                m[x0:x1 + 1, y0:y1 + 1, z0:z0 + int(rng.integers(1, 4))] = 1     # a plate
+            elif what == 2:
+                m[x0:x1 + 1, y0:y1 + 1, :z0] = 1                                  # a step
+            else:
+                m[x0:x1 + 1:3, int(rng.choice([0, 7, 8, 9, 63, 64, y0])) % shape[1], :] = 1     # pillars
+        if rng.random() < 0.25:
+            m |= (rng.random(shape) < 0.001).astype(np.uint8)
+        if rng.random() < 0.1:
+            m[int(rng.integers(0, shape[0])), int(rng.integers(0, shape[1])), :] = 0
     elif kind == 0:
         m = synth.bernoulli_mask(shape, float(rng.choice([0.5, 0.3, 0.1, 0.05, 0.03, 0.02, 0.01, 0.001, 0.9, 0.96, 0.99, 0.999])), int(rng.integers(1 << 30)))
     elif kind == 1:
@@ -105,6 +131,12 @@ while time.time() - t0 < budget:
     # staged from the bit field + far-field x sweep, LOOP form) with small and large stand-by grids, or the old stand-by
     ctx.set_option("dc_fixed", int(rng.random() < 0.7))         # round 5: far-field instances with a compile-time line length (512)
     ctx.set_option("far_predict", int(rng.choice([0, 1, 2, 2])))   # round 5: the far-field pair without probes (learnt / forced)
+    ctx.set_option("plane_skip", int(rng.random() < 0.85))      # round 6: row / plane flags of the far-field pair, the two-valued tiles behind them
+    ctx.set_option("flat_tiles", int(rng.choice([0, 1, 1, 2, 2])))
+    if floor_scene:
+        for k, v in (("dense", 0), ("far_predict", 2), ("envelope", 1), ("envelope_mode", 0), ("z_wave", 1)):
+            if rng.random() < 0.8:
+                ctx.set_option(k, v)
     ctx.set_option("standby_far", int(rng.random() < 0.85))
     ctx.set_option("standby_grid", int(rng.choice([32, 64, 1024])))
     if rng.random() < 0.4:
