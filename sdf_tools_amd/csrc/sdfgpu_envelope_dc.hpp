@@ -1442,7 +1442,8 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         const uint32_t ent = flist[e];
                         const int fl = (int)(ent >> 28), p = (int)((ent >> 12) & 0xffffu);
                         int D1 = (int)(ent & 0xfffu);           // (saturated at kDcLocalSat: then only a candidate found below can finish the voxel)
-                        // offsets in rounds of 4 (8 loads in flight; D1 <= 1023: at most 8 rounds).  A candidate beyond the bound that
+                        // offsets in rounds of 4 (8 loads in flight; D1 <= 1023: at most 8 rounds).  (Round 6 measured rounds of 8 in the y sweep: slower
+                        // on every scene -- room y sweep +3 %, two-box +5 %.)  A candidate beyond the bound that
                         // rides along in a round is still a candidate: harmless.
 #ifdef SDFGPU_DEBUG_HOOKS
                         if (a.dbg & 64) D1 = 1;                 // profiling builds: bit 6 = no local-search rounds (wrong results)
