@@ -557,7 +557,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
     uint32_t* const keys = dc_smem;                             // [16][pitch]
     uint32_t* const args = keys + NL * pitch;                   // [M + 2][16]  best value (distance << B | argmin) of coarse position 8 i
     uint32_t* const misc = args + (M + 2) * NL;                 // per wave: [0..7] span lo, [8..15] span hi, [16..23] smallest site value; [24] filled voxels listed, [25] second pass wanted, [26..28] probe
-    uint32_t* const fl_mn = misc + 48;                          // [16] per line: smallest non-zero entry (flat-positive test), ...
+    uint32_t* const fl_mn = misc + 48;                          // [16] per line: smallest non-zero entry MINUS ONE (0xFFFFFFFF: none), ...
     uint32_t* const fl_mx = misc + 64;                          // [16] ... largest entry
     uint32_t* const flist = misc + kDcMisc;                         // [kDcLocalFilled] filled voxels of pass 0: line << 28 | p << 12 | min(S, kDcLocalSat)
     const int t = threadIdx.x;
@@ -915,10 +915,9 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 }
                 if (cls == 0 && flat_try) {                     // (block-uniform) smallest non-zero and largest entry of each line
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t f = inl ? F[k] : 0u;
-                        fmx[k] = umax(fmx[k], f);
-                        fmn[k] = umin(fmn[k], f ? f : 0xFFFFFFFFu);
+                    for (int k = 0; k < 4; ++k) {               // (rows past the end of the line re-read its last row: harmless here)
+                        fmx[k] = umax(fmx[k], F[k]);
+                        fmn[k] = umin(fmn[k], F[k] - 1u);       // F - 1: a zero entry wraps to the identity of the minimum
                     }
                 }
                 const uint32_t fmin4 = inl ? umin(umin(F[0], F[1]), umin(F[2], F[3])) : finf;
@@ -983,11 +982,12 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         uint32_t zm = 0u, lm = 0u;                              // zero sites / mn sites of this lane's chunks, 8 bits per round of level C
         if (cls == 0 && flat_try && act) {
             const uint32_t* kl = keys + lineT * pitch;
-            const uint32_t mn = fl_mn[lineT], mx = fl_mx[lineT];
+            const uint32_t mn1 = fl_mn[lineT], mx = fl_mx[lineT];
+            const uint32_t mn = mn1 == 0xFFFFFFFFu ? mn1 : mn1 + 1u;
             // does any line hold two values at all?  (block-uniform: every lane reads the same 32 words.)  A tile of one-valued lines --
             // half of the room's -- does without the mn sites: mn = mx, and min(mx, d0^2) is the whole answer
 #pragma unroll
-            for (int l = 0; l < NL; ++l) { const uint32_t a1 = fl_mn[l], b1 = fl_mx[l]; two = two || (b1 != 0u && a1 != b1); }
+            for (int l = 0; l < NL; ++l) { const uint32_t a1 = fl_mn[l] + 1u, b1 = fl_mx[l]; two = two || (b1 != 0u && a1 != b1); }
             bool other = false;
             int n = 0;
 #ifdef SDFGPU_DEBUG_HOOKS
@@ -1001,6 +1001,23 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                     uint32_t cz = mad_i24(pc0, pc0, (uint32_t)(h * h));
                     int inc = 2 * pc0 + 1;
                     uint32_t z8 = 0u;
+                    if (kAllIn || p0 + 8 <= L) {
+                        // whole chunk inside the line: arithmetic instead of compares -- min(e, 1) is the "not a zero site" bit, and
+                        // min(e, e ^ mx) is non-zero iff the entry is neither 0 nor mx
+                        uint32_t nz = 0u, bad = 0u;
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) {
+                            const uint2 kk = *reinterpret_cast<const uint2*>(kl + p0 + k);
+                            const uint32_t f0 = (kk.x >> B) - cz;
+                            cz += (uint32_t)inc; inc += 2;
+                            const uint32_t f1 = (kk.y >> B) - cz;
+                            cz += (uint32_t)inc; inc += 2;
+                            nz |= (umin(f0, 1u) << k) | (umin(f1, 1u) << (k + 1));
+                            bad |= umin(f0, f0 ^ mx) | umin(f1, f1 ^ mx);
+                        }
+                        z8 = ~nz & 0xFFu;
+                        other = other || bad != 0u;
+                    } else {
 #pragma unroll
                     for (int k = 0; k < 8; k += 2) {
                         const uint2 kk = *reinterpret_cast<const uint2*>(kl + p0 + k);
@@ -1008,10 +1025,11 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                         cz += (uint32_t)inc; inc += 2;
                         const uint32_t f1 = (kk.y >> B) - cz;
                         cz += (uint32_t)inc; inc += 2;
-                        const bool in0 = kAllIn || p0 + k < L, in1 = kAllIn || p0 + k + 1 < L;
+                        const bool in0 = p0 + k < L, in1 = p0 + k + 1 < L;
                         z8 |= ((f0 == 0u && in0) ? 1u : 0u) << k;
                         z8 |= ((f1 == 0u && in1) ? 1u : 0u) << (k + 1);
                         other = other || (in0 && f0 != 0u && f0 != mx) || (in1 && f1 != 0u && f1 != mx);
+                    }
                     }
                     zm |= z8 << (8 * n);
                 }
@@ -1023,6 +1041,24 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                 uint32_t cz = mad_i24(pc0, pc0, (uint32_t)(h * h));        // the position's own term (p - h)^2 + h^2: F = (key >> B) - cz
                 int inc = 2 * pc0 + 1;
                 uint32_t z8 = 0u, l8 = 0u;
+                if (kAllIn || p0 + 8 <= L) {
+                    uint32_t nz = 0u, nl = 0u, bad = 0u;
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        const uint2 kk = *reinterpret_cast<const uint2*>(kl + p0 + k);
+                        const uint32_t f0 = (kk.x >> B) - cz;
+                        cz += (uint32_t)inc; inc += 2;
+                        const uint32_t f1 = (kk.y >> B) - cz;
+                        cz += (uint32_t)inc; inc += 2;
+                        const uint32_t x0 = f0 ^ mn, x1 = f1 ^ mn;
+                        nz |= (umin(f0, 1u) << k) | (umin(f1, 1u) << (k + 1));
+                        nl |= (umin(x0, 1u) << k) | (umin(x1, 1u) << (k + 1));
+                        bad |= umin(umin(f0, x0), f0 ^ mx) | umin(umin(f1, x1), f1 ^ mx);
+                    }
+                    z8 = ~nz & 0xFFu;
+                    l8 = ~nl & 0xFFu;
+                    other = other || bad != 0u;
+                } else {
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) {
                     const uint2 kk = *reinterpret_cast<const uint2*>(kl + p0 + k);
@@ -1030,12 +1066,13 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                     cz += (uint32_t)inc; inc += 2;
                     const uint32_t f1 = (kk.y >> B) - cz;
                     cz += (uint32_t)inc; inc += 2;
-                    const bool in0 = kAllIn || p0 + k < L, in1 = kAllIn || p0 + k + 1 < L;
+                    const bool in0 = p0 + k < L, in1 = p0 + k + 1 < L;
                     z8 |= ((f0 == 0u && in0) ? 1u : 0u) << k;
                     z8 |= ((f1 == 0u && in1) ? 1u : 0u) << (k + 1);
                     l8 |= ((f0 == mn && in0) ? 1u : 0u) << k;
                     l8 |= ((f1 == mn && in1) ? 1u : 0u) << (k + 1);
                     other = other || (in0 && f0 != 0u && f0 != mn && f0 != mx) || (in1 && f1 != 0u && f1 != mn && f1 != mx);
+                }
                 }
                 zm |= z8 << (8 * n);
                 lm |= l8 << (8 * n);
@@ -1252,7 +1289,8 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
                     // is a zero or mn site, and then one of the other two terms is already smaller)
                     const int ic = imin(i, M - 1), MP = M + 2;
                     const uint32_t z8 = (zm >> (8 * n)) & 0xFFu, l8 = (lm >> (8 * n)) & 0xFFu;
-                    const uint32_t mn = fl_mn[lineT], mx = fl_mx[lineT];
+                    const uint32_t mn1 = fl_mn[lineT], mx = fl_mx[lineT];
+                    const uint32_t mn = mn1 == 0xFFFFFFFFu ? mn1 : mn1 + 1u;
                     int lz = (int)keys[(2 * NL + lineT) * MP + ic], rz = (int)keys[(3 * NL + lineT) * MP + ic];
                     int ll = 0, rl = 0;
                     if (two) { ll = (int)keys[(4 * NL + lineT) * MP + ic]; rl = (int)keys[(5 * NL + lineT) * MP + ic]; }
