@@ -107,6 +107,8 @@ struct EnvDcArgs {
     int64_t group_lines;      // lines per outer unit (tiles that stick out replicate the last line)
     unsigned long long* clocks;   // SDFGPU_PHASE_CLOCKS builds only: per-phase shader-clock sums over waves ([stage - 2][8])
     int dbg;                  // SDFGPU_DEBUG_HOOKS builds only (wrong results): bit0 no search, bit1 no fp64 finish, bit2 no stores, bit3 no level-C scans, bit4 no level-B scans (with bit3)
+                              // bit5 the y sweep's stores to one block per tile, bit6 no local-search rounds; two-valued tiles: bit7 path off (results stay right),
+                              // bit8 no distance chains, bit9 no nearest-site scans, bit10 no classification
     int64_t ntiles;           // LOOP form: tiles of the whole launch (a workgroup takes tiles blockIdx.x, + gridDim.x, ...)
     const uint32_t* bits;     // STAGE 2, scalar (VEC = false) form only: the dense tier's bit field ([x][y][nzw] words, bit i of word w =
     int nzw;                  // voxel z = 32 w + i is filled) INSTEAD of the z field: the stand-by behind a trusted dense tier computes
