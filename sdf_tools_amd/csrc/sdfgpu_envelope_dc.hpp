@@ -545,7 +545,10 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
         wgate = __hip_atomic_load(a.flat_score + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const bool rows_known = STAGE == 2 && a.row_bits && w19 != 0u;
-    const bool floorlike = STAGE == 2 && a.row_bits && a.flat_on && w19 == 0u;
+    // (lines longer than 512: any scene may try -- boxes in open space have two-valued y lines too, c over the box and "no site" beside it:
+    //  y sweep 1.73 -> 1.48 ms at 1024^3, shells 1.12 -> 1.00; at 512^3 the path costs what the search costs there: shells +8 %.  The habit
+    //  closes the gate on scenes that do not qualify either way.)
+    const bool floorlike = STAGE == 2 && a.row_bits && a.flat_on && (w19 == 0u || (LC ? LC : a.L) > 512);
     const bool flat_gate = floorlike && (a.flat_on == 2 || wgate != 0u);
     if (a.probe_stride > 0 && a.i32_flag && i32) { probe_done(a); return; }       // the x tier is already decided: no probe
     if (a.probe_stride > 0 && STAGE == 3 && a.decide_small &&
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
             }
         }
     }
-    // two-valued tiles (see EnvDcArgs::flat_on): tried when every z row of the grid holds a filled voxel -- a floor (block-uniform)
+    // two-valued tiles (see EnvDcArgs::flat_on): tried when every z row of the grid holds a filled voxel -- a floor -- or the lines are long (block-uniform)
     bool flat_try = false;
     uint32_t flat_hash = 0u;
     if constexpr (STAGE == 2 && NL == 16 && VEC && !LOOP) {
