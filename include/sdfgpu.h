@@ -448,8 +448,9 @@ int sdfgpu_get_stage_times(sdfgpu_handle h, double* out_ms_sum, int64_t* out_bui
  *  "dc_fixed"                [AB]     1        far-field kernel: instances with the 512- / 1024-voxel line geometry at compile time
  *  "plane_skip"              [AB]     1        builds that go straight to the far-field pair skip the x-planes without a filled voxel
  *  "flat_tiles"              [AB]     1        ... and their y sweep skips its search in tiles whose lines hold at most two values outside
- *                                              their zero sites (a floor under open space, table tops); 1: while it pays (a device-side
- *                                              habit, sdfgpu_debug_flat_habit), 2: every candidate tile tries, 0: never
+ *                                              their zero sites (a floor under open space, table tops, boxes in open space); tried on
+ *                                              grids with a floor and, for y lines longer than 512, on any scene; 1: while it pays (a
+ *                                              device-side habit, sdfgpu_debug_flat_habit), 2: every candidate tile tries, 0: never
  *
  *  host side / debugging
  *  "host_pack"               [U]      1        host-buffer builds classify on the host and upload 1 bit / voxel (0: upload + classify on
