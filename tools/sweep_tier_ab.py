@@ -63,6 +63,9 @@ if scene == "twobox":                       # the streaming scene: 200 k points 
         masks.append(torch.from_numpy(m).to(dev))
 elif scene == "room":
     masks = [synth.room_mask_torch(shape, dev)] * 3
+elif scene in ("boxes", "shells", "spheres"):      # tools/scene_bench.py's structured scenes
+    m = (synth.solid_spheres_mask_torch(shape, dev) if scene == "spheres" else synth.tutorial_boxes_mask_torch(shape, dev, scene == "boxes"))
+    masks = [m] * 3
 elif scene == "noisyfloor":                 # a floor under 0.05 % noise: every x-plane "has a filled voxel in every row", no tile is two-valued
     masks = []
     for k in range(3):
