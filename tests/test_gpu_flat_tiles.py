@@ -49,6 +49,14 @@ def _scenes(shape):
     m[:, ny // 3:, nz // 3] = 1
     m[::3, ::7, :nz // 2] = 1
     out["floor_plate_pillars"] = m
+    m = np.zeros(shape, np.uint8)                       # walls of whole rows across the lines, thin and thicker than the 31 voxels pass 0
+    m[:, :, 0] = 1                                      # finishes itself (deeper ones are the second pass's), at both ends and in the middle
+    m[:, :min(3, ny), :] = 1
+    m[:, max(ny - 5, 0):, :] = 1
+    if ny >= 100:
+        m[:, ny // 3:ny // 3 + 70, :] = 1
+        m[nx // 2, ny // 3 + 30:ny // 3 + 33, nz // 2:] = 0     # ... with a pocket inside: filled voxels that are NOT saturated next to it
+    out["walls_thin_and_thick"] = m
     m = np.zeros(shape, np.uint8)                       # a floor with one voxel missing under one line: "every row holds a filled voxel" fails there
     m[:, :, 0] = 1
     m[nx // 2, ny // 2, 0] = 0
