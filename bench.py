@@ -830,6 +830,13 @@ def main():
                                                                   "(BASELINE configs[3]'s workload; its 8-GPU partition is --gpus 8)")
                     del m1k
                     torch.cuda.empty_cache()
+                    # ... and the room at that size: the far-field pair on 1024-voxel lines (round 6: its y sweep no longer searches
+                    # the open volume above the floor -- two-valued tiles)
+                    r1k = [synth.room_mask_torch(s1k, dev)]
+                    legs["structured_room_1024"] = run_leg(torch, capi, dev, s1k, res, r1k, {}, 10, 8,
+                                                           "1024x1024x1024 room scene (as structured_room), default policy, ONE GPU")
+                    del r1k
+                    torch.cuda.empty_cache()
             except Exception as e:
                 legs["config_1024_cube_single_gpu"] = {"error": repr(e)}
         except Exception as e:                     # a leg must never take the contract line down with it
