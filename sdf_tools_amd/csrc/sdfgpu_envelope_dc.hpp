@@ -981,7 +981,7 @@ __global__ __launch_bounds__(NT, WPS) void k_envelope_dc(const EnvDcArgs a) {
 #endif
         // Two-valued tiles.  Every lane classifies the positions of its chunks against its line's smallest non-zero entry mn and
         // largest entry mx: zero site, mn site, mx site -- or something else, and then the tile is searched as usual (the keys
-        // are untouched until the verdict; the classification costs ~2 % of a searched tile).
+        // are untouched until the verdict; tracking + classification cost a searched tile ~15 %: hence the habit, EnvDcArgs::flat_score).
         bool flat = false, two = false;
         constexpr bool kAllIn = LC != 0 && LC % 8 == 0;          // (every position of every chunk lies inside the line)
         uint32_t zm = 0u, lm = 0u;                              // zero sites / mn sites of this lane's chunks, 8 bits per round of level C
